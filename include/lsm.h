@@ -1,0 +1,183 @@
+/*
+ * lsm.h — C ABI of libhiplsm: the MI355X (gfx950) grid-update hot path of
+ * LevelSetMethods.jl behind plain pointers and sizes.
+ *
+ * The reference has no FFI: its seam is Julia multiple dispatch on the field type
+ * (AbstractMeshField interface, src/meshfield.jl:11-33).  The entry points below are what a
+ * device-resident AbstractMeshField subtype would `ccall` from the methods the integrator
+ * reaches the field through.  Each declaration cites the reference code whose
+ * loop body it replaces.  No torch/HIP types appear in signatures; `stream` is a hipStream_t
+ * passed as void* (NULL = the handle's own stream).
+ *
+ * Conventions
+ *  - All field pointers are DEVICE pointers to arrays in the *padded layout* described by
+ *    LsmLayout (column-major like Julia's Array, dim 1 fastest, LSM_GHOST ghost layers on each
+ *    side of every used dimension).  The caller owns the memory (AMDGPU.jl ROCArray / torch
+ *    tensor); the library borrows pointers for the duration of a call.
+ *  - Every call returns LSM_OK (0) or a negative error code; lsm_last_error() gives the text.
+ *    The library never throws or aborts.
+ *  - Calls are asynchronous on the handle's stream unless documented otherwise; calls that
+ *    return a host value (lsm_compute_cfl, lsm_download) synchronise.
+ */
+#ifndef LSM_H
+#define LSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSM_MAX_DIM 3
+#define LSM_GHOST 3          /* ghost layers per side: WENO5 needs 3 (src/derivatives.jl:89-121) */
+#define LSM_MAX_TERMS 8
+
+/* status codes */
+enum {
+    LSM_OK = 0,
+    LSM_ERR_INVALID = -1,    /* bad argument / unsupported combination */
+    LSM_ERR_HIP = -2,        /* a HIP runtime call failed */
+    LSM_ERR_NO_DEVICE = -3
+};
+
+/* CartesianGrid (src/meshes.jl:1-5): lower/upper corner and node counts of the GLOBAL grid.
+ * meshsize h_d = (hc_d - lc_d)/(n_d - 1) (src/meshes.jl:109-110). */
+typedef struct LsmGrid {
+    int32_t ndim;                 /* 1, 2 or 3 */
+    int32_t _pad;
+    int64_t n[LSM_MAX_DIM];       /* unused dims must be 1 */
+    double lc[LSM_MAX_DIM];
+    double hc[LSM_MAX_DIM];
+} LsmGrid;
+
+/* BoundaryCondition kinds (src/boundaryconditions.jl:27,40-46,63).  LSM_BC_NONE marks a slab
+ * interface of a multi-GPU decomposition: its ghosts come from the halo exchange, the ghost
+ * fill skips it. */
+enum { LSM_BC_PERIODIC = 0, LSM_BC_EXTRAPOLATION = 1, LSM_BC_SYMMETRY = 2, LSM_BC_NONE = 3 };
+typedef struct LsmBc {
+    int32_t kind;
+    int32_t degree;               /* P of ExtrapolationBC{P}; 0 = NeumannBC, 1 = LinearExtrapolationBC */
+} LsmBc;
+
+/* Slab of the last dimension owned by this handle (multi-GPU); lo is 0-based. */
+typedef struct LsmSlab {
+    int64_t lo;
+    int64_t n;
+} LsmSlab;
+
+/* Padded device layout of one scalar field. element(i1,i2,i3) (0-based LOCAL interior index,
+ * ghosts at -LSM_GHOST..-1 and n..n+LSM_GHOST-1) lives at origin + i1 + i2*stride[1] + i3*stride[2]. */
+typedef struct LsmLayout {
+    int64_t n[LSM_MAX_DIM];       /* local interior extent */
+    int64_t g[LSM_MAX_DIM];       /* ghost width per dim (0 for unused dims) */
+    int64_t stride[LSM_MAX_DIM];  /* stride[0] == 1 */
+    int64_t origin;               /* offset of interior node (0,0,0) */
+    int64_t total;                /* elements to allocate */
+} LsmLayout;
+
+/* LevelSetTerm kinds (src/levelsetterms.jl:45,104,139,211) and SpatialScheme (src/derivatives.jl:11,20) */
+enum { LSM_TERM_ADVECTION = 0, LSM_TERM_NORMAL_MOTION = 1, LSM_TERM_CURVATURE = 2, LSM_TERM_EIKONAL = 3 };
+enum { LSM_SCHEME_UPWIND = 0, LSM_SCHEME_WENO5 = 1 };
+
+/* Coefficient of a term (velocity / speed / b), the device-side counterpart of
+ * _eval_field (src/levelsetterms.jl:42-43).  Julia closures cannot run on the device, so:
+ *   CONST      value[c]                                         (e.g. (x,t)->SVector(1.0))
+ *   ROTATION   u1 = -(w*(x2-c2)), u2 = w*(x1-c1), u3 = 0         with w=value[0], c=value[1..2]
+ *   SEPARABLE  u_c = ((T_c1[i1]*T_c2[i2])*T_c3[i3]) * g(t)       tables on the device, GLOBAL index;
+ *              sep[c] points to the n1+n2+n3 concatenated doubles of component c
+ *              g(t) = 1 (time_kind 0) or cos(pi*t/time_param) (time_kind 1)
+ *   FIELD      field[c] = padded device array (same layout as phi), read in-grid only
+ * Node coordinates are x_d = lc_d + i_d*h_d (src/meshes.jl:114-117). */
+enum { LSM_COEFF_CONST = 0, LSM_COEFF_ROTATION = 1, LSM_COEFF_SEPARABLE = 2, LSM_COEFF_FIELD = 3 };
+enum { LSM_TIME_ONE = 0, LSM_TIME_COS = 1 };
+typedef struct LsmCoeff {
+    int32_t kind;
+    int32_t time_kind;
+    double time_param;
+    double value[4];
+    const void* field[LSM_MAX_DIM];
+    const double* sep[LSM_MAX_DIM];
+} LsmCoeff;
+
+typedef struct LsmTerm {
+    int32_t kind;                 /* LSM_TERM_* */
+    int32_t scheme;               /* LSM_SCHEME_* (advection only) */
+    LsmCoeff coeff;               /* velocity (ndim comps) / speed / b (1 comp); unused for Eikonal */
+    const void* s0;               /* Eikonal frozen sign field S0 (padded, src/levelsetterms.jl:217-221) or NULL */
+} LsmTerm;
+
+/* How a stage forms its base value before subtracting the terms (src/timestepping.jl:126-202):
+ *   PSI     base = psi[I]                          (FE, RK2 predictor, RK3 stage 1; :129,:147,:172)
+ *   RK3_S2  base = 0.75*phin[I] + 0.25*psi[I]      (:182)
+ *   RK3_S3  base = (phin[I] + 2*psi[I]) / 3        (:193)
+ *   OTHER   base = phin[I]                         (RK2 corrector accumulates onto corr; :160)
+ */
+enum { LSM_BASE_PSI = 0, LSM_BASE_RK3_S2 = 1, LSM_BASE_RK3_S3 = 2, LSM_BASE_OTHER = 3 };
+
+/* arithmetic mode (lsm_create flags) */
+enum {
+    LSM_MODE_FAST = 0,    /* default: reciprocal-based divisions, FMA contraction, fused WENO weights;
+                             within 1e-13*max|phi| of the reference arithmetic per stage */
+    LSM_MODE_STRICT = 1   /* literal reference operation order, IEEE division, no contraction */
+};
+enum { LSM_DTYPE_F64 = 0, LSM_DTYPE_F32 = 1 };
+
+typedef struct LsmHandle LsmHandle;
+
+/* Host callback run between stage launches so host-side update_func hooks keep their
+ * (stage field, stage time) semantics (src/timestepping.jl:131,149,158,174,185,196).
+ * Called with the stream synchronised. Return non-zero to abort the step. */
+typedef int (*LsmStageHook)(void* user, int stage, const void* stage_field, double stage_time);
+
+/* ---- lifetime (LevelSetEquation construction, src/levelsetequation.jl:59-78) ---- */
+int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSlab* slab /* NULL = whole grid */,
+               int dtype, int mode, int device, LsmHandle** out);
+void lsm_destroy(LsmHandle* h);
+const char* lsm_last_error(const LsmHandle* h /* NULL = creation errors */);
+const char* lsm_version(void);
+int lsm_sync(LsmHandle* h);
+
+/* ---- layout + transfers (MeshField <-> device field; values(ϕ), src/meshfield.jl:58) ---- */
+int lsm_layout(const LsmHandle* h, LsmLayout* out);
+int lsm_upload(LsmHandle* h, void* dev_padded, const void* host_dense);     /* interior only; synchronous */
+int lsm_download(LsmHandle* h, const void* dev_padded, void* host_dense);   /* interior only; synchronous */
+
+/* ---- ghost resolution: _getindexbc + bc_stencil (src/meshfield.jl:248-260,
+ *      src/boundaryconditions.jl:107-153) materialised into the ghost layers, dim 1 -> dim N.
+ *      dim_mask bit d fills dimension d+1 (7 = all). */
+int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream);
+
+/* ---- one loop body of _advance! (src/timestepping.jl:128-137,143-164,170-202), all terms fused:
+ *      out[I]  = (base - cdt*L_1(psi)[I]) - cdt*L_2(psi)[I] ...
+ *      out2[I] = (psi[I] - cdt2*L_1) - cdt2*L_2 ...   (RK2's corr accumulator; NULL to skip)
+ *      psi needs valid ghosts; out/out2 ghosts are NOT filled. out may alias phin (pointwise). */
+int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin,
+              void* out, void* out2, int base_mode, double cdt, double cdt2, double t_stage, void* stream);
+
+/* ---- compute_cfl (src/levelsetterms.jl:22-38,90-96,123-127,172-178,250).  *dt_out is the raw
+ *      minimum (Inf, NaN and <=0 possible): the CALLER raises the reference's ArgumentError. */
+int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, double t, double* dt_out);
+
+/* ---- _advance! per integrator.  phi's ghosts are (re)filled on entry and valid on return.
+ *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63). */
+int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1,
+                   double tc, double dt, LsmStageHook hook, void* user);
+int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2,
+                    double tc, double dt, LsmStageHook hook, void* user);
+int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2,
+                    double tc, double dt, LsmStageHook hook, void* user);
+
+/* ---- EikonalReinitializationTerm(ϕ₀) constructor map: S0 = v/sqrt(v^2+Δx^2) (src/levelsetterms.jl:217-221) */
+int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream);
+
+/* ---- min/max of the interior, for show (src/meshfield.jl:300-303) ---- */
+int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax);
+
+/* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
+int lsm_profile_enable(LsmHandle* h, int on);
+int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total);   /* synchronises; resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSM_H */
