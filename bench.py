@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py — Mcells/s per RK3 step of the headline equation (BASELINE.json):
+WENO5 advection by the vortex-deformation field + Eikonal reinitialisation, fp64, RK3, NeumannBC.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N = 1: 512³ on one MI355X (the configuration the metric is quoted on).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is 1024 × 1024 × 128·N,
+slab-decomposed along the last dimension (every rank owns 1024 × 1024 × 128 = 512³ cells: weak
+scaling), ghost planes exchanged over RCCL/xGMI after every stage, Δt all-reduced.
+
+A "step" is one pass of the reference's step loop body (src/timestepping.jl:104-116):
+compute_cfl + the 3 fused RK3 stage kernels + ghost fills (hooks = identity).  Inputs are resident
+in HBM when the timed region starts.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6
+
+
+def build_equation(lsm, n, comm, device, mode):
+    h = 1.0 / (n[0] - 1)
+    grid = lsm.CartesianGrid((0.0, 0.0, 0.0), tuple((k - 1) * h for k in n), n)   # uniform spacing in every run
+    ic = lsm.LazyMeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+    vel = lsm.vortex_deformation(grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(vel, lsm.WENO5()), lsm.EikonalReinitializationTerm()), ic=ic,
+                              bc=lsm.NeumannBC(), integrator=lsm.RK3(), comm=comm, device=device, mode=mode)
+    return eq, grid, vel
+
+
+def one_step(eq, tc):
+    """Loop body of _integrate! (src/timestepping.jl:104-116) without hooks."""
+    eq._update_terms(eq.state, tc)
+    dt = eq.integrator.cfl * eq.compute_cfl(tc)
+    eq._advance(tc, dt)
+    return tc + dt
+
+
+def cpu_baseline(n_sample, threads):
+    """The reference-faithful CPU oracle timed on a bounded sample of the same workload
+    (kind 'port': the reference is Julia and cannot run here)."""
+    from oracle import oracle as orc
+    n = (n_sample,) * 3
+    g = orc.Grid((0, 0, 0), (1, 1, 1), n)
+    bc = orc.make_bc("neumann", 3)
+    x, y, z = g.coords()
+    s2 = lambda a: np.sin(np.pi * a) * np.sin(np.pi * a)
+    s = lambda a: np.sin(2 * np.pi * a)
+    terms = [orc.advection(orc.separable([[2 * s2(x), s(y), s(z)], [-s(x), s2(y), s(z)], [-s(x), s(y), s2(z)]], orc.TIME_COS, 3.0)),
+             orc.eikonal()]
+    phi = g.sample(lambda X, Y, Z: np.sqrt((X - 0.35) ** 2 + (Y - 0.35) ** 2 + (Z - 0.35) ** 2) - 0.15)
+    orc.set_threads(threads)
+    t0 = time.perf_counter()
+    steps, _, _ = orc.integrate(orc.RK3, g, bc, phi, terms, 1.0, max_steps=1)
+    el = time.perf_counter() - t0
+    orc.set_threads(1)
+    return n_sample ** 3 * steps / el / 1e6, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=512, help="cells per side of the per-GPU 512³-equivalent workload")
+    ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=192)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import lsm_amd as lsm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = dist.group.WORLD
+
+    if world == 1:
+        n = (args.n, args.n, args.n)
+        workload = f"3D {args.n}^3 vortex-deformation WENO5 advection + EikonalReinitializationTerm, RK3, NeumannBC, fp64"
+    else:
+        side = 2 * args.n
+        n = (side, side, (args.n // 4) * world)
+        workload = (f"3D {n[0]}x{n[1]}x{n[2]} vortex-deformation WENO5 advection + EikonalReinitializationTerm, RK3, NeumannBC, "
+                    f"fp64, slab-decomposed over {world} GPUs ({side}x{side}x{args.n // 4} per GPU)")
+    cells = n[0] * n[1] * n[2]
+
+    eq, grid, vel = build_equation(lsm, n, comm, local_rank, args.mode)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tc = 0.0
+    for _ in range(args.warmup):
+        tc = one_step(eq, tc)
+    eq.backend.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tc = one_step(eq, tc)
+    barrier()
+    el = time.perf_counter() - t0
+    n_launch, stage_ms = eq.backend.profile_read()
+    eq.backend.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    ms_per_step = el / args.steps * 1e3
+    mcells = cells * args.steps / el / 1e6
+    # algorithmic bytes: RK3 step = 8·sizeof(T) = 64 B/node over 3 stage launches
+    local_cells = cells // world
+    bytes_per_launch = local_cells * 64.0 / 3.0
+    avg_launch_s = stage_ms / max(1, n_launch) * 1e-3
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+    # fp64 VALU view of the same kernel (the binding resource): ≈1.0 kflop/node-stage
+    out = {
+        "metric": "Mcells/s per RK3 step (WENO5 advect+reinit), 512^3 fp64; HBM GB/s vs peak",
+        "value": round(mcells, 2),
+        "unit": "Mcells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "grid": list(n), "cells": cells, "integrator": "RK3", "cfl": 0.5,
+                   "arithmetic_mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "stage_kernel<3,WENO5 adv,Eikonal> (fused RK3 stage)",
+                     "stage_launches": int(n_launch), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "stage_time_fraction_of_step": round(stage_ms / (el * 1e3), 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        v1, t1 = cpu_baseline(args.cpu_sample, 1)
+        nthr = orc.max_threads()
+        vN, tN = cpu_baseline(args.cpu_sample, nthr)
+        out["cpu_baseline"] = {"value": round(v1, 4), "unit": "Mcells/s", "cores": 1, "kind": "port",
+                               "sample": f"1 RK3 step of the same equation on {args.cpu_sample}^3 (oracle, single thread as the "
+                                         f"reference runs; {t1:.1f} s)",
+                               "all_cores": {"value": round(vN, 4), "cores": nthr, "seconds": round(tN, 2)}}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,6 +136,9 @@ void lsm_destroy(LsmHandle* h);
 const char* lsm_last_error(const LsmHandle* h /* NULL = creation errors */);
 const char* lsm_version(void);
 int lsm_sync(LsmHandle* h);
+/* adopt the stream the caller's array library works on (hipStream_t as void*; the handle owns
+ * a non-blocking stream of its own until this is called) */
+int lsm_set_stream(LsmHandle* h, void* stream);
 
 /* ---- layout + transfers (MeshField <-> device field; values(ϕ), src/meshfield.jl:58) ---- */
 int lsm_layout(const LsmHandle* h, LsmLayout* out);

@@ -1,0 +1,21 @@
+"""levelsetmethods.jl_amd — MI355X-native grid-update hot path of LevelSetMethods.jl.
+
+Hand-written HIP kernels for gfx950 (csrc/) behind the C ABI of include/lsm.h, plus the host-side
+mirror of the reference's LevelSetEquation / integrate! / MeshField interface (api.py).
+
+The directory name contains a dot, so import it through the repo-root shim: ``import lsm_amd``.
+"""
+from . import _lib
+from ._lib import LsmError, build
+from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm, EikonalReinitializationTerm,
+                  ExtrapolationBC, ForwardEuler, LazyMeshField, LevelSetEquation, LevelSetTerm, LinearExtrapolationBC, MeshField,
+                  NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField, SeparableCoefficient,
+                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, integrate_, vortex_deformation)
+
+__all__ = [
+    "AdvectionTerm", "BoundaryCondition", "CartesianGrid", "CurvatureTerm", "EikonalReinitializationTerm",
+    "ExtrapolationBC", "ForwardEuler", "LazyMeshField", "LevelSetEquation", "LevelSetTerm", "LinearExtrapolationBC", "MeshField",
+    "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3", "RigidRotation", "ROCMeshField",
+    "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
+    "integrate_", "vortex_deformation", "LsmError", "build",
+]

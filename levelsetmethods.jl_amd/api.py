@@ -1,0 +1,766 @@
+"""Host-side mirror of the reference's operator interface for the grid-update path:
+CartesianGrid / MeshField / boundary conditions / terms / integrators / LevelSetEquation /
+integrate! (Python spelling: ``integrate_``), with the same names, argument meaning and error
+behaviour, driving the HIP kernels through the C ABI (include/lsm.h).
+
+The step loop, hooks, Δt arithmetic and error raising stay on the host exactly as in
+src/timestepping.jl:101-122; only `_advance!` and `compute_cfl` cross into the library.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+# ----------------------------------------------------------------------------- meshes.jl
+
+
+class CartesianGrid:
+    """CartesianGrid(lc, hc, n) — src/meshes.jl:1-5,34-42."""
+
+    def __init__(self, lc, hc, n):
+        lc, hc, n = tuple(lc), tuple(hc), tuple(n)
+        if not (len(lc) == len(hc) == len(n)):
+            raise ValueError("all arguments must have the same length")
+        self.lc = tuple(float(x) for x in lc)
+        self.hc = tuple(float(x) for x in hc)
+        self.n = tuple(int(x) for x in n)
+
+    @property
+    def ndim(self):
+        return len(self.n)
+
+    def size(self):
+        return self.n
+
+    def meshsize(self, dim=None):
+        """(hc - lc) / (n - 1) — src/meshes.jl:109-110 (dim is 0-based)."""
+        h = tuple((self.hc[d] - self.lc[d]) / (self.n[d] - 1) for d in range(self.ndim))
+        return h if dim is None else h[dim]
+
+    def getnode(self, I):
+        """lc + (I-1)*h for a 0-based index tuple I — src/meshes.jl:114-130."""
+        I = tuple(I)
+        if not all(0 <= I[d] < self.n[d] for d in range(self.ndim)):
+            raise ValueError(f"{I} is not a valid node index for this grid")
+        h = self.meshsize()
+        return tuple(self.lc[d] + float(I[d]) * h[d] for d in range(self.ndim))
+
+    def coords(self):
+        h = self.meshsize()
+        return [self.lc[d] + np.arange(self.n[d], dtype=np.float64) * h[d] for d in range(self.ndim)]
+
+    def _c(self):
+        g = L.LsmGrid()
+        g.ndim = self.ndim
+        for d in range(3):
+            g.n[d] = self.n[d] if d < self.ndim else 1
+            g.lc[d] = self.lc[d] if d < self.ndim else 0.0
+            g.hc[d] = self.hc[d] if d < self.ndim else 1.0
+        return g
+
+    def __repr__(self):
+        dom = " × ".join(f"[{a}, {b}]" for a, b in zip(self.lc, self.hc))
+        return (f"CartesianGrid in ℝ{self.ndim}\n  ├─ domain:  {dom}\n  ├─ nodes:   {' × '.join(map(str, self.n))}\n"
+                f"  └─ spacing: h = ({', '.join(f'{x:.4g}' for x in self.meshsize())})")
+
+
+# ----------------------------------------------------------------------------- boundaryconditions.jl
+
+class BoundaryCondition:
+    pass
+
+
+class PeriodicBC(BoundaryCondition):
+    kind, degree = L.BC_PERIODIC, 0
+
+    def __repr__(self):
+        return "Periodic"
+
+
+class ExtrapolationBC(BoundaryCondition):
+    """ExtrapolationBC{P} — src/boundaryconditions.jl:40-46."""
+    kind = L.BC_EXTRAPOLATION
+
+    def __init__(self, P=0):
+        if P < 0:
+            raise ValueError("extrapolation order P must be at least 0")
+        self.degree = int(P)
+
+    def __repr__(self):
+        return {0: "Neumann", 1: "Linear extrapolation"}.get(self.degree, f"Degree {self.degree} extrapolation")
+
+
+def NeumannBC():
+    return ExtrapolationBC(0)
+
+
+def LinearExtrapolationBC():
+    return ExtrapolationBC(1)
+
+
+class SymmetryBC(BoundaryCondition):
+    kind, degree = L.BC_SYMMETRY, 0
+
+    def __repr__(self):
+        return "Symmetry"
+
+
+def _same_bc(a, b):
+    return a.kind == b.kind and a.degree == b.degree
+
+
+def _normalize_bc(bc, dim):
+    """src/boundaryconditions.jl:166-188."""
+    if isinstance(bc, BoundaryCondition):
+        return tuple((bc, bc) for _ in range(dim))
+    if len(bc) != dim:
+        raise ValueError("invalid number of boundary conditions")
+    out = []
+    for i, b in enumerate(bc):
+        if isinstance(b, BoundaryCondition):
+            out.append((b, b))
+            continue
+        if not (len(b) == 2 and all(isinstance(x, BoundaryCondition) for x in b)):
+            raise ValueError(f"invalid boundary condition for dimension {i + 1}")
+        left, right = b
+        if isinstance(left, PeriodicBC) != isinstance(right, PeriodicBC):
+            raise ValueError(f"periodic boundary conditions cannot be mixed with others in dimension {i + 1}")
+        out.append((left, right))
+    return tuple(out)
+
+
+def _bc_c(bcs, ndim, slab_faces=(False, False)):
+    arr = L.BcArray()
+    for d in range(3):
+        for s in range(2):
+            if d < ndim:
+                arr[d][s].kind, arr[d][s].degree = bcs[d][s].kind, bcs[d][s].degree
+                if d == ndim - 1 and slab_faces[s]:
+                    arr[d][s].kind, arr[d][s].degree = L.BC_NONE, 0
+            else:
+                arr[d][s].kind, arr[d][s].degree = L.BC_EXTRAPOLATION, 0
+    return arr
+
+
+# ----------------------------------------------------------------------------- meshfield.jl
+
+class MeshField:
+    """Host-resident dense field (src/meshfield.jl:51-55): `vals` is a numpy array of shape
+    grid.n in Fortran order (the reference's column-major Array), or shape (ncomp, *grid.n) for
+    vector-valued coefficient fields."""
+
+    def __init__(self, vals_or_f, grid, bc=None):
+        if callable(vals_or_f):
+            xs = np.meshgrid(*grid.coords(), indexing="ij", sparse=True)
+            v = vals_or_f(tuple(xs))
+            if isinstance(v, (tuple, list)):
+                v = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), grid.n) for c in v])
+            else:
+                v = np.broadcast_to(np.asarray(v, dtype=np.float64), grid.n)
+            vals = np.array(v, dtype=np.float64)
+        else:
+            vals = np.array(vals_or_f, dtype=np.float64)
+        if vals.shape[-grid.ndim:] != grid.n:
+            raise ValueError(f"values of shape {vals.shape} do not match the grid {grid.n}")
+        self.vals = np.asfortranarray(vals) if vals.ndim == grid.ndim else vals
+        self.mesh = grid
+        self.bcs = None if bc is None else _normalize_bc(bc, grid.ndim)
+
+    def has_boundary_conditions(self):
+        return self.bcs is not None
+
+    def values(self):
+        return self.vals
+
+    def copy(self):
+        m = MeshField(self.vals.copy(order="K"), self.mesh)
+        m.bcs = self.bcs
+        return m
+
+    def __getitem__(self, I):
+        """ϕ[I] with 0-based I; out-of-grid indices go through the boundary conditions
+        (_getindexbc, src/meshfield.jl:213-260)."""
+        I = tuple(I) if not isinstance(I, int) else (I,)
+        n = self.mesh.n
+        if all(0 <= I[d] < n[d] for d in range(len(n))):
+            return float(self.vals[I])
+        if self.bcs is None:
+            raise ValueError(f"index {I} lies outside the grid, but the field has no boundary conditions to resolve it.")
+        return self._getindexbc(I, len(n))
+
+    def _getindexbc(self, I, dim):
+        if dim == 0:
+            return float(self.vals[I])
+        d = dim - 1
+        n = self.mesh.n[d]
+        if 0 <= I[d] < n:
+            return self._getindexbc(I, dim - 1)
+        left = I[d] < 0
+        bc = self.bcs[d][0 if left else 1]
+        k = -I[d] if left else I[d] - (n - 1)
+        b, sgn = (0, 1) if left else (n - 1, -1)
+        acc = 0.0
+        if bc.kind == L.BC_PERIODIC:
+            J = I[:d] + (((n - 1) - k) if left else k,) + I[d + 1:]
+            acc += 1.0 * self._getindexbc(J, dim - 1)
+        elif bc.kind == L.BC_EXTRAPOLATION:
+            P = bc.degree
+            for j in range(P + 1):
+                w = 1.0
+                for m in range(P + 1):
+                    if m != j:
+                        w *= (-k - m) / (j - m)
+                acc += w * self._getindexbc(I[:d] + (b + sgn * j,) + I[d + 1:], dim - 1)
+        else:
+            acc += 1.0 * self._getindexbc(I[:d] + (b + sgn * k,) + I[d + 1:], dim - 1)
+        return acc
+
+    def __repr__(self):
+        s = f"MeshField on {self.mesh!r}"
+        if self.vals.ndim == self.mesh.ndim:
+            s += f"\n  values: min = {self.vals.min():.4g},  max = {self.vals.max():.4g}"
+        return s
+
+
+class LazyMeshField:
+    """MeshField(f, grid) whose samples are only ever materialised slab by slab (large grids,
+    multi-GPU): `f` receives a tuple of broadcastable coordinate arrays like MeshField's."""
+
+    def __init__(self, f, grid, bc=None):
+        self.f, self.mesh = f, grid
+        self.bcs = None if bc is None else _normalize_bc(bc, grid.ndim)
+
+    def has_boundary_conditions(self):
+        return self.bcs is not None
+
+    def local_values(self, slab):
+        cs = self.mesh.coords()
+        if slab is not None:
+            cs[-1] = cs[-1][slab[0]:slab[0] + slab[1]]
+        xs = np.meshgrid(*cs, indexing="ij", sparse=True)
+        shape = tuple(len(c) for c in cs)
+        return np.asfortranarray(np.broadcast_to(np.asarray(self.f(tuple(xs)), dtype=np.float64), shape))
+
+
+class ROCMeshField:
+    """Device-resident field: a padded HBM buffer (layout from lsm_layout) + the grid + the
+    normalised boundary conditions + the backend handle.  Plays the role of the
+    `ROCMeshField <: AbstractMeshField` of SURVEY.md §8b."""
+
+    def __init__(self, backend, mesh, bcs, buf=None):
+        self.backend, self.mesh, self.bcs = backend, mesh, bcs
+        self.buf = backend.alloc() if buf is None else buf
+
+    @classmethod
+    def from_host(cls, backend, mf, bcs=None, local=None):
+        f = cls(backend, mf.mesh, bcs if bcs is not None else mf.bcs)
+        v = mf.vals if local is None else mf.vals[(Ellipsis, local)]
+        backend.upload(f.buf, v)
+        return f
+
+    def values(self):
+        """Host copy of the (local) interior, Fortran order."""
+        return self.backend.download(self.buf)
+
+    def to_host(self):
+        m = MeshField(self.values(), self.mesh)
+        m.bcs = self.bcs
+        return m
+
+    def copy(self):
+        return ROCMeshField(self.backend, self.mesh, self.bcs, self.backend.clone(self.buf))
+
+    def copy_(self, src):
+        """copy!(dest, src) — src/meshfield.jl:289-292; accepts a device or a host field."""
+        if isinstance(src, ROCMeshField):
+            self.backend.copy_(self.buf, src.buf)
+        else:
+            self.backend.upload(self.buf, src.vals if isinstance(src, MeshField) else src)
+        return self
+
+    def extrema(self):
+        return self.backend.extrema(self.buf)
+
+    def __repr__(self):
+        lo, hi = self.extrema()
+        return f"ROCMeshField on {self.mesh!r}\n  values: min = {lo:.4g},  max = {hi:.4g}"
+
+
+# ----------------------------------------------------------------------------- derivatives.jl schemes
+
+class SpatialScheme:
+    pass
+
+
+class Upwind(SpatialScheme):
+    code = L.SCHEME_UPWIND
+
+
+class WENO5(SpatialScheme):
+    code = L.SCHEME_WENO5
+
+
+# ----------------------------------------------------------------------------- coefficient catalogue
+# Julia closures f(x,t) cannot run on the device (SURVEY.md §7 hard part 2).  Coefficients are:
+#   numbers / tuples            -> CONST
+#   RigidRotation               -> ROTATION   (the (x,t)->(-x₂,x₁) of the reference's tests/docs)
+#   SeparableCoefficient        -> SEPARABLE  (per-axis tables × g(t), e.g. vortex deformation)
+#   MeshField                   -> FIELD      (device arrays, SoA per component)
+#   python callable f(x,t)      -> FIELD re-sampled on the host before the CFL and each stage (slow path)
+
+class RigidRotation:
+    """u = ω·(-(x₂-c₂), x₁-c₁ [, 0])."""
+
+    def __init__(self, omega=1.0, center=(0.0, 0.0)):
+        self.omega, self.center = float(omega), (float(center[0]), float(center[1]))
+
+
+class SeparableCoefficient:
+    """u_c(x,t) = ((T_c1[i1]·T_c2[i2])·T_c3[i3])·g(t); tables[c][axis] are 1-D arrays over the
+    GLOBAL grid; time is None (g=1) or ('cos', T) for g = cos(πt/T)."""
+
+    def __init__(self, tables, time=None):
+        self.tables = [[np.asarray(t, dtype=np.float64) for t in comp] for comp in tables]
+        self.time = time
+
+
+def vortex_deformation(grid, period=3.0):
+    """LeVeque's 3-D deformation field:
+    u = 2 sin²(πx) sin(2πy) sin(2πz) g, v = -sin(2πx) sin²(πy) sin(2πz) g, w = -sin(2πx) sin(2πy) sin²(πz) g,
+    g = cos(πt/period).  Tables are evaluated with the host libm at the node coordinates."""
+    x, y, z = grid.coords()
+    s2 = lambda a: np.sin(np.pi * a) * np.sin(np.pi * a)
+    s = lambda a: np.sin(2 * np.pi * a)
+    return SeparableCoefficient([[2 * s2(x), s(y), s(z)], [-s(x), s2(y), s(z)], [-s(x), s(y), s2(z)]], time=("cos", period))
+
+
+class _Coeff:
+    """Resolved coefficient bound to a backend: owns device buffers, fills an LsmCoeff."""
+
+    def __init__(self, spec, ncomp, grid, backend, slab):
+        self.spec, self.ncomp, self.grid, self.backend, self.slab = spec, ncomp, grid, backend, slab
+        self.c = L.LsmCoeff()
+        self._keep = []
+        self.callable = None
+        self.fields = None
+        if isinstance(spec, RigidRotation):
+            self.c.kind = L.COEFF_ROTATION
+            self.c.value[0], self.c.value[1], self.c.value[2] = spec.omega, spec.center[0], spec.center[1]
+        elif isinstance(spec, SeparableCoefficient):
+            self.c.kind = L.COEFF_SEPARABLE
+            if spec.time is not None:
+                self.c.time_kind, self.c.time_param = L.TIME_COS, float(spec.time[1])
+            for k in range(ncomp):
+                t = backend.table(np.concatenate(spec.tables[k]))
+                self._keep.append(t)
+                self.c.sep[k] = t.data_ptr()
+        elif isinstance(spec, (MeshField, ROCMeshField)) or callable(spec):
+            self.c.kind = L.COEFF_FIELD
+            self.fields = [backend.alloc() for _ in range(ncomp)]
+            for k, t in enumerate(self.fields):
+                self.c.field[k] = t.data_ptr()
+            if callable(spec):
+                self.callable = spec
+            else:
+                self.set_values(spec.vals if isinstance(spec, MeshField) else spec)
+        else:
+            vals = spec if isinstance(spec, (tuple, list, np.ndarray)) else (spec,)
+            if len(vals) != ncomp:
+                raise ValueError(f"expected {ncomp} coefficient component(s), got {len(vals)}")
+            self.c.kind = L.COEFF_CONST
+            for k, v in enumerate(vals):
+                self.c.value[k] = float(v)
+
+    def _local(self, a):
+        if self.slab is None:
+            return a
+        return a[..., self.slab[0]:self.slab[0] + self.slab[1]]
+
+    def set_values(self, vals):
+        """Upload new values (global array of shape grid.n or (ncomp, *grid.n))."""
+        vals = np.asarray(vals, dtype=np.float64)
+        if vals.ndim == self.grid.ndim:
+            vals = vals[None]
+        for k in range(self.ncomp):
+            self.backend.upload(self.fields[k], self._local(vals[k]))
+
+    def refresh(self, t):
+        """Slow path: re-sample a python callable f(x, t) on the host."""
+        if self.callable is None:
+            return
+        xs = tuple(np.meshgrid(*self.grid.coords(), indexing="ij", sparse=True))
+        v = self.callable(xs, t)
+        if not isinstance(v, (tuple, list)):
+            v = (v,)
+        self.set_values(np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), self.grid.n) for c in v]))
+
+
+# ----------------------------------------------------------------------------- levelsetterms.jl
+
+class LevelSetTerm:
+    update_func = None
+    coeff = None
+
+    def _bind(self, grid, backend, slab):
+        pass
+
+
+class AdvectionTerm(LevelSetTerm):
+    """AdvectionTerm(𝐮[, scheme = WENO5(), update_func]) — 𝐮 ⋅ ∇ϕ (src/levelsetterms.jl:45-63)."""
+    kind = L.TERM_ADVECTION
+
+    def __init__(self, velocity, scheme=None, update_func=None):
+        self.velocity, self.scheme, self.update_func = velocity, scheme or WENO5(), update_func
+
+    def _bind(self, grid, backend, slab):
+        self.coeff = _Coeff(self.velocity, grid.ndim, grid, backend, slab)
+
+    def __repr__(self):
+        return "𝐮 ⋅ ∇ ϕ"
+
+
+class CurvatureTerm(LevelSetTerm):
+    """CurvatureTerm(b) — b κ|∇ϕ| (src/levelsetterms.jl:104-107)."""
+    kind = L.TERM_CURVATURE
+
+    def __init__(self, b):
+        self.b = b
+
+    def _bind(self, grid, backend, slab):
+        self.coeff = _Coeff(self.b, 1, grid, backend, slab)
+
+    def __repr__(self):
+        return "b κ|∇ϕ|"
+
+
+class NormalMotionTerm(LevelSetTerm):
+    """NormalMotionTerm(v[, update_func]) — v|∇ϕ| (src/levelsetterms.jl:139-146)."""
+    kind = L.TERM_NORMAL_MOTION
+
+    def __init__(self, speed, update_func=None):
+        self.speed, self.update_func = speed, update_func
+
+    def _bind(self, grid, backend, slab):
+        self.coeff = _Coeff(self.speed, 1, grid, backend, slab)
+
+    def __repr__(self):
+        return "v|∇ϕ|"
+
+
+class EikonalReinitializationTerm(LevelSetTerm):
+    """EikonalReinitializationTerm([ϕ₀]) — sign(ϕ)(|∇ϕ| - 1) (src/levelsetterms.jl:211-222).
+    With ϕ₀ (host MeshField or device field) the smoothed sign S₀ = ϕ₀/√(ϕ₀²+Δx²) is frozen."""
+    kind = L.TERM_EIKONAL
+
+    def __init__(self, phi0=None):
+        self.phi0 = phi0
+        self.s0 = None
+
+    def _bind(self, grid, backend, slab):
+        if self.phi0 is None:
+            return
+        if isinstance(self.phi0, ROCMeshField):
+            src = self.phi0.buf
+        else:
+            src = backend.alloc()
+            v = self.phi0.vals if isinstance(self.phi0, MeshField) else np.asarray(self.phi0)
+            backend.upload(src, v if slab is None else v[..., slab[0]:slab[0] + slab[1]])
+        self.s0 = backend.alloc()
+        backend.eikonal_sign(src, self.s0)
+
+    def __repr__(self):
+        return "sign(ϕ) (|∇ϕ| - 1)" if self.phi0 is None else "sign(ϕ₀) (|∇ϕ| - 1)"
+
+
+def _terms_c(terms):
+    arr = (L.LsmTerm * max(1, len(terms)))()
+    for i, t in enumerate(terms):
+        arr[i].kind = t.kind
+        arr[i].scheme = t.scheme.code if isinstance(t, AdvectionTerm) else 0
+        if t.coeff is not None:
+            C.memmove(C.byref(arr[i].coeff), C.byref(t.coeff.c), C.sizeof(L.LsmCoeff))
+        if isinstance(t, EikonalReinitializationTerm) and t.s0 is not None:
+            arr[i].s0 = t.s0.data_ptr()
+    return arr
+
+
+# ----------------------------------------------------------------------------- timestepping.jl
+
+class TimeIntegrator:
+    def __init__(self, cfl=0.5):
+        self.cfl = float(cfl)
+
+    def __repr__(self):
+        return f"{self._describe}\n  └─ cfl: {self.cfl}"
+
+
+class ForwardEuler(TimeIntegrator):
+    name, _describe = "fe", "ForwardEuler (1st order explicit)"
+
+
+class RK2(TimeIntegrator):
+    name, _describe = "rk2", "RK2 (2nd order TVD Runge-Kutta, Heun's method)"
+
+
+class RK3(TimeIntegrator):
+    name, _describe = "rk3", "RK3 (3rd order TVD Runge-Kutta)"
+
+
+def _jl_min(*xs):
+    m = xs[0]
+    for x in xs[1:]:
+        m = float("nan") if (math.isnan(m) or math.isnan(x)) else (x if x < m else m)
+    return m
+
+
+def _eps(x):
+    return float(np.spacing(abs(float(x))))
+
+
+# ----------------------------------------------------------------------------- levelsetequation.jl
+
+class LevelSetEquation:
+    """LevelSetEquation(; terms, integrator = RK2(), ic, bc = nothing, t = 0) — src/levelsetequation.jl:59-78.
+
+    Extra keywords of this implementation: mode ('fast' | 'strict' arithmetic), device, and
+    `comm` (a torch.distributed process group: the grid is then split into slabs of the last
+    dimension, one per rank, with ghost-plane exchange over RCCL)."""
+
+    def __init__(self, *, terms, ic, integrator=None, bc=None, t=0, mode="fast", device=0, comm=None, backend_factory=None):
+        if isinstance(terms, LevelSetTerm):
+            terms = (terms,)
+        if not (isinstance(terms, tuple) and all(isinstance(x, LevelSetTerm) for x in terms)):
+            raise ValueError(f"terms must be a LevelSetTerm or a tuple of them, got {type(terms)}")
+        if len(terms) == 0 or len(terms) > L.MAX_TERMS:
+            raise ValueError(f"between 1 and {L.MAX_TERMS} terms are supported")
+        self.terms = terms
+        self.integrator = integrator or RK2()
+        if bc is None:
+            if not ic.has_boundary_conditions():
+                raise ValueError("no boundary conditions: pass `bc` or build `ic` with one")
+            bcs = ic.bcs
+        else:
+            bcs = _normalize_bc(bc, ic.mesh.ndim)
+        self.mesh_ = ic.mesh
+        self.bcs = bcs
+        self.t = t
+        self.comm = comm
+        grid = ic.mesh
+        N = grid.ndim
+        # slab decomposition of the last dimension
+        self.rank, self.world = 0, 1
+        self.slab = None
+        slab_faces = (False, False)
+        if comm is not None:
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
+            nl = grid.n[N - 1]
+            base, rem = divmod(nl, self.world)
+            counts = [base + (1 if r < rem else 0) for r in range(self.world)]
+            lo = sum(counts[:self.rank])
+            self.slab = (lo, counts[self.rank])
+            self.counts = counts
+            periodic = bcs[N - 1][0].kind == L.BC_PERIODIC
+            slab_faces = (self.rank > 0 or (periodic and self.world > 1), self.rank < self.world - 1 or (periodic and self.world > 1))
+            self.periodic_last = periodic
+        factory = backend_factory
+        if factory is None:
+            from .backend import HipBackend
+            factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device)
+        self.backend = factory(grid._c(), _bc_c(bcs, N, slab_faces), self.slab)
+        # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
+        self.state = ROCMeshField(self.backend, grid, bcs)
+        if isinstance(ic, ROCMeshField):
+            self.backend.copy_(self.state.buf, ic.buf)
+        elif isinstance(ic, LazyMeshField):
+            self.backend.upload(self.state.buf, ic.local_values(self.slab))
+        else:
+            v = ic.vals
+            self.backend.upload(self.state.buf, v if self.slab is None else v[..., self.slab[0]:self.slab[0] + self.slab[1]])
+        for term in terms:
+            term._bind(grid, self.backend, self.slab)
+        self._bufs = None
+        self._hook_keep = None
+
+    # accessors (src/levelsetequation.jl:124-162)
+    def current_state(self):
+        return self.state
+
+    def current_time(self):
+        return self.t
+
+    def mesh(self):
+        return self.mesh_
+
+    def time_integrator(self):
+        return self.integrator
+
+    def __repr__(self):
+        terms = " + ".join(repr(t) for t in self.terms)
+        return f"LevelSetEquation\n  ├─ equation: ϕₜ + {terms} = 0\n  ├─ time:     {self.t}\n  ├─ integrator: {self.integrator._describe}"
+
+    # ---- update_term! (src/levelsetterms.jl:14,65-69,148-152) + slow-path coefficient sampling
+    def _needs_hook(self):
+        return any(t.update_func is not None or (t.coeff is not None and t.coeff.callable is not None) for t in self.terms)
+
+    def _update_terms(self, field, t):
+        for term in self.terms:
+            if term.coeff is not None:
+                term.coeff.refresh(t)
+            if term.update_func is not None:
+                term.update_func(term.coeff, field, t)
+
+    # ---- compute_cfl (src/levelsetterms.jl:22-28)
+    def compute_cfl(self, t=None):
+        t = self.t if t is None else t
+        arr = _terms_c(self.terms)
+        dt = self.backend.compute_cfl_local(arr, len(self.terms), self.state.buf, t)
+        if self.comm is not None and self.world > 1:
+            dt = self._allreduce_min(dt)
+        if not dt > 0:
+            raise ValueError(f"invalid time-step based on CFL condition: Δt = {dt} (check for NaN/Inf in velocity or speed)")
+        return dt
+
+    def _allreduce_min(self, dt):
+        import torch
+        import torch.distributed as dist
+        dev = self.state.buf.device
+        x = torch.tensor([-1.0 if math.isnan(dt) else dt], dtype=torch.float64, device=dev)   # NaN must win
+        dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.comm)
+        v = float(x.item())
+        return float("nan") if v < 0 else v
+
+    # ---- _advance! (src/timestepping.jl:126-202)
+    def _advance(self, tc, dt):
+        b = self.backend
+        if self._bufs is None:
+            self._bufs = (b.alloc(), b.alloc())   # cached across integrate! calls (the reference reallocates)
+        b1, b2 = self._bufs
+        arr = _terms_c(self.terms)
+        n = len(self.terms)
+        phi = self.state.buf
+        name = self.integrator.name
+        if self.comm is None:
+            hook = None
+            if self._needs_hook():
+                def cb(_user, stage, field_ptr, t_stage):
+                    try:
+                        fld = self.state if stage == 0 else ROCMeshField(b, self.mesh_, self.bcs, b1 if stage == 1 else b2)
+                        self._update_terms(fld, t_stage)
+                        return 0
+                    except Exception as e:   # surface python errors as an aborted step
+                        self._hook_error = e
+                        return 1
+                hook = L.StageHook(cb)
+                self._hook_keep = hook
+            self._hook_error = None
+            try:
+                b.advance_single(name, arr, n, phi, b1, b2, tc, dt, hook)
+            except L.LsmError:
+                if self._hook_error is not None:
+                    raise self._hook_error
+                raise
+            return
+        # slab mode: stage by stage with ghost-plane exchange between stages
+        fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)
+        self._halo(phi)
+        if name == "fe":
+            self._update_terms(self.state, tc)
+            b.stage(_terms_c(self.terms), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            b.copy_(phi, b1)
+            self._halo(phi)
+        elif name == "rk2":
+            self._update_terms(self.state, tc)
+            b.stage(_terms_c(self.terms), n, phi, None, b1, b2, L.BASE_PSI, dt, 0.5 * dt, tc)
+            self._halo(b1)
+            self._update_terms(fld(b1), tc + dt)
+            b.stage(_terms_c(self.terms), n, b1, b2, phi, None, L.BASE_OTHER, 0.5 * dt, 0.0, tc + dt)
+            self._halo(phi)
+        else:
+            self._update_terms(self.state, tc)
+            b.stage(_terms_c(self.terms), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            self._halo(b1)
+            self._update_terms(fld(b1), tc + dt)
+            b.stage(_terms_c(self.terms), n, b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
+            self._halo(b2)
+            self._update_terms(fld(b2), tc + 0.5 * dt)
+            b.stage(_terms_c(self.terms), n, b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
+            self._halo(phi)
+
+    def _halo(self, buf):
+        """Ghost resolution for a slab: BC fill of every dimension (slab interfaces are skipped by
+        the library), then exchange of LSM_GHOST full padded planes with the neighbouring ranks.
+        Because the exchanged planes carry their own dim-1..N-1 ghosts, the corner composition of
+        _getindexbc (src/meshfield.jl:248-260) is preserved."""
+        import torch.distributed as dist
+        b = self.backend
+        b.fill_ghosts(buf, 7)
+        if self.world == 1:
+            return
+        N = self.mesh_.ndim
+        G = L.GHOST
+        sl = int(b.lay.stride[N - 1])          # elements per padded plane
+        nloc = int(b.lay.n[N - 1])
+        flat = b.flat(buf)
+        plane = lambda k0, k1: flat[(k0 + G) * sl:(k1 + G) * sl]   # local plane range [k0, k1)
+        up = self.rank + 1 if self.rank < self.world - 1 else (0 if self.periodic_last else None)
+        dn = self.rank - 1 if self.rank > 0 else (self.world - 1 if self.periodic_last else None)
+        ops = []
+        # periodic wrap has period n-1 (nodes 1 and n coincide, src/boundaryconditions.jl:107-119):
+        # across the wrap the sender skips its duplicate end node.
+        wrap_up = self.rank == self.world - 1
+        wrap_dn = self.rank == 0
+        if up is not None:
+            s0 = nloc - G - (1 if wrap_up else 0)
+            ops.append(dist.P2POp(dist.isend, plane(s0, s0 + G), up, group=self.comm))
+            ops.append(dist.P2POp(dist.irecv, plane(nloc, nloc + G), up, group=self.comm))
+        if dn is not None:
+            s0 = 1 if wrap_dn else 0
+            ops.append(dist.P2POp(dist.isend, plane(s0, s0 + G), dn, group=self.comm))
+            ops.append(dist.P2POp(dist.irecv, plane(-G, 0), dn, group=self.comm))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def gather_state(self):
+        """Full-grid host copy of the state on every rank (tests / diagnostics)."""
+        v = self.state.values()
+        if self.comm is None or self.world == 1:
+            return v
+        import torch
+        import torch.distributed as dist
+        N = self.mesh_.ndim
+        parts = [None] * self.world
+        dist.all_gather_object(parts, v, group=self.comm)
+        return np.asfortranarray(np.concatenate(parts, axis=N - 1))
+
+
+def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
+    """integrate!(ls, tf, Δt = Inf; prehook, posthook) — src/levelsetequation.jl:194-203 and the
+    step loop _integrate! of src/timestepping.jl:101-122, on the host."""
+    tc = ls.current_time()
+    if not tf >= tc:
+        raise ValueError(f"final time {tf} must be ≥ initial time {tc}: the level-set equation cannot be solved back in time")
+    alpha = ls.integrator.cfl
+    while tc <= tf - _eps(tc):
+        if prehook is not None:
+            prehook(ls)
+        ls._update_terms(ls.state, tc)
+        step = _jl_min(dt, alpha * ls.compute_cfl(tc), tf - tc)
+        ls._advance(tc, step)
+        tc += step
+        ls.t = tc
+        if posthook is not None:
+            posthook(ls)
+    ls.t = tf
+    return ls
+
+
+def current_state(ls):
+    return ls.current_state()
+
+
+def current_time(ls):
+    return ls.current_time()

@@ -1,0 +1,130 @@
+"""HipBackend — device memory (torch tensors as plain HBM buffers), streams and the calls into
+libhiplsm.so.  torch is plumbing here: allocation, the current HIP stream, and (in slab mode)
+torch.distributed point-to-point over RCCL/xGMI for the ghost-plane exchange.
+
+The interface (layout / alloc / upload / download / fill_ghosts / stage / compute_cfl_local /
+advance_single / eikonal_sign / extrema / table) is the seam the host logic in api.py talks to.
+The only implementation in this package is the HIP one; it raises if the library or the GPU is
+missing — there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, grid_c, bc_c, slab=None, mode="fast", device=0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("levelsetmethods.jl_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.torch = torch
+        self.lib = L.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ndim = int(grid_c.ndim)
+        self._grid = grid_c
+        self._bc = bc_c
+        self.slab = slab
+        h = C.c_void_p()
+        slab_c = L.LsmSlab(slab[0], slab[1]) if slab is not None else None
+        code = self.lib.lsm_create(C.byref(grid_c), bc_c, C.byref(slab_c) if slab_c is not None else None, L.DTYPE_F64,
+                                   L.MODE_STRICT if mode == "strict" else L.MODE_FAST, device, C.byref(h))
+        if code != L.OK:
+            raise L.LsmError(f"lsm_create failed ({code}): {self.lib.lsm_last_error(None).decode()}")
+        self.h = h
+        # kernels, torch copies and RCCL all order on torch's current stream
+        L.check(self.h, self.lib.lsm_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "lsm_set_stream")
+        self.lay = L.LsmLayout()
+        L.check(self.h, self.lib.lsm_layout(self.h, C.byref(self.lay)), "lsm_layout")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lsm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory
+    def alloc(self):
+        return self.torch.zeros(int(self.lay.total), dtype=self.torch.float64, device=self.device)
+
+    def clone(self, t):
+        return t.clone()
+
+    def copy_(self, dst, src):
+        dst.copy_(src)
+
+    def ptr(self, t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def local_shape(self):
+        return tuple(int(self.lay.n[d]) for d in range(self.ndim))
+
+    def upload(self, t, dense):
+        a = np.asfortranarray(dense, dtype=np.float64)
+        assert a.shape == self.local_shape(), (a.shape, self.local_shape())
+        L.check(self.h, self.lib.lsm_upload(self.h, self.ptr(t), a.ctypes.data_as(C.c_void_p)), "lsm_upload")
+
+    def download(self, t):
+        out = np.empty(self.local_shape(), dtype=np.float64, order="F")
+        L.check(self.h, self.lib.lsm_download(self.h, self.ptr(t), out.ctypes.data_as(C.c_void_p)), "lsm_download")
+        return out
+
+    def table(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
+
+    def flat(self, t):
+        return t
+
+    # ---- kernels
+    def fill_ghosts(self, t, mask=7):
+        L.check(self.h, self.lib.lsm_fill_ghosts(self.h, self.ptr(t), mask, None), "lsm_fill_ghosts")
+
+    def stage(self, terms_c, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t):
+        L.check(self.h, self.lib.lsm_stage(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out),
+                                           self.ptr(out2), base_mode, cdt, cdt2, t, None), "lsm_stage")
+
+    def compute_cfl_local(self, terms_c, nterms, phi, t):
+        dt = C.c_double(0.0)
+        L.check(self.h, self.lib.lsm_compute_cfl(self.h, terms_c, nterms, self.ptr(phi), t, C.byref(dt)), "lsm_compute_cfl")
+        return dt.value
+
+    def advance_single(self, which, terms_c, nterms, phi, b1, b2, tc, dt, hook):
+        cb = hook if hook is not None else C.cast(None, L.StageHook)
+        if which == "fe":
+            code = self.lib.lsm_advance_fe(self.h, terms_c, nterms, self.ptr(phi), self.ptr(b1), tc, dt, cb, None)
+        elif which == "rk2":
+            code = self.lib.lsm_advance_rk2(self.h, terms_c, nterms, self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
+        else:
+            code = self.lib.lsm_advance_rk3(self.h, terms_c, nterms, self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
+        L.check(self.h, code, f"lsm_advance_{which}")
+
+    def eikonal_sign(self, phi0, s0):
+        L.check(self.h, self.lib.lsm_eikonal_sign(self.h, self.ptr(phi0), self.ptr(s0), None), "lsm_eikonal_sign")
+
+    def extrema(self, t):
+        lo, hi = C.c_double(), C.c_double()
+        L.check(self.h, self.lib.lsm_extrema(self.h, self.ptr(t), C.byref(lo), C.byref(hi)), "lsm_extrema")
+        return lo.value, hi.value
+
+    def sync(self):
+        L.check(self.h, self.lib.lsm_sync(self.h), "lsm_sync")
+
+    def profile_enable(self, on=True):
+        L.check(self.h, self.lib.lsm_profile_enable(self.h, 1 if on else 0), "lsm_profile_enable")
+
+    def profile_read(self):
+        n, ms = C.c_int64(), C.c_double()
+        L.check(self.h, self.lib.lsm_profile_read(self.h, C.byref(n), C.byref(ms)), "lsm_profile_read")
+        return n.value, ms.value

@@ -1,0 +1,520 @@
+// lsm_api.hip — host side of the C ABI declared in include/lsm.h.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lsm_internal.h"
+
+namespace lsm {
+int launch_stage_fast_1d(const Combo&, const StageArgs&, hipStream_t);
+int launch_stage_fast_2d(const Combo&, const StageArgs&, hipStream_t);
+int launch_stage_fast_3d(const Combo&, const StageArgs&, hipStream_t);
+int launch_stage_strict_1d(const Combo&, const StageArgs&, hipStream_t);
+int launch_stage_strict_2d(const Combo&, const StageArgs&, hipStream_t);
+int launch_stage_strict_3d(const Combo&, const StageArgs&, hipStream_t);
+
+// must list exactly the combinations of LSM_FOR_EACH_COMBO (stage_kernel.h)
+bool combo_available(const Combo& c) {
+    static const int tab[][4] = {{1, 0, 0, 0}, {2, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}, {0, 0, 0, 2},
+                                 {2, 0, 0, 2}, {2, 0, 0, 1}, {0, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}};
+    for (auto& t : tab)
+        if (t[0] == c.adv && t[1] == c.nm && t[2] == c.curv && t[3] == c.eik) return true;
+    return false;
+}
+}  // namespace lsm
+
+using namespace lsm;
+
+struct LsmHandle {
+    LsmGrid grid;
+    LsmBc bc[LSM_MAX_DIM][2];
+    LsmSlab slab;
+    int dtype, mode, device;
+    LsmLayout lay;
+    int nloc[3], goff[3], gn[3];
+    double h[3], h2[3], inv_h[3], inv_h2[3], dxmin;
+    double w[3][2][LSM_GHOST][8];
+    hipStream_t stream;
+    bool own_stream;
+    double* d_partial;   // 2 * MAXB doubles
+    int* d_flag;
+    double* d_result;    // 2 doubles
+    double* h_result;    // pinned, 2 doubles
+    std::string err;
+    bool prof;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used;
+};
+
+static const int MAXB = 4096;
+static std::string g_create_err;
+
+static int fail(LsmHandle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+#define LSM_HIP(h, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(h, LSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// _lagrange_extrap_weight — src/boundaryconditions.jl:90-97
+static double lagrange_w(int j, int k, int P) {
+    double w = 1.0;
+    for (int m = 0; m <= P; ++m) {
+        if (m == j) continue;
+        w *= (double)(-k - m) / (double)(j - m);
+    }
+    return w;
+}
+
+extern "C" {
+
+const char* lsm_version(void) { return "hiplsm 0.1 (gfx950)"; }
+
+const char* lsm_last_error(const LsmHandle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSlab* slab, int dtype, int mode, int device,
+               LsmHandle** out) {
+    if (!grid || !bc || !out) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: null argument");
+    if (grid->ndim < 1 || grid->ndim > 3) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: ndim must be 1, 2 or 3");
+    if (dtype != LSM_DTYPE_F64) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: only LSM_DTYPE_F64 is implemented");
+    if (mode != LSM_MODE_FAST && mode != LSM_MODE_STRICT) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad mode");
+    const int N = grid->ndim;
+    for (int d = 0; d < 3; ++d) {
+        if (d >= N && grid->n[d] != 1) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: unused dims must have n = 1");
+        if (d < N && grid->n[d] < 4) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: need at least 4 nodes per dimension");
+        if (d < N && grid->n[d] > 0x7fffffff) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: dimension too large");
+    }
+    for (int d = 0; d < N; ++d) {
+        const bool pl = bc[d][0].kind == LSM_BC_PERIODIC, pr = bc[d][1].kind == LSM_BC_PERIODIC;
+        const bool slabface = bc[d][0].kind == LSM_BC_NONE || bc[d][1].kind == LSM_BC_NONE;
+        if (pl != pr && !slabface)   // src/boundaryconditions.jl:184-186
+            return fail(nullptr, LSM_ERR_INVALID, "periodic boundary conditions cannot be mixed with others in a dimension");
+        for (int s = 0; s < 2; ++s) {
+            const LsmBc& b = bc[d][s];
+            if (b.kind < 0 || b.kind > LSM_BC_NONE) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad bc kind");
+            if (b.kind == LSM_BC_EXTRAPOLATION && (b.degree < 0 || b.degree > 7))   // src/boundaryconditions.jl:42
+                return fail(nullptr, LSM_ERR_INVALID, "extrapolation order P must be in 0..7");
+            if (b.kind == LSM_BC_NONE && d != N - 1)
+                return fail(nullptr, LSM_ERR_INVALID, "LSM_BC_NONE (slab interface) is only valid on the last dimension");
+        }
+    }
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0)
+        return fail(nullptr, LSM_ERR_NO_DEVICE, "lsm_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= dev_count) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad device index");
+
+    LsmHandle* h = new LsmHandle();
+    h->grid = *grid;
+    memcpy(h->bc, bc, sizeof(h->bc));
+    h->dtype = dtype; h->mode = mode; h->device = device;
+    h->prof = false; h->ev_used = 0;
+    h->slab.lo = 0; h->slab.n = grid->n[N - 1];
+    if (slab) h->slab = *slab;
+    if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
+        delete h;
+        return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad slab (needs >= 3 planes inside the grid)");
+    }
+    long long s = 1;
+    h->lay.origin = 0;
+    for (int d = 0; d < 3; ++d) {
+        h->nloc[d] = (int)grid->n[d];
+        h->goff[d] = 0;
+        h->gn[d] = (int)grid->n[d];
+        if (d == N - 1) { h->nloc[d] = (int)h->slab.n; h->goff[d] = (int)h->slab.lo; }
+        h->lay.n[d] = h->nloc[d];
+        h->lay.g[d] = d < N ? LSM_GHOST : 0;
+        h->lay.stride[d] = s;
+        h->lay.origin += h->lay.g[d] * s;
+        s *= h->lay.n[d] + 2 * h->lay.g[d];
+    }
+    h->lay.total = s;
+    h->dxmin = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (d < N) {
+            h->h[d] = (grid->hc[d] - grid->lc[d]) / (double)(grid->n[d] - 1);   // src/meshes.jl:110
+            h->h2[d] = h->h[d] * h->h[d];
+            h->inv_h[d] = 1.0 / h->h[d];
+            h->inv_h2[d] = 1.0 / h->h2[d];
+            h->dxmin = d == 0 ? h->h[d] : (h->h[d] < h->dxmin ? h->h[d] : h->dxmin);
+            if (!(h->h[d] > 0)) { delete h; return fail(nullptr, LSM_ERR_INVALID, "lsm_create: hc must exceed lc"); }
+        } else {
+            h->h[d] = h->h2[d] = h->inv_h[d] = h->inv_h2[d] = 1.0;
+        }
+        for (int sd = 0; sd < 2; ++sd)
+            for (int k = 1; k <= LSM_GHOST; ++k)
+                for (int j = 0; j < 8; ++j) {
+                    const LsmBc& b = h->bc[d][sd];
+                    h->w[d][sd][k - 1][j] =
+                        (b.kind == LSM_BC_EXTRAPOLATION && j <= b.degree) ? lagrange_w(j, k, b.degree) : 0.0;
+                }
+        if (d < N)
+            for (int sd = 0; sd < 2; ++sd)
+                if (h->bc[d][sd].kind == LSM_BC_EXTRAPOLATION && h->bc[d][sd].degree + 1 > h->nloc[d]) {
+                    delete h;
+                    return fail(nullptr, LSM_ERR_INVALID, "lsm_create: extrapolation degree exceeds the node count");
+                }
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    h->own_stream = true;
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_partial, sizeof(double) * 2 * MAXB);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 2);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 2, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        std::string m = std::string("lsm_create: ") + hipGetErrorString(e);
+        delete h;
+        return fail(nullptr, LSM_ERR_HIP, m);
+    }
+    *out = h;
+    return LSM_OK;
+}
+
+void lsm_destroy(LsmHandle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto e : h->ev_start) (void)hipEventDestroy(e);
+    for (auto e : h->ev_stop) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_partial);
+    (void)hipFree(h->d_flag);
+    (void)hipFree(h->d_result);
+    (void)hipHostFree(h->h_result);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// adopt an external stream (e.g. the one the caller's array library works on)
+int lsm_set_stream(LsmHandle* h, void* stream) {
+    if (!h) return LSM_ERR_INVALID;
+    if (h->own_stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return LSM_OK;
+}
+
+int lsm_sync(LsmHandle* h) {
+    if (!h) return LSM_ERR_INVALID;
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    return LSM_OK;
+}
+
+int lsm_layout(const LsmHandle* h, LsmLayout* out) {
+    if (!h || !out) return LSM_ERR_INVALID;
+    *out = h->lay;
+    return LSM_OK;
+}
+
+static int copy_interior(LsmHandle* h, void* dev, void* host, bool to_dev) {
+    LSM_HIP(h, hipSetDevice(h->device));
+    const size_t row = sizeof(double) * (size_t)h->nloc[0];
+    for (int k = 0; k < h->nloc[2]; ++k) {
+        double* d = (double*)dev + h->lay.origin + (long long)k * h->lay.stride[2];
+        double* s = (double*)host + (size_t)k * h->nloc[0] * h->nloc[1];
+        if (to_dev)
+            LSM_HIP(h, hipMemcpy2DAsync(d, sizeof(double) * h->lay.stride[1], s, row, row, h->nloc[1], hipMemcpyHostToDevice, h->stream));
+        else
+            LSM_HIP(h, hipMemcpy2DAsync(s, row, d, sizeof(double) * h->lay.stride[1], row, h->nloc[1], hipMemcpyDeviceToHost, h->stream));
+    }
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    return LSM_OK;
+}
+int lsm_upload(LsmHandle* h, void* dev_padded, const void* host_dense) {
+    if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
+    return copy_interior(h, dev_padded, (void*)host_dense, true);
+}
+int lsm_download(LsmHandle* h, const void* dev_padded, void* host_dense) {
+    if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
+    return copy_interior(h, (void*)dev_padded, host_dense, false);
+}
+
+int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
+    if (!h || !field) return LSM_ERR_INVALID;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const int N = h->grid.ndim;
+    for (int d = 0; d < N; ++d) {
+        if (!((dim_mask >> d) & 1)) continue;
+        if (h->bc[d][0].kind == LSM_BC_NONE && h->bc[d][1].kind == LSM_BC_NONE) continue;
+        GhostArgs a;
+        for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
+        a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+        a.dim = d;
+        for (int sd = 0; sd < 2; ++sd) { a.kind[sd] = h->bc[d][sd].kind; a.degree[sd] = h->bc[d][sd].degree; }
+        memcpy(a.w, h->w[d], sizeof(a.w));
+        a.v = (double*)field;
+        launch_ghost_fill(N, a, s);
+    }
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+static void fill_coeff(const LsmCoeff& c, double t, CoeffArgs& o) {
+    o.kind = c.kind;
+    for (int k = 0; k < 4; ++k) o.v[k] = c.value[k];
+    o.tfac = c.time_kind == LSM_TIME_COS ? cos(M_PI * t / c.time_param) : 1.0;
+    for (int k = 0; k < 3; ++k) { o.f[k] = (const double*)c.field[k]; o.sep[k] = c.sep[k]; }
+}
+
+static void base_args(const LsmHandle* h, StageArgs& a) {
+    memset(&a, 0, sizeof(a));
+    for (int d = 0; d < 3; ++d) {
+        a.n[d] = h->nloc[d]; a.goff[d] = h->goff[d]; a.gn[d] = h->gn[d];
+        a.lc[d] = h->grid.lc[d]; a.h[d] = h->h[d]; a.h2[d] = h->h2[d]; a.inv_h[d] = h->inv_h[d]; a.inv_h2[d] = h->inv_h2[d];
+    }
+    a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+    a.dxmin = h->dxmin;
+}
+
+static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
+    if (c.kind < 0 || c.kind > LSM_COEFF_FIELD) return fail(h, LSM_ERR_INVALID, "bad coefficient kind");
+    if (c.kind == LSM_COEFF_FIELD)
+        for (int k = 0; k < ncomp; ++k)
+            if (!c.field[k]) return fail(h, LSM_ERR_INVALID, "FIELD coefficient with a null component");
+    if (c.kind == LSM_COEFF_SEPARABLE)
+        for (int k = 0; k < ncomp; ++k)
+            if (!c.sep[k]) return fail(h, LSM_ERR_INVALID, "SEPARABLE coefficient with a null table");
+    if (c.kind == LSM_COEFF_ROTATION && h->grid.ndim < 2) return fail(h, LSM_ERR_INVALID, "ROTATION needs ndim >= 2");
+    return LSM_OK;
+}
+
+static int profile_pair(LsmHandle* h, hipEvent_t* a, hipEvent_t* b) {
+    if (h->ev_used == h->ev_start.size()) {
+        hipEvent_t x, y;
+        LSM_HIP(h, hipEventCreate(&x));
+        LSM_HIP(h, hipEventCreate(&y));
+        h->ev_start.push_back(x);
+        h->ev_stop.push_back(y);
+    }
+    *a = h->ev_start[h->ev_used];
+    *b = h->ev_stop[h->ev_used];
+    h->ev_used++;
+    return LSM_OK;
+}
+
+int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+              int base_mode, double cdt, double cdt2, double t_stage, void* stream) {
+    if (!h || !terms || !psi || !out) return h ? fail(h, LSM_ERR_INVALID, "lsm_stage: null argument") : LSM_ERR_INVALID;
+    if (nterms < 1 || nterms > LSM_MAX_TERMS) return fail(h, LSM_ERR_INVALID, "lsm_stage: nterms must be in 1..8");
+    if (base_mode != LSM_BASE_PSI && !phin) return fail(h, LSM_ERR_INVALID, "lsm_stage: phin required for this base mode");
+    if (psi == out || psi == out2) return fail(h, LSM_ERR_INVALID, "lsm_stage: out must not alias the stencil input psi");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const int N = h->grid.ndim;
+    int i = 0;
+    bool first = true;
+    while (i < nterms) {
+        Combo c{0, 0, 0, 0};
+        StageArgs a;
+        base_args(h, a);
+        int cnt = 0;
+        while (i < nterms && cnt < NSLOTS) {
+            const LsmTerm& tm = terms[i];
+            Combo trial = c;
+            int slot;
+            switch (tm.kind) {
+            case LSM_TERM_ADVECTION:
+                if (c.adv) goto flush;
+                if (tm.scheme != LSM_SCHEME_UPWIND && tm.scheme != LSM_SCHEME_WENO5) return fail(h, LSM_ERR_INVALID, "bad scheme");
+                trial.adv = tm.scheme == LSM_SCHEME_WENO5 ? 2 : 1; slot = SLOT_ADV; break;
+            case LSM_TERM_NORMAL_MOTION: if (c.nm) goto flush; trial.nm = 1; slot = SLOT_NM; break;
+            case LSM_TERM_CURVATURE: if (c.curv) goto flush; trial.curv = 1; slot = SLOT_CURV; break;
+            case LSM_TERM_EIKONAL: if (c.eik) goto flush; trial.eik = tm.s0 ? 1 : 2; slot = SLOT_EIK; break;
+            default: return fail(h, LSM_ERR_INVALID, "lsm_stage: bad term kind");
+            }
+            if (!combo_available(trial)) break;
+            c = trial;
+            a.order[cnt++] = slot;
+            if (slot == SLOT_ADV) { int r = check_coeff(h, tm.coeff, N); if (r) return r; fill_coeff(tm.coeff, t_stage, a.adv); a.adv_scheme = tm.scheme; }
+            if (slot == SLOT_NM) { int r = check_coeff(h, tm.coeff, 1); if (r) return r; fill_coeff(tm.coeff, t_stage, a.nm); }
+            if (slot == SLOT_CURV) { int r = check_coeff(h, tm.coeff, 1); if (r) return r; fill_coeff(tm.coeff, t_stage, a.curv); }
+            if (slot == SLOT_EIK) a.s0 = (const double*)tm.s0;
+            ++i;
+        }
+    flush:
+        if (cnt == 0) return fail(h, LSM_ERR_INVALID, "lsm_stage: internal planner error");
+        a.nterms = cnt;
+        a.psi = (const double*)psi;
+        a.out = (double*)out;
+        a.out2 = (double*)out2;
+        a.cdt = cdt; a.cdt2 = cdt2;
+        if (first) { a.base_mode = base_mode; a.phin = (const double*)phin; a.out2_accum = 0; }
+        else       { a.base_mode = LSM_BASE_OTHER; a.phin = (const double*)out; a.out2_accum = 1; }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) { int r = profile_pair(h, &e0, &e1); if (r) return r; LSM_HIP(h, hipEventRecord(e0, s)); }
+        int r;
+        if (h->mode == LSM_MODE_STRICT)
+            r = N == 1 ? launch_stage_strict_1d(c, a, s) : (N == 2 ? launch_stage_strict_2d(c, a, s) : launch_stage_strict_3d(c, a, s));
+        else
+            r = N == 1 ? launch_stage_fast_1d(c, a, s) : (N == 2 ? launch_stage_fast_2d(c, a, s) : launch_stage_fast_3d(c, a, s));
+        if (r) return fail(h, LSM_ERR_INVALID, "lsm_stage: kernel combination not instantiated");
+        if (h->prof) LSM_HIP(h, hipEventRecord(e1, s));
+        first = false;
+    }
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+// Julia's min: NaN-propagating
+static double jl_min(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (b < a ? b : a); }
+
+int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, double t, double* dt_out) {
+    if (!h || !terms || !dt_out) return h ? fail(h, LSM_ERR_INVALID, "lsm_compute_cfl: null argument") : LSM_ERR_INVALID;
+    if (nterms < 1 || nterms > LSM_MAX_TERMS) return fail(h, LSM_ERR_INVALID, "lsm_compute_cfl: nterms must be in 1..8");
+    (void)phi;
+    const int N = h->grid.ndim;
+    double best = 0;
+    for (int k = 0; k < nterms; ++k) {
+        const LsmTerm& tm = terms[k];
+        double dt;
+        if (tm.kind == LSM_TERM_EIKONAL) {
+            dt = h->dxmin;                                                 // src/levelsetterms.jl:250
+        } else if (tm.coeff.kind == LSM_COEFF_CONST) {                     // node-independent: evaluate once
+            if (tm.kind == LSM_TERM_CURVATURE) {
+                dt = (h->dxmin * h->dxmin) / (2 * fabs(tm.coeff.value[0]));      // :123-127
+            } else {
+                double s = 0;
+                for (int d = 0; d < N; ++d) {
+                    const double u = tm.kind == LSM_TERM_ADVECTION ? tm.coeff.value[d] : tm.coeff.value[0];
+                    const double q = fabs(u) / h->h[d];
+                    s = d == 0 ? q : s + q;
+                }
+                dt = 1 / s;                                                      // :90-96, :172-178
+            }
+        } else {
+            if (tm.kind < 0 || tm.kind > LSM_TERM_EIKONAL) return fail(h, LSM_ERR_INVALID, "bad term kind");
+            int r = check_coeff(h, tm.coeff, tm.kind == LSM_TERM_ADVECTION ? N : 1);
+            if (r) return r;
+            CflArgs a;
+            memset(&a, 0, sizeof(a));
+            for (int d = 0; d < 3; ++d) {
+                a.n[d] = h->nloc[d]; a.goff[d] = h->goff[d]; a.gn[d] = h->gn[d];
+                a.lc[d] = h->grid.lc[d]; a.h[d] = h->h[d];
+            }
+            a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+            a.term_kind = tm.kind;
+            fill_coeff(tm.coeff, t, a.coeff);
+            a.partial = h->d_partial;
+            a.nanflag = h->d_flag;
+            int nb = cfl_blocks(N, h->nloc);
+            if (nb > MAXB) nb = MAXB;
+            LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+            launch_cfl(N, a, nb, h->stream);
+            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, h->stream);
+            LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            LSM_HIP(h, hipStreamSynchronize(h->stream));
+            dt = h->h_result[0];
+        }
+        best = k == 0 ? dt : jl_min(best, dt);
+    }
+    *dt_out = best;
+    return LSM_OK;
+}
+
+static int check_single_device(LsmHandle* h) {
+    const int N = h->grid.ndim;
+    if (h->bc[N - 1][0].kind == LSM_BC_NONE || h->bc[N - 1][1].kind == LSM_BC_NONE)
+        return fail(h, LSM_ERR_INVALID,
+                    "lsm_advance_*: this handle is a slab of a multi-GPU grid; drive it with lsm_stage + lsm_fill_ghosts + halo exchange");
+    return LSM_OK;
+}
+static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, const void* field, double t) {
+    if (!hook) return LSM_OK;
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    if (hook(user, stage, field, t)) return fail(h, LSM_ERR_INVALID, "stage hook requested abort");
+    return LSM_OK;
+}
+#define LSM_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+
+// _advance!(::ForwardEuler) — src/timestepping.jl:128-137
+int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, double tc, double dt,
+                   LsmStageHook hook, void* user) {
+    if (!h || !phi || !buf1) return LSM_ERR_INVALID;
+    LSM_TRY(check_single_device(h));
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
+    LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));
+    LSM_HIP(h, hipMemcpyAsync(phi, buf1, sizeof(double) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));   // copy!(ϕ, dst)
+    return lsm_fill_ghosts(h, phi, 7, nullptr);
+}
+
+// _advance!(::RK2) — src/timestepping.jl:143-164 (pred = buf1, corr = buf2; the final copy!(ϕ, corr)
+// is folded into the corrector, which writes ϕ directly)
+int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc, double dt,
+                    LsmStageHook hook, void* user) {
+    if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
+    LSM_TRY(check_single_device(h));
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
+    LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc, nullptr));
+    LSM_TRY(lsm_fill_ghosts(h, buf1, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+    LSM_TRY(lsm_stage(h, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt, nullptr));
+    return lsm_fill_ghosts(h, phi, 7, nullptr);
+}
+
+// _advance!(::RK3) — src/timestepping.jl:170-202 (stage 3 writes ϕ in place: it reads ϕ only pointwise)
+int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc, double dt,
+                    LsmStageHook hook, void* user) {
+    if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
+    LSM_TRY(check_single_device(h));
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
+    LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));
+    LSM_TRY(lsm_fill_ghosts(h, buf1, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+    LSM_TRY(lsm_stage(h, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt, nullptr));
+    LSM_TRY(lsm_fill_ghosts(h, buf2, 7, nullptr));
+    LSM_TRY(run_hook(h, hook, user, 2, buf2, tc + 0.5 * dt));
+    LSM_TRY(lsm_stage(h, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt, nullptr));
+    return lsm_fill_ghosts(h, phi, 7, nullptr);
+}
+
+int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream) {
+    if (!h || !phi0 || !s0_out) return LSM_ERR_INVALID;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    launch_eikonal_sign(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->dxmin,
+                        (const double*)phi0, (double*)s0_out, s);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
+    if (!h || !phi || !vmin || !vmax) return LSM_ERR_INVALID;
+    int nb = cfl_blocks(h->grid.ndim, h->nloc);
+    if (nb > MAXB) nb = MAXB;
+    launch_extrema(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, (const double*)phi, h->d_partial,
+                   h->d_partial + MAXB, nb, h->d_result, h->stream);
+    LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    *vmin = h->h_result[0];
+    *vmax = h->h_result[1];
+    return LSM_OK;
+}
+
+int lsm_profile_enable(LsmHandle* h, int on) {
+    if (!h) return LSM_ERR_INVALID;
+    h->prof = on != 0;
+    h->ev_used = 0;
+    return LSM_OK;
+}
+
+int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total) {
+    if (!h || !n_stage_launches || !stage_ms_total) return LSM_ERR_INVALID;
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    double tot = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0;
+        LSM_HIP(h, hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i]));
+        tot += ms;
+    }
+    *n_stage_launches = (int64_t)h->ev_used;
+    *stage_ms_total = tot;
+    h->ev_used = 0;
+    return LSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// lsm_aux.hip — the small kernels around the stage kernel: ghost-layer fill, CFL reduction,
+// extrema, Eikonal sign map.  Built with -ffp-contract=off: ghost values and the CFL minimum are
+// bit-for-bit those of the reference arithmetic (they cost nothing next to a stage).
+#include "lsm_internal.h"
+
+namespace lsm {
+
+// ---------------------------------------------------------------------------------------------
+// Ghost fill of ONE dimension: _getindexbc + bc_stencil (src/meshfield.jl:248-260,
+// src/boundaryconditions.jl:107-153).  Filling dims 1..N in order, each pass covering the ghosts
+// already written by the lower dimensions, reproduces the recursion's corner composition exactly:
+//   ghost(i_g, j_g) = Σ_j w2_j · ( Σ_i w1_i ϕ[I_i, J_j] ).
+// One thread per transverse position; it writes the 2·LSM_GHOST ghosts of its line.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ghost_fill_kernel(const GhostArgs a, int ndim) {
+    const int d = a.dim;
+    // transverse extents: lower dims incl. ghosts, higher dims interior
+    int lo[3], ext[3];
+    for (int e = 0; e < 3; ++e) {
+        const int g = e < ndim ? LSM_GHOST : 0;
+        if (e < d) { lo[e] = -g; ext[e] = a.n[e] + 2 * g; }
+        else       { lo[e] = 0;  ext[e] = a.n[e]; }
+    }
+    ext[d] = 1;
+    const long long total = (long long)ext[0] * ext[1] * ext[2];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int I[3];
+    I[0] = lo[0] + (int)(t % ext[0]);
+    I[1] = lo[1] + (int)((t / ext[0]) % ext[1]);
+    I[2] = lo[2] + (int)(t / ((long long)ext[0] * ext[1]));
+    const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+    I[d] = 0;
+    double* line = a.v + a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;   // node 0 of this line
+    const int n = a.n[d];
+    for (int side = 0; side < 2; ++side) {
+        const int kind = a.kind[side];
+        if (kind == LSM_BC_NONE) continue;
+        const int b = side == 0 ? 0 : n - 1;
+        const int dir = side == 0 ? 1 : -1;
+        for (int k = 1; k <= LSM_GHOST; ++k) {
+            double acc = 0.0;
+            if (kind == LSM_BC_PERIODIC) {
+                const int j = side == 0 ? (n - 1) - k : k;          // period n-1 (src/boundaryconditions.jl:107-119)
+                acc += 1.0 * line[j * sd];
+            } else if (kind == LSM_BC_EXTRAPOLATION) {
+                for (int j = 0; j <= a.degree[side]; ++j) acc += a.w[side][k - 1][j] * line[(b + dir * j) * sd];
+            } else {
+                acc += 1.0 * line[(b + dir * k) * sd];              // mirror about the boundary node
+            }
+            line[(b - dir * k) * sd] = acc;
+        }
+    }
+}
+
+void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s) {
+    long long total = 1;
+    for (int e = 0; e < 3; ++e) {
+        if (e == a.dim) continue;
+        const int g = e < ndim ? LSM_GHOST : 0;
+        total *= (e < a.dim) ? a.n[e] + 2 * g : a.n[e];
+    }
+    const int block = 256;
+    const unsigned grid = (unsigned)((total + block - 1) / block);
+    hipLaunchKernelGGL(ghost_fill_kernel, dim3(grid), dim3(block), 0, s, a, ndim);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NaN-propagating min reduction helpers (Julia's min(x, NaN) = NaN, src/levelsetterms.jl:31-38).
+// The minimum over non-NaN values and an "any NaN" flag are reduced separately.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <int NCOMP>
+__device__ __forceinline__ void cfl_coeff(const CoeffArgs& c, const CflArgs& a, int ndim, const int gi[3], long long center,
+                                          double out[3]) {
+    if (c.kind == LSM_COEFF_CONST) {
+        for (int k = 0; k < NCOMP; ++k) out[k] = c.v[k];
+    } else if (c.kind == LSM_COEFF_ROTATION) {
+        const double x1 = a.lc[0] + (double)gi[0] * a.h[0];
+        const double x2 = ndim > 1 ? a.lc[1] + (double)gi[1] * a.h[1] : 0.0;
+        out[0] = -(c.v[0] * (x2 - c.v[2]));
+        if (NCOMP > 1) out[1] = c.v[0] * (x1 - c.v[1]);
+        if (NCOMP > 2) out[2] = 0.0;
+    } else if (c.kind == LSM_COEFF_SEPARABLE) {
+        for (int k = 0; k < NCOMP; ++k) {
+            const double* T = c.sep[k];
+            double p = T[gi[0]];
+            if (ndim > 1) p = p * T[a.gn[0] + gi[1]];
+            if (ndim > 2) p = p * T[a.gn[0] + a.gn[1] + gi[2]];
+            out[k] = p * c.tfac;
+        }
+    } else {
+        for (int k = 0; k < NCOMP; ++k) out[k] = c.f[k][center];
+    }
+}
+
+// per-node CFL of one term, grid-stride; one partial per block (src/levelsetterms.jl:90-96,172-178)
+__global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
+    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
+    double best = __builtin_inf();
+    int sawnan = 0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        int I[3];
+        I[0] = (int)(t % a.n[0]);
+        I[1] = (int)((t / a.n[0]) % a.n[1]);
+        I[2] = (int)(t / ((long long)a.n[0] * a.n[1]));
+        const int gi[3] = {I[0] + a.goff[0], I[1] + a.goff[1], I[2] + a.goff[2]};
+        const long long center = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
+        double u[3] = {0, 0, 0};
+        double cfl;
+        if (a.term_kind == LSM_TERM_ADVECTION) {
+            if (ndim == 1) cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+            else if (ndim == 2) cfl_coeff<2>(a.coeff, a, ndim, gi, center, u);
+            else cfl_coeff<3>(a.coeff, a, ndim, gi, center, u);
+            double s = __builtin_fabs(u[0]) / a.h[0];
+            if (ndim > 1) s = s + __builtin_fabs(u[1]) / a.h[1];
+            if (ndim > 2) s = s + __builtin_fabs(u[2]) / a.h[2];
+            cfl = 1 / s;
+        } else if (a.term_kind == LSM_TERM_NORMAL_MOTION) {
+            cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+            double s = __builtin_fabs(u[0]) / a.h[0];
+            if (ndim > 1) s = s + __builtin_fabs(u[0]) / a.h[1];
+            if (ndim > 2) s = s + __builtin_fabs(u[0]) / a.h[2];
+            cfl = 1 / s;
+        } else { /* curvature with a field/analytic b: Δx² / (2|b|) */
+            cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+            double dx = a.h[0];
+            if (ndim > 1) dx = a.h[1] < dx ? a.h[1] : dx;
+            if (ndim > 2) dx = a.h[2] < dx ? a.h[2] : dx;
+            cfl = (dx * dx) / (2 * __builtin_fabs(u[0]));
+        }
+        if (cfl != cfl) sawnan = 1;
+        else best = cfl < best ? cfl : best;
+    }
+    best = wave_min(best);
+    sawnan = __any(sawnan) ? 1 : 0;
+    __shared__ double smin[4];
+    __shared__ int snan[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { smin[wave] = best; snan[wave] = sawnan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = smin[0];
+        int f = snan[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smin[w] < m ? smin[w] : m; f |= snan[w]; }
+        a.partial[blockIdx.x] = m;
+        if (f) atomicOr(a.nanflag, 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, int nblocks, const int* nanflag, double* out) {
+    double best = __builtin_inf();
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) best = partial[i] < best ? partial[i] : best;
+    best = wave_min(best);
+    __shared__ double smin[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) smin[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = smin[0];
+        for (int w = 1; w < 4; ++w) m = smin[w] < m ? smin[w] : m;
+        out[0] = *nanflag ? __builtin_nan("") : m;
+    }
+}
+
+int cfl_blocks(int /*ndim*/, const int n[3]) {
+    const long long total = (long long)n[0] * n[1] * n[2];
+    long long b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(cfl_kernel, dim3(nblocks), dim3(256), 0, s, a, ndim);
+}
+void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(cfl_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, nanflag, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// extrema of the interior (show, src/meshfield.jl:300-303)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) extrema_kernel(int n0, int n1, int n2, long long s1, long long s2, long long origin,
+                                                      const double* v, double* pmin, double* pmax) {
+    const long long total = (long long)n0 * n1 * n2;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
+        const double x = v[origin + i0 + i1 * s1 + i2 * s2];
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    __shared__ double sl[4], sh[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sl[wave] = lo; sh[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = sl[w] < lo ? sl[w] : lo; hi = sh[w] > hi ? sh[w] : hi; }
+        lo = sl[0] < lo ? sl[0] : lo;
+        hi = sh[0] > hi ? sh[0] : hi;
+        pmin[blockIdx.x] = lo;
+        pmax[blockIdx.x] = hi;
+    }
+}
+__global__ void __launch_bounds__(256) extrema_final_kernel(const double* pmin, const double* pmax, int nblocks, double* out2) {
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        lo = pmin[i] < lo ? pmin[i] : lo;
+        hi = pmax[i] > hi ? pmax[i] : hi;
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    __shared__ double sl[4], sh[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sl[wave] = lo; sh[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 4; ++w) { lo = sl[w] < lo ? sl[w] : lo; hi = sh[w] > hi ? sh[w] : hi; }
+        out2[0] = lo;
+        out2[1] = hi;
+    }
+}
+void launch_extrema(int /*ndim*/, const int n[3], long long s1, long long s2, long long origin, const double* v,
+                    double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s) {
+    hipLaunchKernelGGL(extrema_kernel, dim3(nblocks), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, v, partial_min,
+                       partial_max);
+    hipLaunchKernelGGL(extrema_final_kernel, dim3(1), dim3(256), 0, s, partial_min, partial_max, nblocks, out2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// EikonalReinitializationTerm(ϕ₀): S₀ = v / sqrt(v² + Δx²) on the interior (src/levelsetterms.jl:217-221)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) eikonal_sign_kernel(int n0, int n1, int n2, long long s1, long long s2,
+                                                           long long origin, double dx, const double* phi0, double* s0) {
+    const long long total = (long long)n0 * n1 * n2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
+        const long long q = origin + i0 + i1 * s1 + i2 * s2;
+        const double v = phi0[q];
+        s0[q] = v / __builtin_sqrt(v * v + dx * dx);
+    }
+}
+void launch_eikonal_sign(int /*ndim*/, const int n[3], long long s1, long long s2, long long origin, double dxmin,
+                         const double* phi0, double* s0, hipStream_t s) {
+    const long long total = (long long)n[0] * n[1] * n[2];
+    long long b = (total + 255) / 256;
+    const int nb = (int)(b > 4096 ? 4096 : b);
+    hipLaunchKernelGGL(eikonal_sign_kernel, dim3(nb), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, dxmin, phi0, s0);
+}
+
+}  // namespace lsm

@@ -1,0 +1,98 @@
+// lsm_internal.h — structs shared by the host API (lsm_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lsm.h"
+
+namespace lsm {
+
+// term-kind slots inside a fused stage kernel
+enum { SLOT_ADV = 0, SLOT_NM = 1, SLOT_CURV = 2, SLOT_EIK = 3, NSLOTS = 4 };
+
+// device view of an LsmCoeff, time factor already evaluated on the host for this stage
+struct CoeffArgs {
+    int kind;
+    int _pad;
+    double v[4];
+    double tfac;
+    const double* f[3];
+    const double* sep[3];
+};
+
+// everything a stage kernel needs, passed by value
+struct StageArgs {
+    // geometry (local slab)
+    int n[3];          // local interior extent
+    int goff[3];       // global index of local (0,0,0)
+    int gn[3];         // global node counts
+    long long s1, s2;  // strides of dim 1 and dim 2 (elements)
+    long long origin;
+    double lc[3];
+    double h[3];       // meshsize (src/meshes.jl:110), computed on the host in IEEE double
+    double h2[3];      // h*h
+    double inv_h[3];
+    double inv_h2[3];
+    double dxmin;      // minimum(meshsize)
+    // fields
+    const double* psi;
+    const double* phin;
+    double* out;
+    double* out2;
+    int base_mode;     // LSM_BASE_*
+    int out2_accum;    // 0: out2 starts from psi, 1: out2 accumulates onto itself (multi-pass)
+    double cdt, cdt2;
+    // terms of this pass, in user order: order[k] is a SLOT_*
+    int nterms;
+    int order[NSLOTS];
+    int adv_scheme;
+    CoeffArgs adv, nm, curv;
+    const double* s0;  // Eikonal frozen sign (NULL = current-sign mode)
+};
+
+struct GhostArgs {
+    int n[3];
+    long long s1, s2, origin;
+    int dim;             // dimension being filled
+    int kind[2];         // per side
+    int degree[2];
+    double w[2][LSM_GHOST][8];  // Lagrange weights per side, ghost distance k-1, node j
+    double* v;
+};
+
+struct CflArgs {
+    int n[3];
+    int goff[3];
+    int gn[3];
+    long long s1, s2, origin;
+    double lc[3];
+    double h[3];
+    int term_kind;
+    CoeffArgs coeff;
+    double* partial;     // one value per block
+    int* nanflag;        // set to 1 if any node produced NaN
+};
+
+// compile-time description of one instantiated fused kernel
+struct Combo {
+    int adv;   // 0 none, 1 upwind, 2 weno5
+    int nm;    // 0/1
+    int curv;  // 0/1
+    int eik;   // 0 none, 1 frozen S0, 2 current sign
+};
+
+// launchers implemented in stage_{fast,strict}.hip; return 0 if the combo is instantiated
+int launch_stage_fast(int ndim, const Combo& c, const StageArgs& a, hipStream_t s);
+int launch_stage_strict(int ndim, const Combo& c, const StageArgs& a, hipStream_t s);
+bool combo_available(const Combo& c);
+
+// small kernels (lsm_aux.hip)
+void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s);
+int cfl_blocks(int ndim, const int n[3]);
+void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s);
+void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, hipStream_t s);
+void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const double* v,
+                    double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s);
+void launch_eikonal_sign(int ndim, const int n[3], long long s1, long long s2, long long origin, double dxmin,
+                         const double* phi0, double* s0, hipStream_t s);
+
+}  // namespace lsm

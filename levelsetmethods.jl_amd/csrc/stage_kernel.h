@@ -1,0 +1,461 @@
+// stage_kernel.h — the fused RK-stage kernel: one loop body of _advance!
+// (src/timestepping.jl:128-137,143-164,170-202) for all terms of a pass, one thread per grid node.
+//
+// Decomposition (CDNA4, 64-wide waves):
+//   * a workgroup owns a TX×TY tile of the leading dimension(s) and MARCHES along the last
+//     dimension (z in 3-D, y in 2-D): the stencil line along the march axis lives in registers
+//     (2G+1 doubles per thread), the current plane's tile + halo lives in LDS for the x/y
+//     neighbours.  Each ψ value is fetched from HBM/L2 once per tile (+halo), every neighbour
+//     read is an LDS ds_read_b64 or a register.
+//   * the LDS planes form a ring of 2·LEAD+2 slots (LEAD = 1 when the curvature term needs the
+//     edge-diagonal neighbours of planes m±1): ONE s_barrier per plane, the next plane's global
+//     loads are issued before the barrier and written to LDS after the compute (issue-early /
+//     write-late), so their latency hides under ≈340 fp64 VALU slots of WENO arithmetic.
+//   * upwind selection never diverges: the biased stencil is fetched through a sign-flipped LDS
+//     stride (x,y) or v_cndmask on the register line (march axis).
+#pragma once
+#include <type_traits>
+#include "lsm_internal.h"
+#include "stage_math.h"
+
+namespace lsm {
+namespace LSM_NS {
+
+constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
+    int g = 0;
+    if (ADV == 2) g = 3;
+    if (ADV == 1 && g < 1) g = 1;
+    if ((NM || EIK) && g < 2) g = 2;
+    if (CURV && g < 1) g = 1;
+    return g;
+}
+
+// _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h)
+template <int NDIM, int NCOMP>
+LSM_DEV void eval_coeff(const CoeffArgs& c, const StageArgs& a, const int gi[3], long long center, double out[3]) {
+    if (c.kind == LSM_COEFF_CONST) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) out[k] = c.v[k];
+    } else if (c.kind == LSM_COEFF_ROTATION) {
+        double x1 = a.lc[0] + (double)gi[0] * a.h[0];
+        double x2 = NDIM > 1 ? a.lc[1] + (double)gi[1] * a.h[1] : 0.0;
+        out[0] = -(c.v[0] * (x2 - c.v[2]));
+        if (NCOMP > 1) out[1] = c.v[0] * (x1 - c.v[1]);
+        if (NCOMP > 2) out[2] = 0.0;
+    } else if (c.kind == LSM_COEFF_SEPARABLE) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) {
+            const double* T = c.sep[k];
+            double p = T[gi[0]];
+            if (NDIM > 1) p = p * T[a.gn[0] + gi[1]];
+            if (NDIM > 2) p = p * T[a.gn[0] + a.gn[1] + gi[2]];
+            out[k] = p * c.tfac;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) out[k] = c.f[k][center];
+    }
+}
+
+// Everything one node needs: pointers into the LDS ring at the node's own position and the
+// register line along the march axis.
+template <int NDIM, int G, int W>
+struct NodeView {
+    const double* T0;   // plane m   (own position)
+    const double* Tm;   // plane m-1 (curvature only)
+    const double* Tp;   // plane m+1 (curvature only)
+    const double* zl;   // register line, zl[G] = centre (MARCH only)
+    double c;           // centre value
+    // neighbour at offset k along dimension D
+    template <int D>
+    LSM_DEV double at(int k) const {
+        if constexpr (D == 0) return T0[k];
+        else if constexpr (D == 1 && NDIM == 3) return T0[k * W];
+        else return zl[G + k];
+    }
+    // neighbour at (sa along A, sb along B), A<B, for the mixed second difference
+    template <int A, int B>
+    LSM_DEV double corner(int sa, int sb) const {
+        if constexpr (NDIM == 3 && A == 0 && B == 1) return T0[sa + sb * W];
+        else {
+            const double* P = sb > 0 ? Tp : Tm;
+            if constexpr (A == 0) return P[sa];
+            else return P[sa * W];
+        }
+    }
+};
+
+template <int NDIM, int D, int G, int W, class NV>
+LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
+    const bool up = v > 0;
+    double q[6];
+    if constexpr (D == 0 || (D == 1 && NDIM == 3)) {
+        constexpr int st = D == 0 ? 1 : W;
+        const int ss = up ? st : -st;
+        q[0] = nv.T0[-3 * ss]; q[1] = nv.T0[-2 * ss]; q[2] = nv.T0[-ss];
+        q[3] = nv.c;
+        q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
+    } else {
+        q[0] = up ? nv.zl[G - 3] : nv.zl[G + 3];
+        q[1] = up ? nv.zl[G - 2] : nv.zl[G + 2];
+        q[2] = up ? nv.zl[G - 1] : nv.zl[G + 1];
+        q[3] = nv.c;
+        q[4] = up ? nv.zl[G + 1] : nv.zl[G - 1];
+        q[5] = up ? nv.zl[G + 2] : nv.zl[G - 2];
+    }
+    const double hs = up ? a.h[D] : -a.h[D];
+    const double ihs = up ? a.inv_h[D] : -a.inv_h[D];
+    return weno5_upwind(q, hs, ihs, 1.0e-99 * a.h2[D]);
+}
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class NV>
+LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long long idx, bool active) {
+    const double c = nv.c;
+    double Ladv = 0.0, Lnm = 0.0, Lcurv = 0.0, Leik = 0.0;
+
+    // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
+    if constexpr (ADV != 0) {
+        double u[3];
+        eval_coeff<NDIM, NDIM>(a.adv, a, gi, idx, u);
+        auto one = [&](auto Dc) {
+            constexpr int D = decltype(Dc)::value;
+            const double v = u[D];
+            double der;
+            if constexpr (ADV == 2) {
+                der = weno_dim<NDIM, D, G, W>(nv, a, v);
+            } else {
+#if LSM_STRICT
+                der = v > 0 ? (c - nv.template at<D>(-1)) / a.h[D] : (nv.template at<D>(1) - c) / a.h[D];
+#else
+                der = (v > 0 ? (c - nv.template at<D>(-1)) : (nv.template at<D>(1) - c)) * a.inv_h[D];
+#endif
+            }
+            return v * der;
+        };
+        Ladv = one(std::integral_constant<int, 0>{});
+        if constexpr (NDIM > 1) Ladv = Ladv + one(std::integral_constant<int, 1>{});
+        if constexpr (NDIM > 2) Ladv = Ladv + one(std::integral_constant<int, 2>{});
+    }
+
+    // ---- second-order ENO pairs shared by NormalMotion and Eikonal — src/levelsetterms.jl:161-163,255-257
+    double A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
+    if constexpr (NM || EIK) {
+        auto pr = [&](auto Dc) {
+            constexpr int D = decltype(Dc)::value;
+            eno2_pair(nv.template at<D>(-2), nv.template at<D>(-1), c, nv.template at<D>(1), nv.template at<D>(2), a.h[D],
+                      a.h2[D], a.inv_h[D], A[D], B[D]);
+        };
+        pr(std::integral_constant<int, 0>{});
+        if constexpr (NDIM > 1) pr(std::integral_constant<int, 1>{});
+        if constexpr (NDIM > 2) pr(std::integral_constant<int, 2>{});
+    }
+
+    // ---- NormalMotionTerm — src/levelsetterms.jl:156-170
+    if constexpr (NM) {
+        double vv[3];
+        eval_coeff<NDIM, 1>(a.nm, a, gi, idx, vv);
+        const double v = vv[0];
+#if LSM_STRICT
+        double gp = 0.0, gm = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            double x = positive(A[d]) * positive(A[d]) + negative(B[d]) * negative(B[d]);
+            double y = negative(A[d]) * negative(A[d]) + positive(B[d]) * positive(B[d]);
+            if (d == 0) { gp = x; gm = y; } else { gp = gp + x; gm = gm + y; }
+        }
+        Lnm = positive(v) * lsm_sqrt(gp) + negative(v) * lsm_sqrt(gm);
+#else
+        const bool vpos = v > 0;
+        double g2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            double x, y;
+            godunov_sel(vpos, A[d], B[d], x, y);
+            g2 += x + y;
+        }
+        Lnm = v * lsm_sqrt(g2);
+#endif
+    }
+
+    // ---- CurvatureTerm: b κ |∇ϕ| — src/levelsetterms.jl:111-121, src/levelsetops.jl:197-244
+    if constexpr (CURV) {
+        double bb[3];
+        eval_coeff<NDIM, 1>(a.curv, a, gi, idx, bb);
+        double gr[3] = {0, 0, 0}, Hd[3] = {0, 0, 0};
+        double H01 = 0, H02 = 0, H12 = 0;
+        auto first = [&](auto Dc) {
+            constexpr int D = decltype(Dc)::value;
+            const double p1 = nv.template at<D>(1), m1 = nv.template at<D>(-1);
+#if LSM_STRICT
+            gr[D] = (p1 - m1) / (2 * a.h[D]);
+            Hd[D] = (p1 - 2 * c + m1) / a.h2[D];
+#else
+            gr[D] = (p1 - m1) * (0.5 * a.inv_h[D]);
+            Hd[D] = (p1 - 2 * c + m1) * a.inv_h2[D];
+#endif
+        };
+        first(std::integral_constant<int, 0>{});
+        if constexpr (NDIM > 1) first(std::integral_constant<int, 1>{});
+        if constexpr (NDIM > 2) first(std::integral_constant<int, 2>{});
+        // D2(ϕ,I,(a,b)) = (D⁰_b(I+e_a) - D⁰_b(I-e_a)) / (2h_a), upper triangle a<b — src/derivatives.jl:144-149
+        auto mixed = [&](auto Ac, auto Bc) {
+            constexpr int A_ = decltype(Ac)::value, B_ = decltype(Bc)::value;
+            const double pp = nv.template corner<A_, B_>(1, 1), pm = nv.template corner<A_, B_>(1, -1);
+            const double mp = nv.template corner<A_, B_>(-1, 1), mm = nv.template corner<A_, B_>(-1, -1);
+#if LSM_STRICT
+            return ((pp - pm) / (2 * a.h[B_]) - (mp - mm) / (2 * a.h[B_])) / (2 * a.h[A_]);
+#else
+            return ((pp - pm) - (mp - mm)) * (0.25 * a.inv_h[A_] * a.inv_h[B_]);
+#endif
+        };
+        if constexpr (NDIM > 1) H01 = mixed(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        if constexpr (NDIM > 2) {
+            H02 = mixed(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            H12 = mixed(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        }
+        double q = gr[0] * gr[0];
+        if constexpr (NDIM > 1) q = q + gr[1] * gr[1];
+        if constexpr (NDIM > 2) q = q + gr[2] * gr[2];
+        double lap = Hd[0];
+        if constexpr (NDIM > 1) lap = lap + Hd[1];
+        if constexpr (NDIM > 2) lap = lap + Hd[2];
+        // gᵀHg in the order of LinearAlgebra.dot(x, ::Symmetric, y) (upper triangle by columns)
+        double r = 0.0;
+        r += gr[0] * (Hd[0] * gr[0]);
+        if constexpr (NDIM > 1) {
+            r += gr[1] * (Hd[1] * gr[1]);
+            r += gr[0] * (H01 * gr[1]) + gr[1] * (H01 * gr[0]);
+        }
+        if constexpr (NDIM > 2) {
+            r += gr[2] * (Hd[2] * gr[2]);
+            r += gr[0] * (H02 * gr[2]) + gr[2] * (H02 * gr[0]);
+            r += gr[1] * (H12 * gr[2]) + gr[2] * (H12 * gr[1]);
+        }
+#if LSM_STRICT
+        const double kappa = q < 2.220446049250313e-16 ? 0.0 : (lap * q - r) / pow(q, 1.5);
+        Lcurv = bb[0] * kappa * lsm_sqrt(q);
+#else
+        // κ|∇ϕ| = (Δϕ q - gᵀHg)/q : the q^(3/2) and the sqrt cancel
+        Lcurv = q < 2.220446049250313e-16 ? 0.0 : bb[0] * ((lap * q - r) * fast_rcp(q));
+#endif
+    }
+
+    // ---- EikonalReinitializationTerm: S (|∇ϕ| - 1) — src/levelsetterms.jl:234-265
+    if constexpr (EIK != 0) {
+        const double s = EIK == 1 ? a.s0[idx] : c;
+        const bool vpos = s > 0;
+        double mA = 0.0, mB = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            double x, y;
+            godunov_sel(vpos, A[d], B[d], x, y);
+            if (d == 0) { mA = x; mB = y; } else { mA = mA + x; mB = mB + y; }
+        }
+        const double nrm = lsm_sqrt(mA + mB);
+        double S;
+        if constexpr (EIK == 1) {
+            S = s;
+        } else {
+            const double den = lsm_sqrt(c * c + (nrm * nrm) * (a.dxmin * a.dxmin));
+            S = den == 0.0 ? 0.0 : lsm_div(c, den);
+        }
+        Leik = S * (nrm - 1);
+    }
+
+    // ---- stage combination — src/timestepping.jl:129-136,147-163,172-200
+    if (!active) return;
+    double base;
+    if (a.base_mode == LSM_BASE_PSI) base = c;
+    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * a.phin[idx] + 0.25 * c;
+    else if (a.base_mode == LSM_BASE_RK3_S3)
+#if LSM_STRICT
+        base = (a.phin[idx] + 2 * c) / 3;
+#else
+        base = (a.phin[idx] + 2 * c) * (1.0 / 3);
+#endif
+    else base = a.phin[idx];
+    double b2 = 0.0;
+    if (a.out2) b2 = a.out2_accum ? a.out2[idx] : c;
+    for (int k = 0; k < a.nterms; ++k) {
+        const int o = a.order[k];
+        double L = Ladv;
+        if (NM && o == SLOT_NM) L = Lnm;
+        if (CURV && o == SLOT_CURV) L = Lcurv;
+        if (EIK && o == SLOT_EIK) L = Leik;
+        base -= a.cdt * L;
+        b2 -= a.cdt2 * L;
+    }
+    a.out[idx] = base;
+    if (a.out2) a.out2[idx] = b2;
+}
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC>
+__global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
+    constexpr int G = halo_of(ADV, NM, CURV, EIK);
+    constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
+    constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
+    constexpr int NSLOT = MARCH ? 2 * LEAD + 2 : 1;
+    constexpr int W = TX + 2 * G;
+    constexpr int H = HAS_Y ? TY + 2 * G : 1;
+    constexpr int HW = H * W;
+    constexpr int NT = TX * TY;
+    constexpr int NHX = 2 * G * TY;
+    constexpr int WY = CURV ? W : TX;
+    constexpr int NHY = HAS_Y ? 2 * G * WY : 0;
+    constexpr int NH = NHX + NHY;
+    constexpr int HPT = (NH + NT - 1) / NT;
+    static_assert(!HAS_Y || TY > 1 || true, "");
+    __shared__ double tile[NSLOT * HW];
+
+    const int tid = threadIdx.x;
+    const int tx = tid % TX, ty = tid / TX;
+    const int bx0 = blockIdx.x * TX, by0 = HAS_Y ? blockIdx.y * TY : 0;
+    const int gx = bx0 + tx, gy = by0 + ty;
+    const int nx = a.n[0], ny = HAS_Y ? a.n[1] : 1;
+    const int nm = MARCH ? a.n[NDIM - 1] : 1;
+    const long long sy = HAS_Y ? a.s1 : 0;
+    const long long sm = MARCH ? (NDIM == 3 ? a.s2 : a.s1) : 0;
+    const bool active = gx < nx && gy < ny;
+    const int cx = gx < nx ? gx : nx - 1, cy = gy < ny ? gy : ny - 1;
+    const long long col = a.origin + cx + cy * sy;
+    const int m0 = MARCH ? (NDIM == 3 ? blockIdx.z : blockIdx.y) * MC : 0;
+    const int m1 = MARCH ? (m0 + MC < nm ? m0 + MC : nm) : 1;
+    auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
+
+    // halo elements owned by this thread: LDS offset within a plane, global offset within a plane
+    int hl[HPT > 0 ? HPT : 1];
+    long long hg[HPT > 0 ? HPT : 1];
+    bool hv[HPT > 0 ? HPT : 1];
+#pragma unroll
+    for (int h = 0; h < HPT; ++h) {
+        const int e = tid + h * NT;
+        hv[h] = e < NH;
+        int lx, ly;
+        if (e < NHX) {
+            const int r = e % (2 * G);
+            ly = e / (2 * G) + (HAS_Y ? G : 0);
+            lx = r < G ? r : r + TX;
+        } else {
+            const int e2 = e - NHX;
+            const int row = e2 / WY;
+            lx = (CURV ? 0 : G) + e2 % WY;
+            ly = row < G ? row : row + TY;
+        }
+        int X = bx0 - G + lx;
+        X = X > nx + G - 1 ? nx + G - 1 : X;
+        int Y = 0;
+        if (HAS_Y) {
+            Y = by0 - G + ly;
+            Y = Y > ny + G - 1 ? ny + G - 1 : Y;
+        }
+        hl[h] = ly * W + lx;
+        hg[h] = a.origin + X + Y * sy;
+    }
+    const int lpos = (ty + (HAS_Y ? G : 0)) * W + tx + G;
+    const double* __restrict__ psi = a.psi;
+
+    if constexpr (!MARCH) {
+        const double c = psi[col];
+        tile[lpos] = c;
+#pragma unroll
+        for (int h = 0; h < HPT; ++h)
+            if (hv[h]) tile[hl[h]] = psi[hg[h]];
+        __syncthreads();
+        NodeView<NDIM, G, W> nv{tile + lpos, nullptr, nullptr, nullptr, c};
+        const int gi[3] = {cx + a.goff[0], 0, 0};
+        node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, gi, col, active);
+    } else {
+        double zl[2 * G + 1];
+#pragma unroll
+        for (int j = 0; j <= 2 * G; ++j) zl[j] = psi[col + clampM(m0 - G + j) * sm];
+#pragma unroll
+        for (int pl = -LEAD; pl <= LEAD; ++pl) {
+            const int slot = pl + LEAD;
+            tile[slot * HW + lpos] = zl[G + pl];
+            const long long po = clampM(m0 + pl) * sm;
+#pragma unroll
+            for (int h = 0; h < HPT; ++h)
+                if (hv[h]) tile[slot * HW + hl[h]] = psi[hg[h] + po];
+        }
+        for (int m = m0; m < m1; ++m) {
+            // issue next plane's global loads early
+            const double nxt = psi[col + clampM(m + 1 + G) * sm];
+            double hn[HPT > 0 ? HPT : 1];
+            const long long pn = clampM(m + 1 + LEAD) * sm;
+#pragma unroll
+            for (int h = 0; h < HPT; ++h)
+                if (hv[h]) hn[h] = psi[hg[h] + pn];
+            __syncthreads();
+            const int rel = m - m0;
+            const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
+            const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
+            const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
+            NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
+            int gi[3];
+            gi[0] = cx + a.goff[0];
+            if (NDIM == 3) { gi[1] = cy + a.goff[1]; gi[2] = m + a.goff[2]; }
+            else { gi[1] = m + a.goff[1]; gi[2] = 0; }
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, gi, col + (long long)m * sm, active);
+            // shift the register line, write the next plane to its ring slot
+#pragma unroll
+            for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
+            zl[2 * G] = nxt;
+            const int wslot = (rel + 1 + 2 * LEAD) % NSLOT;
+            tile[wslot * HW + lpos] = zl[G + LEAD];
+#pragma unroll
+            for (int h = 0; h < HPT; ++h)
+                if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];
+        }
+    }
+}
+
+template <int NDIM>
+struct TileCfg;
+template <>
+struct TileCfg<1> { static constexpr int TX = 256, TY = 1, MC = 1; };
+template <>
+struct TileCfg<2> { static constexpr int TX = 256, TY = 1, MC = 32; };
+template <>
+struct TileCfg<3> { static constexpr int TX = 32, TY = 8, MC = 32; };
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK>
+void launch_one(const StageArgs& a, hipStream_t s) {
+    using T = TileCfg<NDIM>;
+    dim3 block(T::TX * T::TY);
+    dim3 grid((a.n[0] + T::TX - 1) / T::TX, 1, 1);
+    if (NDIM == 2) grid.y = (a.n[1] + T::MC - 1) / T::MC;
+    if (NDIM == 3) {
+        grid.y = (a.n[1] + T::TY - 1) / T::TY;
+        grid.z = (a.n[2] + T::MC - 1) / T::MC;
+    }
+    hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, a);
+}
+
+// the instantiated fused combinations (keep in sync with combo_available in lsm_api.hip)
+#define LSM_FOR_EACH_COMBO(X) \
+    X(1, 0, 0, 0)             \
+    X(2, 0, 0, 0)             \
+    X(0, 1, 0, 0)             \
+    X(0, 0, 1, 0)             \
+    X(0, 0, 0, 1)             \
+    X(0, 0, 0, 2)             \
+    X(2, 0, 0, 2)             \
+    X(2, 0, 0, 1)             \
+    X(0, 1, 1, 0)             \
+    X(2, 0, 1, 0)             \
+    X(2, 1, 0, 0)
+
+template <int NDIM>
+int launch_ndim(const Combo& c, const StageArgs& a, hipStream_t s) {
+#define LSM_X(ADV, NM, CURV, EIK)                                         \
+    if (c.adv == ADV && c.nm == NM && c.curv == CURV && c.eik == EIK) { \
+        launch_one<NDIM, ADV, NM, CURV, EIK>(a, s);                       \
+        return 0;                                                         \
+    }
+    LSM_FOR_EACH_COMBO(LSM_X)
+#undef LSM_X
+    return -1;
+}
+
+}  // namespace LSM_NS
+}  // namespace lsm

@@ -1,0 +1,170 @@
+// stage_math.h — per-node arithmetic of the level-set terms for gfx950 (fp64 VALU).
+//
+// Included twice, from stage_fast.hip (LSM_STRICT=0, built with -ffp-contract=fast) and from
+// stage_strict.hip (LSM_STRICT=1, built with -ffp-contract=off):
+//
+//  STRICT  the reference's operation order verbatim (src/derivatives.jl:28-175,
+//          src/levelsetterms.jl:73-265, src/levelsetops.jl:197-244): true IEEE divisions, no
+//          contraction.  Used to prove indexing / ghost / stage logic bit for bit against the oracle.
+//  FAST    same mathematics reorganised for the fp64 vector pipe, which — not HBM — bounds this
+//          kernel (≈340 fp64 VALU slots per node-stage against 24 bytes):
+//            * differences stay undivided (Δ, not Δ/h); WENO5 is homogeneous of degree one, so the
+//              1/h is applied once per dimension and the ε floor becomes 1e-99·h²;
+//            * the three WENO weights use ONE reciprocal: Σ_k c_k Π_{j≠k}(S_j+ε)² d_k / Σ_k c_k Π_{j≠k}(S_j+ε)²
+//              instead of 6 divisions (src/derivatives.jl:73-78);
+//            * divisions/sqrt are v_rcp_f64 / v_rsq_f64 seeds + Newton/Goldschmidt FMA steps (≤2 ulp);
+//            * minmod by sign bits, upwind selection by operand flips.
+//          Valid for neighbour differences in ~[1e-35, 1e+35] (beyond that the weight products
+//          leave the fp64 range; exactly flat data is handled); within 1e-13·max|ϕ| per stage.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lsm {
+namespace LSM_NS {
+
+#define LSM_DEV __device__ __forceinline__
+
+LSM_DEV double positive(double x) { return x > 0.0 ? x : 0.0; }   // src/levelsetterms.jl:180
+LSM_DEV double negative(double x) { return x < 0.0 ? x : 0.0; }   // src/levelsetterms.jl:181
+
+#if LSM_STRICT
+
+LSM_DEV double jl_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (b > a ? b : a); }
+
+// _weno5 — src/derivatives.jl:61-81, verbatim
+LSM_DEV double weno5_core(double v1, double v2, double v3, double v4, double v5) {
+    double dphi1 = (1.0 / 3) * v1 - (7.0 / 6) * v2 + (11.0 / 6) * v3;
+    double dphi2 = -(1.0 / 6) * v2 + (5.0 / 6) * v3 + (1.0 / 3) * v4;
+    double dphi3 = (1.0 / 3) * v3 + (5.0 / 6) * v4 - (1.0 / 6) * v5;
+    double a1 = v1 - 2 * v2 + v3, b1 = v1 - 4 * v2 + 3 * v3;
+    double a2 = v2 - 2 * v3 + v4, b2 = v2 - v4;
+    double a3 = v3 - 2 * v4 + v5, b3 = 3 * v3 - 4 * v4 + v5;
+    double S1 = (13.0 / 12) * (a1 * a1) + (1.0 / 4) * (b1 * b1);
+    double S2 = (13.0 / 12) * (a2 * a2) + (1.0 / 4) * (b2 * b2);
+    double S3 = (13.0 / 12) * (a3 * a3) + (1.0 / 4) * (b3 * b3);
+    double m = jl_max(jl_max(jl_max(jl_max(v1 * v1, v2 * v2), v3 * v3), v4 * v4), v5 * v5);
+    double eps = 1.0e-6 * m + 1.0e-99;
+    double t1 = S1 + eps, t2 = S2 + eps, t3 = S3 + eps;
+    double al1 = 0.1 / (t1 * t1);
+    double al2 = 0.6 / (t2 * t2);
+    double al3 = 0.3 / (t3 * t3);
+    double w1 = al1 / (al1 + al2 + al3);
+    double w2 = al2 / (al1 + al2 + al3);
+    double w3 = al3 / (al1 + al2 + al3);
+    return w1 * dphi1 + w2 * dphi2 + w3 * dphi3;
+}
+
+// limiter (minmod) — src/levelsetterms.jl:184-187
+LSM_DEV double limiter(double x, double y) {
+    if (!(x * y > 0.0)) return 0.0;
+    return __builtin_fabs(x) <= __builtin_fabs(y) ? x : y;
+}
+
+// upwind-biased WENO5 derivative from the six values q0..q5 = ϕ[I + s·(-3..2)e] (s = +1 if u>0
+// else -1) and hs = s·h:  v_k = (q_k - q_{k-1})/hs reproduces D⁻ (s=+1) / D⁺ (s=-1) of
+// src/derivatives.jl:89-121 bit for bit, since (a-b)/(-h) == (b-a)/h in IEEE arithmetic.
+LSM_DEV double weno5_upwind(const double q[6], double hs, double /*inv_hs*/, double /*eps_floor*/) {
+    return weno5_core((q[1] - q[0]) / hs, (q[2] - q[1]) / hs, (q[3] - q[2]) / hs, (q[4] - q[3]) / hs,
+                      (q[5] - q[4]) / hs);
+}
+
+// second-order ENO one-sided derivatives (src/levelsetterms.jl:161-163,255-257)
+LSM_DEV void eno2_pair(double m2, double m1, double c, double p1, double p2, double h, double h2, double /*inv_h*/,
+                       double& A, double& B) {
+    double dm = (c - m1) / h;
+    double dp = (p1 - c) / h;
+    double d20 = (p1 - 2 * c + m1) / h2;
+    double d2mm = (m2 - 2 * m1 + c) / h2;
+    double d2pp = (c - 2 * p1 + p2) / h2;
+    A = dm + 0.5 * h * limiter(d2mm, d20);
+    B = dp - 0.5 * h * limiter(d2pp, d20);
+}
+LSM_DEV double lsm_sqrt(double x) { return __builtin_sqrt(x); }
+LSM_DEV double lsm_div(double a, double b) { return a / b; }
+
+#else  // ------------------------------------------------------------------ FAST
+
+LSM_DEV double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+LSM_DEV double lsm_div(double a, double b) { return a * fast_rcp(b); }
+
+// sqrt for x >= 0 (Goldschmidt on a v_rsq_f64 seed, final residual correction)
+LSM_DEV double lsm_sqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, hh = 0.5 * r;
+    double e = __builtin_fma(-hh, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    hh = __builtin_fma(hh, e, hh);
+    e = __builtin_fma(-hh, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    hh = __builtin_fma(hh, e, hh);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, hh, g);
+    return (x > 0.0 && x < __builtin_inf()) ? g : x;   // 0 -> 0, inf -> inf, NaN -> NaN
+}
+
+// Jiang–Shu WENO5 on UNDIVIDED one-sided differences e1..e5 (ordered from the upwind end inward),
+// returning h·(reference value).  eps_floor = 1e-99·h².
+LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, double e5, double eps_floor) {
+    // candidates pre-multiplied by the linear weights 0.1, 0.6, 0.3
+    double p1 = (0.1 / 3) * e1 - (0.7 / 6) * e2 + (1.1 / 6) * e3;
+    double p2 = -(0.6 / 6) * e2 + (3.0 / 6) * e3 + (0.6 / 3) * e4;
+    double p3 = (0.3 / 3) * e3 + (1.5 / 6) * e4 - (0.3 / 6) * e5;
+    double a1 = e1 - 2 * e2 + e3, b1 = e1 - 4 * e2 + 3 * e3;
+    double a2 = e2 - 2 * e3 + e4, b2 = e2 - e4;
+    double a3 = e3 - 2 * e4 + e5, b3 = 3 * e3 - 4 * e4 + e5;
+    double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(__builtin_fabs(e1), __builtin_fabs(e2)),
+                                             __builtin_fmax(__builtin_fabs(e3), __builtin_fabs(e4))),
+                              __builtin_fabs(e5));
+    double eps = __builtin_fma(1.0e-6 * m, m, eps_floor);
+    double r1 = __builtin_fma((13.0 / 12) * a1, a1, __builtin_fma((0.25 * b1), b1, eps));
+    double r2 = __builtin_fma((13.0 / 12) * a2, a2, __builtin_fma((0.25 * b2), b2, eps));
+    double r3 = __builtin_fma((13.0 / 12) * a3, a3, __builtin_fma((0.25 * b3), b3, eps));
+    double s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
+    double w1 = s2 * s3, w2 = s1 * s3, w3 = s1 * s2;   // ∝ α_k/c_k
+    double num = w1 * p1 + w2 * p2 + w3 * p3;
+    double den = 0.1 * w1 + 0.6 * w2 + 0.3 * w3;
+    den = __builtin_fmax(den, 1.0e-300);              // exactly flat data: 0/tiny = 0, as the reference
+    return num * fast_rcp(den);
+}
+
+LSM_DEV double weno5_upwind(const double q[6], double /*hs*/, double inv_hs, double eps_floor) {
+    return weno5_undivided(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], eps_floor) * inv_hs;
+}
+
+// minmod on undivided second differences by sign bits
+LSM_DEV double minmod_fast(double x, double y) {
+    double m = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
+    unsigned hx = (unsigned)__double2hiint(x), hy = (unsigned)__double2hiint(y);
+    bool same = ((hx ^ hy) >> 31) == 0;
+    return same ? __builtin_copysign(m, x) : 0.0;
+}
+
+LSM_DEV void eno2_pair(double m2, double m1, double c, double p1, double p2, double /*h*/, double /*h2*/, double inv_h,
+                       double& A, double& B) {
+    double dm = c - m1, dp = p1 - c;
+    double s0 = dp - dm;
+    double smm = dm - (m1 - m2);
+    double spp = (p2 - p1) - dp;
+    A = (dm + 0.5 * minmod_fast(smm, s0)) * inv_h;
+    B = (dp - 0.5 * minmod_fast(spp, s0)) * inv_h;
+}
+#endif
+
+// Godunov selection shared by Eikonal (_compute_∇_norm, src/levelsetterms.jl:252-265):
+// v>0 ? (positive(A)², negative(B)²) : (negative(A)², positive(B)²)
+LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) {
+    double a = vpos ? positive(A) : negative(A);
+    double b = vpos ? negative(B) : positive(B);
+    a2 = a * a;
+    b2 = b * b;
+}
+
+}  // namespace LSM_NS
+}  // namespace lsm

@@ -281,7 +281,7 @@ static double curvature(const F* f, const int64_t I[3]) {
     double nrmsq = gr[0] * gr[0];
     for (int d = 1; d < N; ++d) nrmsq = nrmsq + gr[d] * gr[d];
     if (nrmsq < 2.220446049250313e-16) return 0.0;
-    double H[3][3];
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int a = 0; a < N; ++a)
         for (int b = a; b < N; ++b) H[a][b] = (a == b) ? D20(f, I, a) : D2mixed(f, I, a, b); /* upper triangle */
     double lap = H[0][0];

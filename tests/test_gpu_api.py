@@ -1,0 +1,146 @@
+"""The reference's own hot-path tests, run through the drop-in host API (lsm_amd) on the GPU.
+Same grids, boundary conditions, integrators and thresholds as the reference test files cited."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsm():
+    import lsm_amd
+    return lsm_amd
+
+
+def _advection_error_1d(lsm, integrator, N, u=1.0, tf=0.5, scheme=None):
+    """test/test-timestepping.jl:8-22"""
+    grid = lsm.CartesianGrid((-1.0,), (1.0,), (N,))
+    phi = lsm.MeshField(lambda x: np.sin(np.pi * x[0]), grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((u,), scheme or lsm.WENO5()),), ic=phi, bc=lsm.PeriodicBC(),
+                              integrator=integrator)
+    lsm.integrate_(eq, tf)
+    out = lsm.current_state(eq).values()
+    x = grid.coords()[0]
+    return np.abs(out - np.sin(np.pi * (x - u * tf))).max()
+
+
+def test_integrator_accuracy_1d(lsm):
+    """test/test-timestepping.jl:24-34"""
+    assert _advection_error_1d(lsm, lsm.ForwardEuler(), 200) < 0.05
+    assert _advection_error_1d(lsm, lsm.RK2(), 200) < 1.0e-3
+    assert _advection_error_1d(lsm, lsm.RK3(), 200) < 1.0e-5
+
+
+def test_weno5_spatial_order(lsm):
+    """test/test-levelsetequation.jl:26-45"""
+    Ns = [20, 40, 80]
+    e = [_advection_error_1d(lsm, lsm.RK3(cfl=1.0e-2), N) for N in Ns]
+    orders = [math.log(e[i] / e[i + 1]) / math.log(Ns[i + 1] / Ns[i]) for i in range(2)]
+    assert all(o >= 4.5 for o in orders), orders
+
+
+def test_dumbbell_rotation_792_steps(lsm):
+    """docs/src/time-integrators.md:92-94: one revolution at cfl 0.5 costs exactly 792 steps and
+    integrate! lands exactly on tf."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (64, 64))
+    disk = lambda c: lsm.MeshField(lambda x: np.hypot(x[0] - c[0], x[1] - c[1]) - 0.25, grid).vals
+    bar = lsm.MeshField(lambda x: np.maximum(np.abs(x[0]) - 0.5, np.abs(x[1]) - 0.1), grid).vals
+    phi0 = lsm.MeshField(np.minimum(np.minimum(disk((-0.5, 0.0)), disk((0.5, 0.0))), bar), grid)
+    eq = lsm.LevelSetEquation(terms=lsm.AdvectionTerm(lsm.RigidRotation()), ic=phi0, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    steps = []
+    lsm.integrate_(eq, 2 * math.pi, posthook=lambda e: steps.append(e.current_time()))
+    assert len(steps) == 792
+    assert eq.current_time() == 2 * math.pi
+    out = eq.current_state().values()
+    assert np.abs(out - phi0.vals)[np.abs(phi0.vals) < 0.1].max() < 0.05   # the shape came back
+
+
+def test_eikonal_term_converges_to_sdf(lsm):
+    """test/test-levelsetterms.jl:33-51"""
+    grid = lsm.CartesianGrid((-1.0,), (1.0,), (101,))
+    phi = lsm.MeshField(lambda x: 2 * (x[0] - 0.3), grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.EikonalReinitializationTerm(phi),), ic=phi, bc=lsm.LinearExtrapolationBC())
+    lsm.integrate_(eq, 2.0)
+    out = eq.current_state().values()
+    exact = grid.coords()[0] - 0.3
+    assert np.where(np.abs(out) > 0.5, 0.0, np.abs(out - exact)).max() < 0.05
+
+
+def test_nan_robustness(lsm):
+    """test/test-levelsetterms.jl:53-77"""
+    grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (31, 31))
+    phi = lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - 0.7, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.CurvatureTerm(-0.1),), ic=phi, bc=lsm.NeumannBC(), integrator=lsm.RK2())
+    lsm.integrate_(eq, 0.1)
+    assert not np.isnan(eq.current_state().values()).any()
+    g1 = lsm.CartesianGrid((-1.0,), (1.0,), (31,))
+    flat = lsm.MeshField(lambda x: 0.0 * x[0], g1)
+    eq2 = lsm.LevelSetEquation(terms=(lsm.EikonalReinitializationTerm(),), ic=flat, bc=lsm.NeumannBC(), integrator=lsm.RK2())
+    lsm.integrate_(eq2, 0.1)
+    assert not np.isnan(eq2.current_state().values()).any()
+
+
+def test_normal_motion_and_curvature_orders(lsm):
+    """test/test-levelsetequation.jl:67-119"""
+    def run(term, exact, r0, tf):
+        Ns, errs = [30, 60, 120], []
+        for N in Ns:
+            grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (N, N))
+            phi = lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - r0, grid)
+            eq = lsm.LevelSetEquation(terms=(term,), ic=phi, bc=lsm.ExtrapolationBC(2), integrator=lsm.RK3())
+            lsm.integrate_(eq, tf)
+            out = eq.current_state().values()
+            X, Y = np.meshgrid(*grid.coords(), indexing="ij")
+            r = np.hypot(X, Y)
+            errs.append(np.abs(out - exact(r))[(r >= 0.5) & (r <= 1.5)].max())
+        return [math.log(errs[i] / errs[i + 1]) / math.log(2) for i in range(2)]
+    assert all(o >= 1.5 for o in run(lsm.NormalMotionTerm(0.5), lambda r: r - 0.5 - 0.5 * 0.2, 0.5, 0.2))
+    assert all(o >= 1.5 for o in run(lsm.CurvatureTerm(-0.1), lambda r: np.sqrt(r ** 2 + 0.2 * 0.2) - 0.7, 0.7, 0.2))
+
+
+def test_cfl_error_and_backward_time(lsm):
+    """src/levelsetterms.jl:26, src/levelsetequation.jl:196"""
+    grid = lsm.CartesianGrid((-1.0,), (1.0,), (32,))
+    phi = lsm.MeshField(lambda x: x[0], grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((float("nan"),)),), ic=phi, bc=lsm.NeumannBC())
+    with pytest.raises(ValueError, match="invalid time-step based on CFL condition"):
+        lsm.integrate_(eq, 1.0)
+    eq2 = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0,)),), ic=phi, bc=lsm.NeumannBC(), t=1.0)
+    with pytest.raises(ValueError, match="cannot be solved back in time"):
+        lsm.integrate_(eq2, 0.5)
+    with pytest.raises(ValueError, match="no boundary conditions"):
+        lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0,)),), ic=phi)
+
+
+def test_callable_velocity_and_update_func_hooks(lsm, orc):
+    """A python closure velocity u(x,t) (re-sampled per stage: slow path) and an update_func hook
+    (src/levelsetterms.jl:65-69) give the same result as the catalogued rotation."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (48, 40))
+    ic = lsm.MeshField(lambda x: np.hypot(x[0] - 0.3, x[1]) - 0.4, grid)
+    mk = lambda vel, **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(vel, lsm.WENO5(), **kw),), ic=ic, bc=lsm.NeumannBC(),
+                                                integrator=lsm.RK3(), mode="strict")
+    a = mk(lsm.RigidRotation())
+    calls = []
+    b = mk(lambda x, t: (-x[1], x[0]), update_func=lambda coeff, field, t: calls.append(t))
+    lsm.integrate_(a, 0.2)
+    lsm.integrate_(b, 0.2)
+    assert np.array_equal(a.current_state().values(), b.current_state().values())
+    assert len(calls) > 0 and len(calls) % 4 == 0   # once before the CFL + once per RK3 stage
+
+
+def test_state_is_a_copy_and_hooks_can_mutate(lsm):
+    """src/levelsetequation.jl:67-76 (ic is copied) and :180-185 (hooks may mutate the state)."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (32, 32))
+    ic = lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - 0.5, grid)
+    keep = ic.vals.copy()
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(1.0),), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.ForwardEuler())
+    times = [0.0]
+    lsm.integrate_(eq, 0.05, prehook=lambda e: e.current_state().copy_(ic), posthook=lambda e: times.append(e.current_time()))
+    assert np.array_equal(ic.vals, keep)
+    last = times[-1] - times[-2]
+    one = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(1.0),), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.ForwardEuler())
+    lsm.integrate_(one, last)
+    # with the state reset before every step, the final state is ONE step of size `last` from ic
+    assert np.allclose(eq.current_state().values(), one.current_state().values(), atol=1e-12)
