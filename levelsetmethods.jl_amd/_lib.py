@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhiplsm.so")
+LIB_PATH = os.environ.get("LSM_AMD_LIB") or os.path.join(_HERE, "libhiplsm.so")   # env override: kernel-variant experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 GHOST = 3

@@ -403,7 +403,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
             launch_cfl(N, a, nb, h->stream);
-            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, h->stream);
+            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, h->stream);
             LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             LSM_HIP(h, hipStreamSynchronize(h->stream));
             dt = h->h_result[0];

@@ -110,85 +110,88 @@ __device__ __forceinline__ void cfl_coeff(const CoeffArgs& c, const CflArgs& a, 
     }
 }
 
-// per-node CFL of one term, grid-stride; one partial per block (src/levelsetterms.jl:90-96,172-178)
+// Per-node CFL of one term (src/levelsetterms.jl:90-96,123-127,172-178).  The node formulas are
+//   advection 1/Σ_d(|u_d|/h_d),  normal motion 1/Σ_d(|v|/h_d),  curvature Δx²/(2|b|),
+// i.e. a correctly-rounded, monotonically DEcreasing function f of a per-node quantity s
+// (s = Σ|u_d|/h_d, resp. |b|).  Because IEEE division is monotone, min_I f(s_I) == f(max_I s_I)
+// bit for bit, so the kernel reduces max s (plus an any-NaN flag: Julia's min propagates NaN) and
+// the final kernel applies f once.  One workgroup walks whole x-rows: the row's y/z table factors
+// and coordinates are wave-uniform.
 __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
-    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
-    double best = __builtin_inf();
+    const int nrows = a.n[1] * a.n[2];
+    double best = 0.0;   // s >= 0
     int sawnan = 0;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        int I[3];
-        I[0] = (int)(t % a.n[0]);
-        I[1] = (int)((t / a.n[0]) % a.n[1]);
-        I[2] = (int)(t / ((long long)a.n[0] * a.n[1]));
-        const int gi[3] = {I[0] + a.goff[0], I[1] + a.goff[1], I[2] + a.goff[2]};
-        const long long center = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
-        double u[3] = {0, 0, 0};
-        double cfl;
-        if (a.term_kind == LSM_TERM_ADVECTION) {
-            if (ndim == 1) cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
-            else if (ndim == 2) cfl_coeff<2>(a.coeff, a, ndim, gi, center, u);
-            else cfl_coeff<3>(a.coeff, a, ndim, gi, center, u);
-            double s = __builtin_fabs(u[0]) / a.h[0];
-            if (ndim > 1) s = s + __builtin_fabs(u[1]) / a.h[1];
-            if (ndim > 2) s = s + __builtin_fabs(u[2]) / a.h[2];
-            cfl = 1 / s;
-        } else if (a.term_kind == LSM_TERM_NORMAL_MOTION) {
-            cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
-            double s = __builtin_fabs(u[0]) / a.h[0];
-            if (ndim > 1) s = s + __builtin_fabs(u[0]) / a.h[1];
-            if (ndim > 2) s = s + __builtin_fabs(u[0]) / a.h[2];
-            cfl = 1 / s;
-        } else { /* curvature with a field/analytic b: Δx² / (2|b|) */
-            cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
-            double dx = a.h[0];
-            if (ndim > 1) dx = a.h[1] < dx ? a.h[1] : dx;
-            if (ndim > 2) dx = a.h[2] < dx ? a.h[2] : dx;
-            cfl = (dx * dx) / (2 * __builtin_fabs(u[0]));
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int i1 = row % a.n[1], i2 = row / a.n[1];
+        const long long rbase = a.origin + i1 * a.s1 + i2 * a.s2;
+        for (int i0 = threadIdx.x; i0 < a.n[0]; i0 += blockDim.x) {
+            const int gi[3] = {i0 + a.goff[0], i1 + a.goff[1], i2 + a.goff[2]};
+            const long long center = rbase + i0;
+            double u[3] = {0, 0, 0};
+            double sv;
+            if (a.term_kind == LSM_TERM_ADVECTION) {
+                if (ndim == 1) cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+                else if (ndim == 2) cfl_coeff<2>(a.coeff, a, ndim, gi, center, u);
+                else cfl_coeff<3>(a.coeff, a, ndim, gi, center, u);
+                sv = __builtin_fabs(u[0]) / a.h[0];
+                if (ndim > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
+                if (ndim > 2) sv = sv + __builtin_fabs(u[2]) / a.h[2];
+            } else if (a.term_kind == LSM_TERM_NORMAL_MOTION) {
+                cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+                sv = __builtin_fabs(u[0]) / a.h[0];
+                if (ndim > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
+                if (ndim > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
+            } else { /* curvature with a field/analytic b */
+                cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+                sv = __builtin_fabs(u[0]);
+            }
+            if (sv != sv) sawnan = 1;
+            else best = sv > best ? sv : best;
         }
-        if (cfl != cfl) sawnan = 1;
-        else best = cfl < best ? cfl : best;
     }
-    best = wave_min(best);
+    best = wave_max(best);
     sawnan = __any(sawnan) ? 1 : 0;
-    __shared__ double smin[4];
+    __shared__ double smax[4];
     __shared__ int snan[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { smin[wave] = best; snan[wave] = sawnan; }
+    if (lane == 0) { smax[wave] = best; snan[wave] = sawnan; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double m = smin[0];
+        double m = smax[0];
         int f = snan[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smin[w] < m ? smin[w] : m; f |= snan[w]; }
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smax[w] > m ? smax[w] : m; f |= snan[w]; }
         a.partial[blockIdx.x] = m;
         if (f) atomicOr(a.nanflag, 1);
     }
 }
 
-__global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, int nblocks, const int* nanflag, double* out) {
-    double best = __builtin_inf();
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) best = partial[i] < best ? partial[i] : best;
-    best = wave_min(best);
-    __shared__ double smin[4];
+__global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, int nblocks, const int* nanflag, double* out,
+                                                        int term_kind, double dxmin) {
+    double best = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) best = partial[i] > best ? partial[i] : best;
+    best = wave_max(best);
+    __shared__ double smax[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) smin[wave] = best;
+    if (lane == 0) smax[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double m = smin[0];
-        for (int w = 1; w < 4; ++w) m = smin[w] < m ? smin[w] : m;
-        out[0] = *nanflag ? __builtin_nan("") : m;
+        double m = smax[0];
+        for (int w = 1; w < 4; ++w) m = smax[w] > m ? smax[w] : m;
+        const double cfl = term_kind == LSM_TERM_CURVATURE ? (dxmin * dxmin) / (2 * m) : 1 / m;
+        out[0] = *nanflag ? __builtin_nan("") : cfl;
     }
 }
 
 int cfl_blocks(int /*ndim*/, const int n[3]) {
-    const long long total = (long long)n[0] * n[1] * n[2];
-    long long b = (total + 255) / 256;
-    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    const long long rows = (long long)n[1] * n[2];
+    return (int)(rows > 2048 ? 2048 : (rows < 1 ? 1 : rows));
 }
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s) {
     hipLaunchKernelGGL(cfl_kernel, dim3(nblocks), dim3(256), 0, s, a, ndim);
 }
-void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(cfl_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, nanflag, out);
+void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(cfl_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, nanflag, out, term_kind, dxmin);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,32 +30,67 @@ constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
     return g;
 }
 
-// _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h)
+// _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h),
+// split into the part that is constant along the march axis (hoisted out of the plane loop: table
+// look-ups of the leading dimensions, the in-plane rotation) and the per-plane remainder.
+// Operation order is exactly ((T1*T2)*T3)*g and lc + i*h, as in the oracle.
 template <int NDIM, int NCOMP>
-LSM_DEV void eval_coeff(const CoeffArgs& c, const StageArgs& a, const int gi[3], long long center, double out[3]) {
+LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1, double pre[3]) {
+    pre[0] = pre[1] = pre[2] = 0.0;
     if (c.kind == LSM_COEFF_CONST) {
 #pragma unroll
-        for (int k = 0; k < NCOMP; ++k) out[k] = c.v[k];
+        for (int k = 0; k < NCOMP; ++k) pre[k] = c.v[k];
     } else if (c.kind == LSM_COEFF_ROTATION) {
-        double x1 = a.lc[0] + (double)gi[0] * a.h[0];
-        double x2 = NDIM > 1 ? a.lc[1] + (double)gi[1] * a.h[1] : 0.0;
-        out[0] = -(c.v[0] * (x2 - c.v[2]));
-        if (NCOMP > 1) out[1] = c.v[0] * (x1 - c.v[1]);
-        if (NCOMP > 2) out[2] = 0.0;
+        const double x1 = a.lc[0] + (double)gi0 * a.h[0];
+        pre[1] = c.v[0] * (x1 - c.v[1]);
+        if (NDIM == 3) {
+            const double x2 = a.lc[1] + (double)gi1 * a.h[1];
+            pre[0] = -(c.v[0] * (x2 - c.v[2]));
+        }
     } else if (c.kind == LSM_COEFF_SEPARABLE) {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) {
             const double* T = c.sep[k];
-            double p = T[gi[0]];
-            if (NDIM > 1) p = p * T[a.gn[0] + gi[1]];
-            if (NDIM > 2) p = p * T[a.gn[0] + a.gn[1] + gi[2]];
+            double p = T[gi0];
+            if (NDIM == 3) p = p * T[a.gn[0] + gi1];
+            pre[k] = p;
+        }
+    }
+}
+template <int NDIM, int NCOMP>
+LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], int gim, long long plane_off, int ocol,
+                        double out[3]) {
+    if (c.kind == LSM_COEFF_CONST) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) out[k] = pre[k];
+    } else if (c.kind == LSM_COEFF_ROTATION) {
+        if (NDIM == 2) {
+            const double x2 = a.lc[1] + (double)gim * a.h[1];
+            out[0] = -(c.v[0] * (x2 - c.v[2]));
+        } else {
+            out[0] = pre[0];
+        }
+        if (NCOMP > 1) out[1] = pre[1];
+        if (NCOMP > 2) out[2] = 0.0;
+    } else if (c.kind == LSM_COEFF_SEPARABLE) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) {
+            double p = pre[k];
+            if (NDIM > 1) p = p * c.sep[k][(NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gim];
             out[k] = p * c.tfac;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NCOMP; ++k) out[k] = c.f[k][center];
+        for (int k = 0; k < NCOMP; ++k) out[k] = (c.f[k] + plane_off)[ocol];
     }
 }
+
+// where a node reads/writes its pointwise operands: uniform plane offset + per-thread in-plane offset
+struct NodeIO {
+    long long plane_off;   // origin + m*stride_march (wave-uniform)
+    int ocol;              // in-plane offset of this thread
+    int gim;               // global march index
+};
 
 // Everything one node needs: pointers into the LDS ring at the node's own position and the
 // register line along the march axis.
@@ -109,14 +144,15 @@ LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
 }
 
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class NV>
-LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long long idx, bool active) {
+LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, const double pre_adv[3], const double pre_nm[3],
+                         const double pre_curv[3], bool active) {
     const double c = nv.c;
     double Ladv = 0.0, Lnm = 0.0, Lcurv = 0.0, Leik = 0.0;
 
     // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
     if constexpr (ADV != 0) {
         double u[3];
-        eval_coeff<NDIM, NDIM>(a.adv, a, gi, idx, u);
+        coeff_eval<NDIM, NDIM>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocol, u);
         auto one = [&](auto Dc) {
             constexpr int D = decltype(Dc)::value;
             const double v = u[D];
@@ -153,7 +189,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
     // ---- NormalMotionTerm — src/levelsetterms.jl:156-170
     if constexpr (NM) {
         double vv[3];
-        eval_coeff<NDIM, 1>(a.nm, a, gi, idx, vv);
+        coeff_eval<NDIM, 1>(a.nm, a, pre_nm, io.gim, io.plane_off, io.ocol, vv);
         const double v = vv[0];
 #if LSM_STRICT
         double gp = 0.0, gm = 0.0;
@@ -180,7 +216,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
     // ---- CurvatureTerm: b κ |∇ϕ| — src/levelsetterms.jl:111-121, src/levelsetops.jl:197-244
     if constexpr (CURV) {
         double bb[3];
-        eval_coeff<NDIM, 1>(a.curv, a, gi, idx, bb);
+        coeff_eval<NDIM, 1>(a.curv, a, pre_curv, io.gim, io.plane_off, io.ocol, bb);
         double gr[3] = {0, 0, 0}, Hd[3] = {0, 0, 0};
         double H01 = 0, H02 = 0, H12 = 0;
         auto first = [&](auto Dc) {
@@ -242,7 +278,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
 
     // ---- EikonalReinitializationTerm: S (|∇ϕ| - 1) — src/levelsetterms.jl:234-265
     if constexpr (EIK != 0) {
-        const double s = EIK == 1 ? a.s0[idx] : c;
+        const double s = EIK == 1 ? (a.s0 + io.plane_off)[io.ocol] : c;
         const bool vpos = s > 0;
         double mA = 0.0, mB = 0.0;
 #pragma unroll
@@ -251,13 +287,19 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
             godunov_sel(vpos, A[d], B[d], x, y);
             if (d == 0) { mA = x; mB = y; } else { mA = mA + x; mB = mB + y; }
         }
-        const double nrm = lsm_sqrt(mA + mB);
+        const double n2 = mA + mB;
+        const double nrm = lsm_sqrt(n2);
         double S;
         if constexpr (EIK == 1) {
             S = s;
         } else {
+#if LSM_STRICT
             const double den = lsm_sqrt(c * c + (nrm * nrm) * (a.dxmin * a.dxmin));
             S = den == 0.0 ? 0.0 : lsm_div(c, den);
+#else
+            const double d2 = __builtin_fma(n2, a.dxmin * a.dxmin, c * c);
+            S = d2 > 0.0 ? c * fast_rsqrt(d2) : 0.0;
+#endif
         }
         Leik = S * (nrm - 1);
     }
@@ -266,16 +308,16 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
     if (!active) return;
     double base;
     if (a.base_mode == LSM_BASE_PSI) base = c;
-    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * a.phin[idx] + 0.25 * c;
+    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * (a.phin + io.plane_off)[io.ocol] + 0.25 * c;
     else if (a.base_mode == LSM_BASE_RK3_S3)
 #if LSM_STRICT
-        base = (a.phin[idx] + 2 * c) / 3;
+        base = ((a.phin + io.plane_off)[io.ocol] + 2 * c) / 3;
 #else
-        base = (a.phin[idx] + 2 * c) * (1.0 / 3);
+        base = ((a.phin + io.plane_off)[io.ocol] + 2 * c) * (1.0 / 3);
 #endif
-    else base = a.phin[idx];
+    else base = (a.phin + io.plane_off)[io.ocol];
     double b2 = 0.0;
-    if (a.out2) b2 = a.out2_accum ? a.out2[idx] : c;
+    if (a.out2) b2 = a.out2_accum ? (a.out2 + io.plane_off)[io.ocol] : c;
     for (int k = 0; k < a.nterms; ++k) {
         const int o = a.order[k];
         double L = Ladv;
@@ -285,8 +327,8 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const int gi[3], long
         base -= a.cdt * L;
         b2 -= a.cdt2 * L;
     }
-    a.out[idx] = base;
-    if (a.out2) a.out2[idx] = b2;
+    (a.out + io.plane_off)[io.ocol] = base;
+    if (a.out2) (a.out2 + io.plane_off)[io.ocol] = b2;
 }
 
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC>
@@ -316,15 +358,21 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
     const long long sy = HAS_Y ? a.s1 : 0;
     const long long sm = MARCH ? (NDIM == 3 ? a.s2 : a.s1) : 0;
     const bool active = gx < nx && gy < ny;
+    // inactive threads of a partial tile still feed the tile: they load their own (ghost) position
+    // while it lies inside the padded array; coefficient lookups use the interior-clamped index.
     const int cx = gx < nx ? gx : nx - 1, cy = gy < ny ? gy : ny - 1;
-    const long long col = a.origin + cx + cy * sy;
+    const int lxg = gx < nx + G ? gx : nx + G - 1;
+    const int lyg = HAS_Y ? (gy < ny + G ? gy : ny + G - 1) : 0;
+    const int ocol = lxg + lyg * (int)sy;               // in-plane offset of this thread's column
     const int m0 = MARCH ? (NDIM == 3 ? blockIdx.z : blockIdx.y) * MC : 0;
     const int m1 = MARCH ? (m0 + MC < nm ? m0 + MC : nm) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
+    // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
+    auto plane = [&](int p) { return a.psi + (a.origin + (long long)clampM(p) * sm); };
 
     // halo elements owned by this thread: LDS offset within a plane, global offset within a plane
     int hl[HPT > 0 ? HPT : 1];
-    long long hg[HPT > 0 ? HPT : 1];
+    int hg[HPT > 0 ? HPT : 1];
     bool hv[HPT > 0 ? HPT : 1];
 #pragma unroll
     for (int h = 0; h < HPT; ++h) {
@@ -349,53 +397,59 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
             Y = Y > ny + G - 1 ? ny + G - 1 : Y;
         }
         hl[h] = ly * W + lx;
-        hg[h] = a.origin + X + Y * sy;
+        hg[h] = X + Y * (int)sy;
     }
     const int lpos = (ty + (HAS_Y ? G : 0)) * W + tx + G;
-    const double* __restrict__ psi = a.psi;
+
+    // coefficient parts that are constant along the march axis
+    double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
+    {
+        const int gi0 = cx + a.goff[0], gi1 = HAS_Y ? cy + a.goff[1] : 0;
+        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM>(a.adv, a, gi0, gi1, pre_adv);
+        if constexpr (NM != 0) coeff_prep<NDIM, 1>(a.nm, a, gi0, gi1, pre_nm);
+        if constexpr (CURV != 0) coeff_prep<NDIM, 1>(a.curv, a, gi0, gi1, pre_curv);
+    }
 
     if constexpr (!MARCH) {
-        const double c = psi[col];
+        const double* P = plane(0);
+        const double c = P[ocol];
         tile[lpos] = c;
 #pragma unroll
         for (int h = 0; h < HPT; ++h)
-            if (hv[h]) tile[hl[h]] = psi[hg[h]];
+            if (hv[h]) tile[hl[h]] = P[hg[h]];
         __syncthreads();
         NodeView<NDIM, G, W> nv{tile + lpos, nullptr, nullptr, nullptr, c};
-        const int gi[3] = {cx + a.goff[0], 0, 0};
-        node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, gi, col, active);
+        const NodeIO io{a.origin, ocol, 0};
+        node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
     } else {
         double zl[2 * G + 1];
 #pragma unroll
-        for (int j = 0; j <= 2 * G; ++j) zl[j] = psi[col + clampM(m0 - G + j) * sm];
+        for (int j = 0; j <= 2 * G; ++j) zl[j] = plane(m0 - G + j)[ocol];
 #pragma unroll
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
             const int slot = pl + LEAD;
             tile[slot * HW + lpos] = zl[G + pl];
-            const long long po = clampM(m0 + pl) * sm;
+            const double* P = plane(m0 + pl);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
-                if (hv[h]) tile[slot * HW + hl[h]] = psi[hg[h] + po];
+                if (hv[h]) tile[slot * HW + hl[h]] = P[hg[h]];
         }
         for (int m = m0; m < m1; ++m) {
-            // issue next plane's global loads early
-            const double nxt = psi[col + clampM(m + 1 + G) * sm];
+            // issue the next plane's global loads early; they land in LDS after this plane's arithmetic
+            const double nxt = plane(m + 1 + G)[ocol];
             double hn[HPT > 0 ? HPT : 1];
-            const long long pn = clampM(m + 1 + LEAD) * sm;
+            const double* Pn = plane(m + 1 + LEAD);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
-                if (hv[h]) hn[h] = psi[hg[h] + pn];
+                if (hv[h]) hn[h] = Pn[hg[h]];
             __syncthreads();
             const int rel = m - m0;
             const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
             const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
             const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
             NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
-            int gi[3];
-            gi[0] = cx + a.goff[0];
-            if (NDIM == 3) { gi[1] = cy + a.goff[1]; gi[2] = m + a.goff[2]; }
-            else { gi[1] = m + a.goff[1]; gi[2] = 0; }
-            node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, gi, col + (long long)m * sm, active);
+            const NodeIO io{a.origin + (long long)m * sm, ocol, m + a.goff[NDIM - 1]};
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
             // shift the register line, write the next plane to its ring slot
 #pragma unroll
             for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
@@ -415,8 +469,17 @@ template <>
 struct TileCfg<1> { static constexpr int TX = 256, TY = 1, MC = 1; };
 template <>
 struct TileCfg<2> { static constexpr int TX = 256, TY = 1, MC = 32; };
+#ifndef LSM_TX3
+#define LSM_TX3 32
+#endif
+#ifndef LSM_TY3
+#define LSM_TY3 8
+#endif
+#ifndef LSM_MC3
+#define LSM_MC3 32
+#endif
 template <>
-struct TileCfg<3> { static constexpr int TX = 32, TY = 8, MC = 32; };
+struct TileCfg<3> { static constexpr int TX = LSM_TX3, TY = LSM_TY3, MC = LSM_MC3; };
 
 template <int NDIM, int ADV, int NM, int CURV, int EIK>
 void launch_one(const StageArgs& a, hipStream_t s) {

@@ -94,6 +94,17 @@ LSM_DEV double fast_rcp(double x) {
 }
 LSM_DEV double lsm_div(double a, double b) { return a * fast_rcp(b); }
 
+// 1/sqrt(x) for x > 0 (v_rsq_f64 seed + two Newton steps)
+LSM_DEV double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    double hx = 0.5 * x;
+    double e = __builtin_fma(-hx * r, r, 0.5);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-hx * r, r, 0.5);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
 // sqrt for x >= 0 (Goldschmidt on a v_rsq_f64 seed, final residual correction)
 LSM_DEV double lsm_sqrt(double x) {
     double r = __builtin_amdgcn_rsq(x);
@@ -110,61 +121,82 @@ LSM_DEV double lsm_sqrt(double x) {
 }
 
 // Jiang–Shu WENO5 on UNDIVIDED one-sided differences e1..e5 (ordered from the upwind end inward),
-// returning h·(reference value).  eps_floor = 1e-99·h².
+// returning h·(reference value), in the second-difference form
+//     Σ ω_k dϕ_k = dϕ₂ + (ω₁/3)(A₁-A₂) + (ω₃/6)(A₂-A₃),   A_k = e_k - 2e_{k+1} + e_{k+2},
+// (algebraically identical to src/derivatives.jl:63-80 because Σω = 1), with the three weights from
+// ONE reciprocal: ω_k ∝ c_k Π_{j≠k} (S_j+ε)².  eps_floor = 1e-99·h².
 LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, double e5, double eps_floor) {
-    // candidates pre-multiplied by the linear weights 0.1, 0.6, 0.3
-    double p1 = (0.1 / 3) * e1 - (0.7 / 6) * e2 + (1.1 / 6) * e3;
-    double p2 = -(0.6 / 6) * e2 + (3.0 / 6) * e3 + (0.6 / 3) * e4;
-    double p3 = (0.3 / 3) * e3 + (1.5 / 6) * e4 - (0.3 / 6) * e5;
-    double a1 = e1 - 2 * e2 + e3, b1 = e1 - 4 * e2 + 3 * e3;
-    double a2 = e2 - 2 * e3 + e4, b2 = e2 - e4;
-    double a3 = e3 - 2 * e4 + e5, b3 = 3 * e3 - 4 * e4 + e5;
-    double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(__builtin_fabs(e1), __builtin_fabs(e2)),
-                                             __builtin_fmax(__builtin_fabs(e3), __builtin_fabs(e4))),
-                              __builtin_fabs(e5));
-    double eps = __builtin_fma(1.0e-6 * m, m, eps_floor);
-    double r1 = __builtin_fma((13.0 / 12) * a1, a1, __builtin_fma((0.25 * b1), b1, eps));
-    double r2 = __builtin_fma((13.0 / 12) * a2, a2, __builtin_fma((0.25 * b2), b2, eps));
-    double r3 = __builtin_fma((13.0 / 12) * a3, a3, __builtin_fma((0.25 * b3), b3, eps));
-    double s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
-    double w1 = s2 * s3, w2 = s1 * s3, w3 = s1 * s2;   // ∝ α_k/c_k
-    double num = w1 * p1 + w2 * p2 + w3 * p3;
-    double den = 0.1 * w1 + 0.6 * w2 + 0.3 * w3;
-    den = __builtin_fmax(den, 1.0e-300);              // exactly flat data: 0/tiny = 0, as the reference
-    return num * fast_rcp(den);
+    const double w1 = e2 - e1, w2 = e3 - e2, w3 = e4 - e3, w4 = e5 - e4;
+    const double A1 = w2 - w1, A2 = w3 - w2, A3 = w4 - w3;
+    const double B1 = __builtin_fma(2.0, w2, A1);      // e1 - 4e2 + 3e3
+    const double B2 = w2 + w3;                         // -(e2 - e4)
+    const double B3 = __builtin_fma(-2.0, w3, A3);     // 3e3 - 4e4 + e5
+    const double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(__builtin_fabs(e1), __builtin_fabs(e2)),
+                                                   __builtin_fmax(__builtin_fabs(e3), __builtin_fabs(e4))),
+                                    __builtin_fabs(e5));
+    const double eps = __builtin_fma(1.0e-6 * m, m, eps_floor);
+    const double r1 = __builtin_fma((13.0 / 12) * A1, A1, __builtin_fma(0.25 * B1, B1, eps));
+    const double r2 = __builtin_fma((13.0 / 12) * A2, A2, __builtin_fma(0.25 * B2, B2, eps));
+    const double r3 = __builtin_fma((13.0 / 12) * A3, A3, __builtin_fma(0.25 * B3, B3, eps));
+    const double s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
+    const double W1 = s2 * s3, W2 = s1 * s3, W3 = s1 * s2;   // ∝ α_k / c_k
+    double den = __builtin_fma(0.1, W1, __builtin_fma(0.6, W2, 0.3 * W3));
+    den = __builtin_fmax(den, 1.0e-300);                      // exactly flat data: 0·(1/tiny) = 0, as the reference
+    const double rc = fast_rcp(den);
+    const double dphi2 = __builtin_fma(-1.0 / 6, e2, __builtin_fma(5.0 / 6, e3, (1.0 / 3) * e4));
+    const double t1 = (W1 * rc) * (A1 - A2);
+    const double t3 = (W3 * rc) * (A2 - A3);
+    return __builtin_fma(0.1 / 3, t1, __builtin_fma(0.3 / 6, t3, dphi2));
 }
 
 LSM_DEV double weno5_upwind(const double q[6], double /*hs*/, double inv_hs, double eps_floor) {
     return weno5_undivided(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], eps_floor) * inv_hs;
 }
 
-// minmod on undivided second differences by sign bits
+// minmod on undivided second differences by sign bits: min(|x|,|y|) carrying x's sign when the
+// signs agree, else 0 (src/levelsetterms.jl:184-187; a zero operand gives 0 either way)
 LSM_DEV double minmod_fast(double x, double y) {
-    double m = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
-    unsigned hx = (unsigned)__double2hiint(x), hy = (unsigned)__double2hiint(y);
-    bool same = ((hx ^ hy) >> 31) == 0;
-    return same ? __builtin_copysign(m, x) : 0.0;
+    const double m = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
+    const int hx = __double2hiint(x), hy = __double2hiint(y);
+    const int hm = __double2hiint(m), lm = __double2loint(m);
+    const bool same = (hx ^ hy) >= 0;
+    const int hi = same ? (hm | (hx & (int)0x80000000)) : 0;
+    const int lo = same ? lm : 0;
+    return __hiloint2double(hi, lo);
 }
 
 LSM_DEV void eno2_pair(double m2, double m1, double c, double p1, double p2, double /*h*/, double /*h2*/, double inv_h,
                        double& A, double& B) {
-    double dm = c - m1, dp = p1 - c;
-    double s0 = dp - dm;
-    double smm = dm - (m1 - m2);
-    double spp = (p2 - p1) - dp;
-    A = (dm + 0.5 * minmod_fast(smm, s0)) * inv_h;
-    B = (dp - 0.5 * minmod_fast(spp, s0)) * inv_h;
+    const double dm = c - m1, dp = p1 - c;
+    const double s0 = dp - dm;
+    const double smm = dm - (m1 - m2);
+    const double spp = (p2 - p1) - dp;
+    A = __builtin_fma(0.5, minmod_fast(smm, s0), dm) * inv_h;
+    B = __builtin_fma(-0.5, minmod_fast(spp, s0), dp) * inv_h;
 }
 #endif
 
-// Godunov selection shared by Eikonal (_compute_∇_norm, src/levelsetterms.jl:252-265):
-// v>0 ? (positive(A)², negative(B)²) : (negative(A)², positive(B)²)
+// Godunov selection shared by Eikonal (_compute_∇_norm, src/levelsetterms.jl:252-265) and, in FAST
+// mode, NormalMotion: v>0 ? (positive(A)², negative(B)²) : (negative(A)², positive(B)²)
+#if LSM_STRICT
 LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) {
     double a = vpos ? positive(A) : negative(A);
     double b = vpos ? negative(B) : positive(B);
     a2 = a * a;
     b2 = b * b;
 }
+#else
+// flip the operands' sign bit instead of selecting: negative(A)² == positive(-A)²
+LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) {
+    const int flip = vpos ? 0 : (int)0x80000000;
+    const double As = __hiloint2double(__double2hiint(A) ^ flip, __double2loint(A));
+    const double Bs = __hiloint2double(__double2hiint(B) ^ flip, __double2loint(B));
+    const double a = __builtin_fmax(As, 0.0);
+    const double b = __builtin_fmin(Bs, 0.0);
+    a2 = a * a;
+    b2 = b * b;
+}
+#endif
 
 }  // namespace LSM_NS
 }  // namespace lsm

@@ -50,6 +50,14 @@ class Case:
             orc.fill_ghosts_padded(self.grid, self.bc, self.olay, p)
         return p
 
+    def zero_pad(self, dense):
+        """Padded copy with zero ghosts (coefficient fields are only ever read in-grid)."""
+        p = orc.to_padded(self.olay, self.nd, np.zeros_like(np.asfortranarray(dense)))
+        p[np.isnan(p)] = 0.0
+        sl = tuple(slice(int(self.olay.g[d]), int(self.olay.g[d] + self.olay.n[d])) for d in range(self.nd))
+        p[sl] = dense
+        return p
+
     def interior(self, p):
         return orc.from_padded(self.olay, self.nd, p)
 
@@ -77,11 +85,11 @@ class Case:
                 self.keep.append(t)
                 hc.sep[i] = t.data_ptr()
         else:  # field: dense arrays
-            padded = [self.pad(a, fill=False) for a in spec[1]]
+            padded = [self.zero_pad(a) for a in spec[1]]
             oc = orc.field(*padded)
             hc.kind = L.COEFF_FIELD
             for i, p in enumerate(padded):
-                t = self.to_dev(np.nan_to_num(p, nan=0.0))
+                t = self.to_dev(p)
                 self.keep.append(t)
                 hc.field[i] = t.data_ptr()
         self.keep.append(oc)
