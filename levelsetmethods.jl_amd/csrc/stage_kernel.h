@@ -30,6 +30,15 @@ constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
     return g;
 }
 
+// load/store through a wave-uniform base pointer plus a 32-bit unsigned BYTE offset: this is the
+// shape (sgpr base + zext(vgpr32)) that selects global_load/store's saddr addressing mode.
+LSM_DEV double ldg(const double* base, unsigned boff) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+LSM_DEV void stg(double* base, unsigned boff, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+
 // _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h),
 // split into the part that is constant along the march axis (hoisted out of the plane loop: table
 // look-ups of the leading dimensions, the in-plane rotation) and the per-plane remainder.
@@ -58,7 +67,7 @@ LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1
     }
 }
 template <int NDIM, int NCOMP>
-LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], int gim, long long plane_off, int ocol,
+LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], int gim, long long plane_off, unsigned ocol,
                         double out[3]) {
     if (c.kind == LSM_COEFF_CONST) {
 #pragma unroll
@@ -81,14 +90,14 @@ LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NCOMP; ++k) out[k] = (c.f[k] + plane_off)[ocol];
+        for (int k = 0; k < NCOMP; ++k) out[k] = ldg(c.f[k] + plane_off, ocol);
     }
 }
 
 // where a node reads/writes its pointwise operands: uniform plane offset + per-thread in-plane offset
 struct NodeIO {
-    long long plane_off;   // origin + m*stride_march (wave-uniform)
-    int ocol;              // in-plane offset of this thread
+    long long plane_off;   // offset of the plane's lowest (ghost) corner (wave-uniform)
+    unsigned ocol;         // in-plane BYTE offset of this thread from that corner
     int gim;               // global march index
 };
 
@@ -201,14 +210,10 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         }
         Lnm = positive(v) * lsm_sqrt(gp) + negative(v) * lsm_sqrt(gm);
 #else
-        const bool vpos = v > 0;
+        const int flip = v > 0 ? 0 : (int)0x80000000;
         double g2 = 0.0;
 #pragma unroll
-        for (int d = 0; d < NDIM; ++d) {
-            double x, y;
-            godunov_sel(vpos, A[d], B[d], x, y);
-            g2 += x + y;
-        }
+        for (int d = 0; d < NDIM; ++d) g2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
         Lnm = v * lsm_sqrt(g2);
 #endif
     }
@@ -278,7 +283,8 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- EikonalReinitializationTerm: S (|∇ϕ| - 1) — src/levelsetterms.jl:234-265
     if constexpr (EIK != 0) {
-        const double s = EIK == 1 ? (a.s0 + io.plane_off)[io.ocol] : c;
+        const double s = EIK == 1 ? ldg(a.s0 + io.plane_off, io.ocol) : c;
+#if LSM_STRICT
         const bool vpos = s > 0;
         double mA = 0.0, mB = 0.0;
 #pragma unroll
@@ -288,6 +294,12 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
             if (d == 0) { mA = x; mB = y; } else { mA = mA + x; mB = mB + y; }
         }
         const double n2 = mA + mB;
+#else
+        const int flip = s > 0 ? 0 : (int)0x80000000;
+        double n2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) n2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
+#endif
         const double nrm = lsm_sqrt(n2);
         double S;
         if constexpr (EIK == 1) {
@@ -298,7 +310,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
             S = den == 0.0 ? 0.0 : lsm_div(c, den);
 #else
             const double d2 = __builtin_fma(n2, a.dxmin * a.dxmin, c * c);
-            S = d2 > 0.0 ? c * fast_rsqrt(d2) : 0.0;
+            S = c * fast_rsqrt(__builtin_fmax(d2, 1.0e-300));   // d2 == 0 implies c == 0: S = 0
 #endif
         }
         Leik = S * (nrm - 1);
@@ -308,16 +320,16 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     if (!active) return;
     double base;
     if (a.base_mode == LSM_BASE_PSI) base = c;
-    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * (a.phin + io.plane_off)[io.ocol] + 0.25 * c;
+    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * ldg(a.phin + io.plane_off, io.ocol) + 0.25 * c;
     else if (a.base_mode == LSM_BASE_RK3_S3)
 #if LSM_STRICT
-        base = ((a.phin + io.plane_off)[io.ocol] + 2 * c) / 3;
+        base = (ldg(a.phin + io.plane_off, io.ocol) + 2 * c) / 3;
 #else
-        base = ((a.phin + io.plane_off)[io.ocol] + 2 * c) * (1.0 / 3);
+        base = (ldg(a.phin + io.plane_off, io.ocol) + 2 * c) * (1.0 / 3);
 #endif
-    else base = (a.phin + io.plane_off)[io.ocol];
+    else base = ldg(a.phin + io.plane_off, io.ocol);
     double b2 = 0.0;
-    if (a.out2) b2 = a.out2_accum ? (a.out2 + io.plane_off)[io.ocol] : c;
+    if (a.out2) b2 = a.out2_accum ? ldg(a.out2 + io.plane_off, io.ocol) : c;
     for (int k = 0; k < a.nterms; ++k) {
         const int o = a.order[k];
         double L = Ladv;
@@ -327,12 +339,20 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         base -= a.cdt * L;
         b2 -= a.cdt2 * L;
     }
-    (a.out + io.plane_off)[io.ocol] = base;
-    if (a.out2) (a.out2 + io.plane_off)[io.ocol] = b2;
+    stg(a.out + io.plane_off, io.ocol, base);
+    if (a.out2) stg(a.out2 + io.plane_off, io.ocol, b2);
 }
 
+#ifndef LSM_WAVES_PER_EU
+#define LSM_WAVES_PER_EU 1
+#endif
+#ifdef LSM_EXP_NOBARRIER
+#define LSM_BARRIER() do {} while (0)
+#else
+#define LSM_BARRIER() __syncthreads()
+#endif
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC>
-__global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
+__global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const StageArgs a) {
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
     constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
     constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
@@ -363,16 +383,19 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
     const int cx = gx < nx ? gx : nx - 1, cy = gy < ny ? gy : ny - 1;
     const int lxg = gx < nx + G ? gx : nx + G - 1;
     const int lyg = HAS_Y ? (gy < ny + G ? gy : ny + G - 1) : 0;
-    const int ocol = lxg + lyg * (int)sy;               // in-plane offset of this thread's column
+    // unsigned in-plane offset from the plane's lowest (ghost) corner: with a wave-uniform base this
+    // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
+    const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
+    const unsigned ocol = 8u * ((unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
     const int m0 = MARCH ? (NDIM == 3 ? blockIdx.z : blockIdx.y) * MC : 0;
     const int m1 = MARCH ? (m0 + MC < nm ? m0 + MC : nm) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
-    auto plane = [&](int p) { return a.psi + (a.origin + (long long)clampM(p) * sm); };
+    auto plane = [&](int p) { return a.psi + (corner + (long long)clampM(p) * sm); };
 
     // halo elements owned by this thread: LDS offset within a plane, global offset within a plane
     int hl[HPT > 0 ? HPT : 1];
-    int hg[HPT > 0 ? HPT : 1];
+    unsigned hg[HPT > 0 ? HPT : 1];
     bool hv[HPT > 0 ? HPT : 1];
 #pragma unroll
     for (int h = 0; h < HPT; ++h) {
@@ -397,7 +420,7 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
             Y = Y > ny + G - 1 ? ny + G - 1 : Y;
         }
         hl[h] = ly * W + lx;
-        hg[h] = X + Y * (int)sy;
+        hg[h] = 8u * ((unsigned)(X + G) + (unsigned)(Y + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
     }
     const int lpos = (ty + (HAS_Y ? G : 0)) * W + tx + G;
 
@@ -412,19 +435,19 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
 
     if constexpr (!MARCH) {
         const double* P = plane(0);
-        const double c = P[ocol];
+        const double c = ldg(P, ocol);
         tile[lpos] = c;
 #pragma unroll
         for (int h = 0; h < HPT; ++h)
-            if (hv[h]) tile[hl[h]] = P[hg[h]];
+            if (hv[h]) tile[hl[h]] = ldg(P, hg[h]);
         __syncthreads();
         NodeView<NDIM, G, W> nv{tile + lpos, nullptr, nullptr, nullptr, c};
-        const NodeIO io{a.origin, ocol, 0};
+        const NodeIO io{corner, ocol, 0};
         node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
     } else {
         double zl[2 * G + 1];
 #pragma unroll
-        for (int j = 0; j <= 2 * G; ++j) zl[j] = plane(m0 - G + j)[ocol];
+        for (int j = 0; j <= 2 * G; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
 #pragma unroll
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
             const int slot = pl + LEAD;
@@ -432,23 +455,23 @@ __global__ void __launch_bounds__(TX* TY) stage_kernel(const StageArgs a) {
             const double* P = plane(m0 + pl);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
-                if (hv[h]) tile[slot * HW + hl[h]] = P[hg[h]];
+                if (hv[h]) tile[slot * HW + hl[h]] = ldg(P, hg[h]);
         }
         for (int m = m0; m < m1; ++m) {
             // issue the next plane's global loads early; they land in LDS after this plane's arithmetic
-            const double nxt = plane(m + 1 + G)[ocol];
+            const double nxt = ldg(plane(m + 1 + G), ocol);
             double hn[HPT > 0 ? HPT : 1];
             const double* Pn = plane(m + 1 + LEAD);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
-                if (hv[h]) hn[h] = Pn[hg[h]];
-            __syncthreads();
+                if (hv[h]) hn[h] = ldg(Pn, hg[h]);
+            LSM_BARRIER();
             const int rel = m - m0;
             const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
             const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
             const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
             NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
-            const NodeIO io{a.origin + (long long)m * sm, ocol, m + a.goff[NDIM - 1]};
+            const NodeIO io{corner + (long long)m * sm, ocol, m + a.goff[NDIM - 1]};
             node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
             // shift the register line, write the next plane to its ring slot
 #pragma unroll

@@ -105,8 +105,11 @@ LSM_DEV double fast_rsqrt(double x) {
     return r;
 }
 
-// sqrt for x >= 0 (Goldschmidt on a v_rsq_f64 seed, final residual correction)
-LSM_DEV double lsm_sqrt(double x) {
+// sqrt for x >= 0 (Goldschmidt on a v_rsq_f64 seed, final residual correction).  The argument is
+// floored at 1e-300 instead of branching on zero: sqrt(0) returns 1e-150 (a select costs ≈4 fp64
+// issue slots on gfx950, an fmax one).
+LSM_DEV double lsm_sqrt(double x0) {
+    const double x = __builtin_fmax(x0, 1.0e-300);
     double r = __builtin_amdgcn_rsq(x);
     double g = x * r, hh = 0.5 * r;
     double e = __builtin_fma(-hh, g, 0.5);
@@ -116,8 +119,7 @@ LSM_DEV double lsm_sqrt(double x) {
     g = __builtin_fma(g, e, g);
     hh = __builtin_fma(hh, e, hh);
     double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, hh, g);
-    return (x > 0.0 && x < __builtin_inf()) ? g : x;   // 0 -> 0, inf -> inf, NaN -> NaN
+    return __builtin_fma(d, hh, g);
 }
 
 // Jiang–Shu WENO5 on UNDIVIDED one-sided differences e1..e5 (ordered from the upwind end inward),
@@ -140,39 +142,33 @@ LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, doubl
     const double r3 = __builtin_fma((13.0 / 12) * A3, A3, __builtin_fma(0.25 * B3, B3, eps));
     const double s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
     const double W1 = s2 * s3, W2 = s1 * s3, W3 = s1 * s2;   // ∝ α_k / c_k
-    double den = __builtin_fma(0.1, W1, __builtin_fma(0.6, W2, 0.3 * W3));
+    const double c1W1 = (0.1 / 3) * W1, c3W3 = (0.3 / 6) * W3;
+    double den = __builtin_fma(3.0, c1W1, __builtin_fma(6.0, c3W3, 0.6 * W2));   // 0.1 W1 + 0.6 W2 + 0.3 W3
     den = __builtin_fmax(den, 1.0e-300);                      // exactly flat data: 0·(1/tiny) = 0, as the reference
     const double rc = fast_rcp(den);
     const double dphi2 = __builtin_fma(-1.0 / 6, e2, __builtin_fma(5.0 / 6, e3, (1.0 / 3) * e4));
-    const double t1 = (W1 * rc) * (A1 - A2);
-    const double t3 = (W3 * rc) * (A2 - A3);
-    return __builtin_fma(0.1 / 3, t1, __builtin_fma(0.3 / 6, t3, dphi2));
+    const double X = __builtin_fma(c1W1, A1 - A2, c3W3 * (A2 - A3));
+    return __builtin_fma(rc, X, dphi2);
 }
 
 LSM_DEV double weno5_upwind(const double q[6], double /*hs*/, double inv_hs, double eps_floor) {
     return weno5_undivided(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], eps_floor) * inv_hs;
 }
 
-// minmod on undivided second differences by sign bits: min(|x|,|y|) carrying x's sign when the
-// signs agree, else 0 (src/levelsetterms.jl:184-187; a zero operand gives 0 either way)
+// minmod(x,y) = max(0,min(x,y)) + min(0,max(x,y)) (src/levelsetterms.jl:184-187 without selects)
 LSM_DEV double minmod_fast(double x, double y) {
-    const double m = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
-    const int hx = __double2hiint(x), hy = __double2hiint(y);
-    const int hm = __double2hiint(m), lm = __double2loint(m);
-    const bool same = (hx ^ hy) >= 0;
-    const int hi = same ? (hm | (hx & (int)0x80000000)) : 0;
-    const int lo = same ? lm : 0;
-    return __hiloint2double(hi, lo);
+    return __builtin_fmax(0.0, __builtin_fmin(x, y)) + __builtin_fmin(0.0, __builtin_fmax(x, y));
 }
 
-LSM_DEV void eno2_pair(double m2, double m1, double c, double p1, double p2, double /*h*/, double /*h2*/, double inv_h,
+// FAST: A and B are returned UNDIVIDED (h·A, h·B); the caller applies 1/h² to the squares.
+LSM_DEV void eno2_pair(double m2, double m1, double c, double p1, double p2, double /*h*/, double /*h2*/, double /*inv_h*/,
                        double& A, double& B) {
     const double dm = c - m1, dp = p1 - c;
     const double s0 = dp - dm;
     const double smm = dm - (m1 - m2);
     const double spp = (p2 - p1) - dp;
-    A = __builtin_fma(0.5, minmod_fast(smm, s0), dm) * inv_h;
-    B = __builtin_fma(-0.5, minmod_fast(spp, s0), dp) * inv_h;
+    A = __builtin_fma(0.5, minmod_fast(smm, s0), dm);
+    B = __builtin_fma(-0.5, minmod_fast(spp, s0), dp);
 }
 #endif
 
@@ -186,15 +182,14 @@ LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) 
     b2 = b * b;
 }
 #else
-// flip the operands' sign bit instead of selecting: negative(A)² == positive(-A)²
-LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) {
-    const int flip = vpos ? 0 : (int)0x80000000;
+// flip the operands' sign bit instead of selecting (negative(A)² == positive(-A)²); A,B undivided,
+// returns inv_h2·(a² + b²)
+LSM_DEV double godunov_term(int flip, double A, double B, double inv_h2) {
     const double As = __hiloint2double(__double2hiint(A) ^ flip, __double2loint(A));
     const double Bs = __hiloint2double(__double2hiint(B) ^ flip, __double2loint(B));
     const double a = __builtin_fmax(As, 0.0);
     const double b = __builtin_fmin(Bs, 0.0);
-    a2 = a * a;
-    b2 = b * b;
+    return __builtin_fma(a, a, b * b) * inv_h2;
 }
 #endif
 
