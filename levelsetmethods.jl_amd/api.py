@@ -707,19 +707,22 @@ class LevelSetEquation:
         plane = lambda k0, k1: flat[(k0 + G) * sl:(k1 + G) * sl]   # local plane range [k0, k1)
         up = self.rank + 1 if self.rank < self.world - 1 else (0 if self.periodic_last else None)
         dn = self.rank - 1 if self.rank > 0 else (self.world - 1 if self.periodic_last else None)
-        ops = []
         # periodic wrap has period n-1 (nodes 1 and n coincide, src/boundaryconditions.jl:107-119):
         # across the wrap the sender skips its duplicate end node.
         wrap_up = self.rank == self.world - 1
         wrap_dn = self.rank == 0
+        # op order [send up, recv dn, send dn, recv up]: messages between one pair of ranks match in
+        # posting order (RCCL and gloo alike), which matters when up == dn (2 ranks, periodic ring).
+        ops = []
         if up is not None:
             s0 = nloc - G - (1 if wrap_up else 0)
             ops.append(dist.P2POp(dist.isend, plane(s0, s0 + G), up, group=self.comm))
-            ops.append(dist.P2POp(dist.irecv, plane(nloc, nloc + G), up, group=self.comm))
         if dn is not None:
+            ops.append(dist.P2POp(dist.irecv, plane(-G, 0), dn, group=self.comm))
             s0 = 1 if wrap_dn else 0
             ops.append(dist.P2POp(dist.isend, plane(s0, s0 + G), dn, group=self.comm))
-            ops.append(dist.P2POp(dist.irecv, plane(-G, 0), dn, group=self.comm))
+        if up is not None:
+            ops.append(dist.P2POp(dist.irecv, plane(nloc, nloc + G), up, group=self.comm))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
