@@ -1,0 +1,216 @@
+# ROCMeshField.jl — the reference-side binding a maintainer would add to LevelSetMethods.jl
+# (e.g. as ext/ROCMExt.jl with AMDGPU as a weak dependency).  Host code stays Julia; AMDGPU.jl only
+# owns the device arrays; every kernel is reached through `ccall` into libhiplsm.so (include/lsm.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: there is no Julia runtime in the build container
+# (SURVEY.md, "Container facts").  The Python host layer (levelsetmethods.jl_amd/api.py) drives the
+# SAME C ABI call for call and is what the GPU tests exercise; this file mirrors it one to one.
+#
+# Extension point used: the AbstractMeshField interface (src/meshfield.jl:11-33) and the methods
+# the integrator reaches a field through (src/timestepping.jl:126-202, src/levelsetterms.jl:22-38).
+
+module ROCMExt
+
+using AMDGPU
+using LevelSetMethods
+import LevelSetMethods as LSM
+using StaticArrays
+
+const libhiplsm = get(ENV, "LSM_AMD_LIB", "libhiplsm.so")
+const LSM_GHOST = 3
+
+# ---- POD mirrors of include/lsm.h ------------------------------------------------------------
+struct LsmGrid
+    ndim::Int32
+    _pad::Int32
+    n::NTuple{3, Int64}
+    lc::NTuple{3, Float64}
+    hc::NTuple{3, Float64}
+end
+struct LsmBc
+    kind::Int32
+    degree::Int32
+end
+struct LsmLayout
+    n::NTuple{3, Int64}
+    g::NTuple{3, Int64}
+    stride::NTuple{3, Int64}
+    origin::Int64
+    total::Int64
+end
+struct LsmCoeff
+    kind::Int32
+    time_kind::Int32
+    time_param::Float64
+    value::NTuple{4, Float64}
+    field::NTuple{3, Ptr{Cvoid}}
+    sep::NTuple{3, Ptr{Float64}}
+end
+struct LsmTerm
+    kind::Int32
+    scheme::Int32
+    coeff::LsmCoeff
+    s0::Ptr{Cvoid}
+end
+
+_pad3(t, fill) = ntuple(i -> i <= length(t) ? t[i] : fill, 3)
+
+lsmgrid(g::LSM.CartesianGrid{N}) where {N} =
+    LsmGrid(N, 0, _pad3(Int64.(g.n), Int64(1)), _pad3(Float64.(g.lc), 0.0), _pad3(Float64.(g.hc), 1.0))
+
+lsmbc(::LSM.PeriodicBC) = LsmBc(0, 0)
+lsmbc(::LSM.ExtrapolationBC{P}) where {P} = LsmBc(1, P)
+lsmbc(::LSM.SymmetryBC) = LsmBc(2, 0)
+
+function _check(h, code, what)
+    code == 0 && return
+    msg = unsafe_string(ccall((:lsm_last_error, libhiplsm), Cstring, (Ptr{Cvoid},), h))
+    error("$what failed ($code): $msg")
+end
+
+# ---- the device field --------------------------------------------------------------------------
+"""
+    ROCMeshField{N,T,B} <: AbstractMeshField{N,T,Float64}
+
+Dense level-set field resident in HBM in libhiplsm's padded layout (ghost layers materialised).
+"""
+mutable struct ROCMeshField{N, T, B} <: LSM.AbstractMeshField{N, T, Float64}
+    buf::ROCVector{Float64}
+    mesh::LSM.CartesianGrid{N, T}
+    bcs::B
+    handle::Ptr{Cvoid}
+    layout::LsmLayout
+end
+
+function _create(mesh::LSM.CartesianGrid{N}, bcs; strict = false) where {N}
+    g = Ref(lsmgrid(mesh))
+    bc = [d <= N ? lsmbc(bcs[d][s]) : LsmBc(1, 0) for s in 1:2, d in 1:3]   # C order bc[dim][side]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    code = ccall((:lsm_create, libhiplsm), Cint,
+        (Ref{LsmGrid}, Ptr{LsmBc}, Ptr{Cvoid}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+        g, bc, C_NULL, 0, strict ? 1 : 0, AMDGPU.device_id(AMDGPU.device()) - 1, h)
+    _check(C_NULL, code, "lsm_create")
+    # kernels run on the stream AMDGPU.jl uses for its own copies
+    _check(h[], ccall((:lsm_set_stream, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], AMDGPU.stream().stream), "lsm_set_stream")
+    lay = Ref{LsmLayout}()
+    _check(h[], ccall((:lsm_layout, libhiplsm), Cint, (Ptr{Cvoid}, Ref{LsmLayout}), h[], lay), "lsm_layout")
+    return h[], lay[]
+end
+
+function ROCMeshField(ϕ::LSM.MeshField{N, T}; strict = false) where {N, T}
+    LSM._check_bc(ϕ)
+    h, lay = _create(LSM.mesh(ϕ), LSM.boundary_conditions(ϕ); strict)
+    buf = AMDGPU.zeros(Float64, lay.total)
+    f = ROCMeshField{N, T, typeof(LSM.boundary_conditions(ϕ))}(buf, LSM.mesh(ϕ), LSM.boundary_conditions(ϕ), h, lay)
+    finalizer(x -> ccall((:lsm_destroy, libhiplsm), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    _check(h, ccall((:lsm_upload, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), h, pointer(buf), values(ϕ)), "lsm_upload")
+    return f
+end
+
+# values(ϕ): host copy on demand (show, hooks, tests)
+function Base.values(ϕ::ROCMeshField{N}) where {N}
+    out = Array{Float64, N}(undef, size(LSM.mesh(ϕ)))
+    _check(ϕ.handle, ccall((:lsm_download, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), ϕ.handle, pointer(ϕ.buf), out), "lsm_download")
+    return out
+end
+LSM.MeshField(ϕ::ROCMeshField) = LSM.MeshField(values(ϕ), LSM.mesh(ϕ), ϕ.bcs)
+
+function Base.copy(ϕ::ROCMeshField{N, T, B}) where {N, T, B}
+    h, lay = _create(ϕ.mesh, ϕ.bcs)
+    f = ROCMeshField{N, T, B}(copy(ϕ.buf), ϕ.mesh, ϕ.bcs, h, lay)
+    finalizer(x -> ccall((:lsm_destroy, libhiplsm), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    return f
+end
+Base.copy!(dst::ROCMeshField, src::ROCMeshField) = (copyto!(dst.buf, src.buf); dst)
+LSM.update_band!(::ROCMeshField) = nothing
+# scalar indexing: slow path for tests and hooks
+Base.getindex(ϕ::ROCMeshField, I::CartesianIndex) = LSM.MeshField(ϕ)[I]
+
+# ---- terms -> LsmTerm ---------------------------------------------------------------------------
+# Julia closures cannot run on the device: constants, catalogued analytic fields and device
+# MeshFields are passed through; anything else is sampled on the host into a FIELD before each stage.
+struct RigidRotation; ω::Float64; c::NTuple{2, Float64}; end     # u = ω·(-(x₂-c₂), x₁-c₁, 0)
+
+_coeff(v::Number) = LsmCoeff(0, 0, 1.0, (Float64(v), 0.0, 0.0, 0.0), (C_NULL, C_NULL, C_NULL), (C_NULL, C_NULL, C_NULL))
+_coeff(v::Union{SVector, Tuple}) = LsmCoeff(0, 0, 1.0, _pad4(Float64.(Tuple(v))), (C_NULL, C_NULL, C_NULL), (C_NULL, C_NULL, C_NULL))
+_coeff(r::RigidRotation) = LsmCoeff(1, 0, 1.0, (r.ω, r.c[1], r.c[2], 0.0), (C_NULL, C_NULL, C_NULL), (C_NULL, C_NULL, C_NULL))
+_coeff(fs::NTuple{K, ROCMeshField}) where {K} =
+    LsmCoeff(3, 0, 1.0, (0.0, 0.0, 0.0, 0.0), _pad3(map(f -> Ptr{Cvoid}(pointer(f.buf)), fs), C_NULL), (C_NULL, C_NULL, C_NULL))
+_pad4(t) = ntuple(i -> i <= length(t) ? t[i] : 0.0, 4)
+
+_term(t::LSM.AdvectionTerm) = LsmTerm(0, LSM.scheme(t) isa LSM.WENO5 ? 1 : 0, _coeff(LSM.velocity(t)), C_NULL)
+_term(t::LSM.NormalMotionTerm) = LsmTerm(1, 0, _coeff(LSM.speed(t)), C_NULL)
+_term(t::LSM.CurvatureTerm) = LsmTerm(2, 0, _coeff(LSM.coefficient(t)), C_NULL)
+_term(t::LSM.EikonalReinitializationTerm{Nothing}) = LsmTerm(3, 0, _coeff(0.0), C_NULL)
+_term(t::LSM.EikonalReinitializationTerm{<:ROCMeshField}) = LsmTerm(3, 0, _coeff(0.0), Ptr{Cvoid}(pointer(t.S₀.buf)))
+
+# EikonalReinitializationTerm(ϕ₀::ROCMeshField): S₀ = ϕ₀/√(ϕ₀²+Δx²) on the device (src/levelsetterms.jl:217-221)
+function LSM.EikonalReinitializationTerm(ϕ₀::ROCMeshField)
+    S₀ = copy(ϕ₀)
+    _check(ϕ₀.handle, ccall((:lsm_eikonal_sign, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ₀.handle, pointer(ϕ₀.buf), pointer(S₀.buf), C_NULL), "lsm_eikonal_sign")
+    return LSM.EikonalReinitializationTerm{typeof(S₀)}(S₀)
+end
+
+# ---- the three methods the integrator dispatches on ---------------------------------------------
+# compute_cfl (src/levelsetterms.jl:22-28): the library returns the raw minimum, Julia throws.
+function LSM.compute_cfl(terms, ϕ::ROCMeshField, t)
+    ts = [_term(term) for term in terms]
+    dt = Ref{Float64}(0.0)
+    _check(ϕ.handle, ccall((:lsm_compute_cfl, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Float64, Ref{Float64}),
+        ϕ.handle, ts, length(ts), pointer(ϕ.buf), t, dt), "lsm_compute_cfl")
+    Δt = dt[]
+    Δt > 0 || throw(ArgumentError("invalid time-step based on CFL condition: Δt = $Δt (check for NaN/Inf in velocity or speed)"))
+    return Δt
+end
+
+# stage hook: lets update_func(field, stage_field, stage_time) run between stage launches
+# (src/timestepping.jl:131,149,158,174,185,196); NULL when every term has the default no-op hook.
+function _hook(terms, fields)
+    all(t -> !hasproperty(t, :update_func) || t.update_func === LSM.AdvectionTerm(0).update_func, terms) && return C_NULL
+    cb = (user, stage, ptr, tstage) -> begin
+        for term in terms; LSM.update_term!(term, fields[stage + 1], tstage); end
+        Cint(0)
+    end
+    return @cfunction($cb, Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Float64))
+end
+
+LSM._alloc_buffers(::LSM.ForwardEuler, ϕ::ROCMeshField) = (copy(ϕ),)
+LSM._alloc_buffers(::Union{LSM.RK2, LSM.RK3}, ϕ::ROCMeshField) = (copy(ϕ), copy(ϕ))
+
+function LSM._advance!(::LSM.ForwardEuler, ϕ::ROCMeshField, (dst,), terms, tc, Δt)
+    ts = [_term(term) for term in terms]
+    _check(ϕ.handle, ccall((:lsm_advance_fe, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, ts, length(ts), pointer(ϕ.buf), pointer(dst.buf), tc, Δt, _hook(terms, (ϕ,)), C_NULL), "lsm_advance_fe")
+    return ϕ
+end
+function LSM._advance!(::LSM.RK2, ϕ::ROCMeshField, (pred, corr), terms, tc, Δt)
+    ts = [_term(term) for term in terms]
+    _check(ϕ.handle, ccall((:lsm_advance_rk2, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, ts, length(ts), pointer(ϕ.buf), pointer(pred.buf), pointer(corr.buf), tc, Δt, _hook(terms, (ϕ, pred)), C_NULL), "lsm_advance_rk2")
+    return ϕ
+end
+function LSM._advance!(::LSM.RK3, ϕ::ROCMeshField, (buf1, buf2), terms, tc, Δt)
+    ts = [_term(term) for term in terms]
+    _check(ϕ.handle, ccall((:lsm_advance_rk3, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, ts, length(ts), pointer(ϕ.buf), pointer(buf1.buf), pointer(buf2.buf), tc, Δt, _hook(terms, (ϕ, buf1, buf2)), C_NULL), "lsm_advance_rk3")
+    return ϕ
+end
+
+# show needs extrema (src/meshfield.jl:300-303)
+function Base.extrema(ϕ::ROCMeshField)
+    lo, hi = Ref{Float64}(), Ref{Float64}()
+    _check(ϕ.handle, ccall((:lsm_extrema, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}, Ref{Float64}), ϕ.handle, pointer(ϕ.buf), lo, hi), "lsm_extrema")
+    return lo[], hi[]
+end
+
+# usage (drop-in):
+#   ϕ  = MeshField(x -> norm(x) - 0.5, grid; bc = NeumannBC())
+#   eq = LevelSetEquation(; terms = (AdvectionTerm(RigidRotation(1.0, (0.0, 0.0))),), ic = ROCMeshField(ϕ), integrator = RK3())
+#   integrate!(eq, 1.0)              # _integrate! (src/timestepping.jl:101-122) runs unchanged on the host
+#   ϕ_final = MeshField(current_state(eq))
+
+end # module

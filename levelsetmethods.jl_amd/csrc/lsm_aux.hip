@@ -115,34 +115,68 @@ __device__ __forceinline__ void cfl_coeff(const CoeffArgs& c, const CflArgs& a, 
 // i.e. a correctly-rounded, monotonically DEcreasing function f of a per-node quantity s
 // (s = Σ|u_d|/h_d, resp. |b|).  Because IEEE division is monotone, min_I f(s_I) == f(max_I s_I)
 // bit for bit, so the kernel reduces max s (plus an any-NaN flag: Julia's min propagates NaN) and
-// the final kernel applies f once.  One workgroup walks whole x-rows: the row's y/z table factors
-// and coordinates are wave-uniform.
+// the final kernel applies f once.
 __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
-    const int nrows = a.n[1] * a.n[2];
+    // one thread per column of the LAST dimension (x fastest across lanes: coalesced FIELD reads);
+    // everything that does not depend on the last index is hoisted out of the march.
+    const int nlast = a.n[ndim - 1];
+    const long long ncol = ndim == 1 ? 1 : (ndim == 2 ? a.n[0] : (long long)a.n[0] * a.n[1]);
+    const long long slast = ndim == 1 ? 1 : (ndim == 2 ? a.s1 : a.s2);
+    const int ncomp = a.term_kind == LSM_TERM_ADVECTION ? ndim : 1;
     double best = 0.0;   // s >= 0
     int sawnan = 0;
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int i1 = row % a.n[1], i2 = row / a.n[1];
-        const long long rbase = a.origin + i1 * a.s1 + i2 * a.s2;
-        for (int i0 = threadIdx.x; i0 < a.n[0]; i0 += blockDim.x) {
-            const int gi[3] = {i0 + a.goff[0], i1 + a.goff[1], i2 + a.goff[2]};
-            const long long center = rbase + i0;
+    for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < (ndim == 1 ? nlast : ncol);
+         col += (long long)gridDim.x * blockDim.x) {
+        // ndim == 1: the "column" is a single node index along x
+        const int i0 = ndim == 1 ? (int)col : (int)(col % a.n[0]);
+        const int i1 = ndim == 3 ? (int)(col / a.n[0]) : 0;
+        const int g0 = i0 + a.goff[0], g1 = i1 + a.goff[1];
+        const long long cbase = a.origin + i0 + (ndim == 3 ? i1 * a.s1 : 0);
+        double pre[3] = {0, 0, 0};
+        const CoeffArgs& c = a.coeff;
+        if (c.kind == LSM_COEFF_SEPARABLE) {
+            for (int k = 0; k < ncomp; ++k) {
+                double p = c.sep[k][g0];
+                if (ndim == 3) p = p * c.sep[k][a.gn[0] + g1];
+                pre[k] = p;
+            }
+        } else if (c.kind == LSM_COEFF_ROTATION) {
+            const double x1 = a.lc[0] + (double)g0 * a.h[0];
+            pre[1] = c.v[0] * (x1 - c.v[1]);
+            if (ndim == 3) pre[0] = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
+        }
+        // the march range is split over gridDim.y chunks for occupancy
+        const int mcount = ndim == 1 ? 1 : nlast;
+        const int chunk = (mcount + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int mb = (int)blockIdx.y * chunk, me = mb + chunk < mcount ? mb + chunk : mcount;
+#pragma unroll 4
+        for (int m = mb; m < me; ++m) {
+            const int gm = m + a.goff[ndim - 1];
             double u[3] = {0, 0, 0};
+            if (c.kind == LSM_COEFF_CONST) {
+                for (int k = 0; k < ncomp; ++k) u[k] = c.v[k];
+            } else if (c.kind == LSM_COEFF_SEPARABLE) {
+                for (int k = 0; k < ncomp; ++k) {
+                    double p = pre[k];
+                    if (ndim > 1) p = p * c.sep[k][(ndim == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gm];
+                    u[k] = p * c.tfac;
+                }
+            } else if (c.kind == LSM_COEFF_ROTATION) {
+                u[0] = ndim == 2 ? -(c.v[0] * ((a.lc[1] + (double)gm * a.h[1]) - c.v[2])) : pre[0];
+                u[1] = pre[1];
+            } else {
+                for (int k = 0; k < ncomp; ++k) u[k] = c.f[k][cbase + (ndim == 1 ? 0 : m * slast)];
+            }
             double sv;
             if (a.term_kind == LSM_TERM_ADVECTION) {
-                if (ndim == 1) cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
-                else if (ndim == 2) cfl_coeff<2>(a.coeff, a, ndim, gi, center, u);
-                else cfl_coeff<3>(a.coeff, a, ndim, gi, center, u);
                 sv = __builtin_fabs(u[0]) / a.h[0];
                 if (ndim > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
                 if (ndim > 2) sv = sv + __builtin_fabs(u[2]) / a.h[2];
             } else if (a.term_kind == LSM_TERM_NORMAL_MOTION) {
-                cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
                 sv = __builtin_fabs(u[0]) / a.h[0];
                 if (ndim > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
                 if (ndim > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
-            } else { /* curvature with a field/analytic b */
-                cfl_coeff<1>(a.coeff, a, ndim, gi, center, u);
+            } else {
                 sv = __builtin_fabs(u[0]);
             }
             if (sv != sv) sawnan = 1;
@@ -160,7 +194,7 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
         double m = smax[0];
         int f = snan[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smax[w] > m ? smax[w] : m; f |= snan[w]; }
-        a.partial[blockIdx.x] = m;
+        a.partial[blockIdx.y * gridDim.x + blockIdx.x] = m;
         if (f) atomicOr(a.nanflag, 1);
     }
 }
@@ -182,12 +216,16 @@ __global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, i
     }
 }
 
-int cfl_blocks(int /*ndim*/, const int n[3]) {
-    const long long rows = (long long)n[1] * n[2];
-    return (int)(rows > 2048 ? 2048 : (rows < 1 ? 1 : rows));
+static const int CFL_CHUNKS = 4;
+int cfl_blocks(int ndim, const int n[3]) {
+    const long long cols = ndim == 1 ? n[0] : (ndim == 2 ? n[0] : (long long)n[0] * n[1]);
+    const long long b = (cols + 255) / 256;
+    const int bx = (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+    return bx * (ndim == 1 ? 1 : CFL_CHUNKS);   // number of partials
 }
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(cfl_kernel, dim3(nblocks), dim3(256), 0, s, a, ndim);
+    const int chunks = ndim == 1 ? 1 : CFL_CHUNKS;
+    hipLaunchKernelGGL(cfl_kernel, dim3(nblocks / chunks, chunks), dim3(256), 0, s, a, ndim);
 }
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
                       hipStream_t s) {
