@@ -161,6 +161,12 @@ int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, c
  *      minimum (Inf, NaN and <=0 possible): the CALLER raises the reference's ArgumentError. */
 int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, double t, double* dt_out);
 
+/* The CFL of a catalogued analytic coefficient WITHOUT time factor (ROTATION, SEPARABLE with
+ * LSM_TIME_ONE) is the same every step; it is computed once per handle and reused as long as the
+ * LsmTerm is byte-identical.  Calling this (with 0 or 1) flushes the cache; pass 0 when table
+ * contents are mutated in place between steps. */
+int lsm_cfl_cache(LsmHandle* h, int enable);
+
 /* ---- _advance! per integrator.  phi's ghosts are (re)filled on entry and valid on return.
  *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63). */
 int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1,

@@ -71,6 +71,7 @@ _SIGS = [
     ("lsm_stage", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                             C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("lsm_compute_cfl", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_double)]),
+    ("lsm_cfl_cache", C.c_int, [_H, C.c_int]),
     ("lsm_advance_fe", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                  StageHook, C.c_void_p]),
     ("lsm_advance_rk2", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,

@@ -583,6 +583,8 @@ class LevelSetEquation:
             term._bind(grid, self.backend, self.slab)
         self._bufs = None
         self._hook_keep = None
+        if any(t.update_func is not None for t in terms) and hasattr(self.backend, "cfl_cache"):
+            self.backend.cfl_cache(False)   # hooks may mutate coefficients in place
 
     # accessors (src/levelsetequation.jl:124-162)
     def current_state(self):

@@ -100,6 +100,9 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_compute_cfl(self.h, terms_c, nterms, self.ptr(phi), t, C.byref(dt)), "lsm_compute_cfl")
         return dt.value
 
+    def cfl_cache(self, enable):
+        L.check(self.h, self.lib.lsm_cfl_cache(self.h, 1 if enable else 0), "lsm_cfl_cache")
+
     def advance_single(self, which, terms_c, nterms, phi, b1, b2, tc, dt, hook):
         cb = hook if hook is not None else C.cast(None, L.StageHook)
         if which == "fe":

@@ -43,6 +43,8 @@ struct LsmHandle {
     double* d_result;    // 2 doubles
     double* h_result;    // pinned, 2 doubles
     std::string err;
+    bool cfl_cache_on;
+    std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients
     bool prof;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used;
@@ -113,6 +115,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     memcpy(h->bc, bc, sizeof(h->bc));
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
+    h->cfl_cache_on = true;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
     if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
@@ -388,6 +391,14 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             if (tm.kind < 0 || tm.kind > LSM_TERM_EIKONAL) return fail(h, LSM_ERR_INVALID, "bad term kind");
             int r = check_coeff(h, tm.coeff, tm.kind == LSM_TERM_ADVECTION ? N : 1);
             if (r) return r;
+            // a catalogued analytic coefficient without time factor gives the same minimum every step
+            const bool cacheable = h->cfl_cache_on && (tm.coeff.kind == LSM_COEFF_ROTATION ||
+                                   (tm.coeff.kind == LSM_COEFF_SEPARABLE && tm.coeff.time_kind == LSM_TIME_ONE));
+            bool hit = false;
+            if (cacheable)
+                for (auto& e : h->cfl_cache)
+                    if (memcmp(&e.first, &tm, sizeof(LsmTerm)) == 0) { dt = e.second; hit = true; break; }
+            if (hit) { best = k == 0 ? dt : jl_min(best, dt); continue; }
             CflArgs a;
             memset(&a, 0, sizeof(a));
             for (int d = 0; d < 3; ++d) {
@@ -407,6 +418,10 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             LSM_HIP(h, hipStreamSynchronize(h->stream));
             dt = h->h_result[0];
+            if (cacheable) {
+                if (h->cfl_cache.size() > 16) h->cfl_cache.clear();
+                h->cfl_cache.emplace_back(tm, dt);
+            }
         }
         best = k == 0 ? dt : jl_min(best, dt);
     }
@@ -492,6 +507,13 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     *vmin = h->h_result[0];
     *vmax = h->h_result[1];
+    return LSM_OK;
+}
+
+int lsm_cfl_cache(LsmHandle* h, int enable) {
+    if (!h) return LSM_ERR_INVALID;
+    h->cfl_cache_on = enable != 0;
+    h->cfl_cache.clear();
     return LSM_OK;
 }
 

@@ -47,6 +47,7 @@ struct StageArgs {
     int adv_scheme;
     CoeffArgs adv, nm, curv;
     const double* s0;  // Eikonal frozen sign (NULL = current-sign mode)
+    unsigned nb[3];    // tiles along x, y (3-D only) and march chunks — set by the launcher
 };
 
 struct GhostArgs {

@@ -369,9 +369,20 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     static_assert(!HAS_Y || TY > 1 || true, "");
     __shared__ double tile[NSLOT * HW];
 
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
+    // own L2.  Remap so that every XCD walks a CONTIGUOUS range of tiles (x fastest, then y, then
+    // march chunk): tiles sharing halo columns/rows then share an L2 (speed only, never correctness).
+    const unsigned ntiles = a.nb[0] * a.nb[1] * a.nb[2];
+    const unsigned per_xcd = (ntiles + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    if (tile_id >= ntiles) return;   // whole workgroup leaves before any barrier
+    const unsigned tbx = tile_id % a.nb[0];
+    const unsigned tby = (tile_id / a.nb[0]) % a.nb[1];
+    const unsigned tbm = tile_id / (a.nb[0] * a.nb[1]);
+
     const int tid = threadIdx.x;
     const int tx = tid % TX, ty = tid / TX;
-    const int bx0 = blockIdx.x * TX, by0 = HAS_Y ? blockIdx.y * TY : 0;
+    const int bx0 = tbx * TX, by0 = HAS_Y ? tby * TY : 0;
     const int gx = bx0 + tx, gy = by0 + ty;
     const int nx = a.n[0], ny = HAS_Y ? a.n[1] : 1;
     const int nm = MARCH ? a.n[NDIM - 1] : 1;
@@ -387,7 +398,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
     const unsigned ocol = 8u * ((unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
-    const int m0 = MARCH ? (NDIM == 3 ? blockIdx.z : blockIdx.y) * MC : 0;
+    const int m0 = MARCH ? (int)tbm * MC : 0;
     const int m1 = MARCH ? (m0 + MC < nm ? m0 + MC : nm) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
@@ -508,13 +519,13 @@ template <int NDIM, int ADV, int NM, int CURV, int EIK>
 void launch_one(const StageArgs& a, hipStream_t s) {
     using T = TileCfg<NDIM>;
     dim3 block(T::TX * T::TY);
-    dim3 grid((a.n[0] + T::TX - 1) / T::TX, 1, 1);
-    if (NDIM == 2) grid.y = (a.n[1] + T::MC - 1) / T::MC;
-    if (NDIM == 3) {
-        grid.y = (a.n[1] + T::TY - 1) / T::TY;
-        grid.z = (a.n[2] + T::MC - 1) / T::MC;
-    }
-    hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, a);
+    StageArgs b = a;
+    b.nb[0] = (a.n[0] + T::TX - 1) / T::TX;
+    b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
+    b.nb[2] = NDIM >= 2 ? (a.n[NDIM - 1] + T::MC - 1) / T::MC : 1;
+    const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
+    dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
+    hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, b);
 }
 
 // the instantiated fused combinations (keep in sync with combo_available in lsm_api.hip)

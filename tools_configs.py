@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Timing of the non-headline BASELINE configs through the host API (GPU box), and a
+FETCH_SIZE calibration run (mode 'calib': kernels with exactly known HBM traffic)."""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+import lsm_amd as lsm
+
+
+def timed(eq, steps, warmup=2):
+    tc = 0.0
+    def one(tc):
+        eq._update_terms(eq.state, tc)
+        dt = eq.integrator.cfl * eq.compute_cfl(tc)
+        eq._advance(tc, dt)
+        return tc + dt
+    for _ in range(warmup):
+        tc = one(tc)
+    eq.backend.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tc = one(tc)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n, ms = eq.backend.profile_read()
+    return el / steps * 1e3, ms / max(n, 1), n // steps
+
+
+def config2(n=2048, steps=20):
+    grid = lsm.CartesianGrid((-1.5, -1.5), (1.5, 1.5), (n, n))
+    ic = lsm.MeshField(lambda x: np.maximum(np.hypot(x[0] + 0.75, x[1]) - 0.5,
+                                            -np.maximum(np.abs(x[0] + 0.75) - 0.1, np.abs(x[1] + 0.25) - 0.5)), grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()),), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    ms, kms, nl = timed(eq, steps)
+    re = lsm.LevelSetEquation(terms=(lsm.EikonalReinitializationTerm(eq.current_state()),), ic=eq.current_state(), bc=lsm.NeumannBC(),
+                              integrator=lsm.RK3())
+    ms2, kms2, nl2 = timed(re, steps)
+    return {"config": f"2D {n}^2 Zalesak", "advect_ms_per_step": ms, "advect_stage_ms": kms, "advect_Mcells_s": n * n / ms / 1e3,
+            "reinit_ms_per_step": ms2, "reinit_stage_ms": kms2, "reinit_Mcells_s": n * n / ms2 / 1e3}
+
+
+def config3(n=512, steps=10):
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    ic = lsm.LazyMeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.1), lsm.CurvatureTerm(-0.1)), ic=ic, bc=lsm.ExtrapolationBC(2), integrator=lsm.RK3())
+    ms, kms, nl = timed(eq, steps)
+    return {"config": f"3D {n}^3 mean-curvature flow (NormalMotion+Curvature)", "ms_per_step": ms, "stage_ms": kms,
+            "Mcells_s": n ** 3 / ms / 1e3, "GBs_algorithmic": n ** 3 * 64 / 3 / kms / 1e6}
+
+
+def calib(n=512):
+    """Known-traffic kernels for the FETCH_SIZE/WRITE_SIZE calibration (run under rocprofv3 --pmc):
+    extrema reads n^3*8 B with 8-byte-per-lane loads; eikonal_sign reads and writes n^3*8 B."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    ic = lsm.LazyMeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.1),), ic=ic, bc=lsm.NeumannBC())
+    b = eq.backend
+    s0 = b.alloc()
+    for _ in range(3):
+        b.extrema(eq.state.buf)
+        b.eikonal_sign(eq.state.buf, s0)
+    torch.cuda.synchronize()
+    return {"calib_bytes_read_each": n ** 3 * 8}
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    out = []
+    if mode in ("all", "2"):
+        out.append(config2())
+    if mode in ("all", "3"):
+        out.append(config3())
+    if mode == "calib":
+        out.append(calib())
+    print(json.dumps(out, indent=1))
