@@ -1,6 +1,7 @@
 // lsm_api.hip — host side of the C ABI declared in include/lsm.h.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -413,8 +414,16 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             int nb = cfl_blocks(N, h->nloc);
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
-            launch_cfl(N, a, nb, h->stream);
-            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, h->stream);
+            static const bool single_env = getenv("LSM_CFL_SINGLE_PASS") != nullptr;   // A/B switch
+            const bool two_pass = !single_env && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
+            if (two_pass) {
+                launch_cfl(N, a, nb, 0, nullptr, h->stream);
+                launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 0, h->stream);
+                launch_cfl(N, a, nb, 1, h->d_result + 1, h->stream);
+            } else {
+                launch_cfl(N, a, nb, 1, nullptr, h->stream);
+            }
+            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 1, h->stream);
             LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             LSM_HIP(h, hipStreamSynchronize(h->stream));
             dt = h->h_result[0];

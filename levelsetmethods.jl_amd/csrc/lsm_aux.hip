@@ -86,29 +86,7 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-template <int NCOMP>
-__device__ __forceinline__ void cfl_coeff(const CoeffArgs& c, const CflArgs& a, int ndim, const int gi[3], long long center,
-                                          double out[3]) {
-    if (c.kind == LSM_COEFF_CONST) {
-        for (int k = 0; k < NCOMP; ++k) out[k] = c.v[k];
-    } else if (c.kind == LSM_COEFF_ROTATION) {
-        const double x1 = a.lc[0] + (double)gi[0] * a.h[0];
-        const double x2 = ndim > 1 ? a.lc[1] + (double)gi[1] * a.h[1] : 0.0;
-        out[0] = -(c.v[0] * (x2 - c.v[2]));
-        if (NCOMP > 1) out[1] = c.v[0] * (x1 - c.v[1]);
-        if (NCOMP > 2) out[2] = 0.0;
-    } else if (c.kind == LSM_COEFF_SEPARABLE) {
-        for (int k = 0; k < NCOMP; ++k) {
-            const double* T = c.sep[k];
-            double p = T[gi[0]];
-            if (ndim > 1) p = p * T[a.gn[0] + gi[1]];
-            if (ndim > 2) p = p * T[a.gn[0] + a.gn[1] + gi[2]];
-            out[k] = p * c.tfac;
-        }
-    } else {
-        for (int k = 0; k < NCOMP; ++k) out[k] = c.f[k][center];
-    }
-}
+#define CFL_MAX_CHUNK 512   // planes per march chunk staged in LDS (launcher keeps chunk <= this)
 
 // Per-node CFL of one term (src/levelsetterms.jl:90-96,123-127,172-178).  The node formulas are
 //   advection 1/Σ_d(|u_d|/h_d),  normal motion 1/Σ_d(|v|/h_d),  curvature Δx²/(2|b|),
@@ -116,71 +94,104 @@ __device__ __forceinline__ void cfl_coeff(const CoeffArgs& c, const CflArgs& a, 
 // (s = Σ|u_d|/h_d, resp. |b|).  Because IEEE division is monotone, min_I f(s_I) == f(max_I s_I)
 // bit for bit, so the kernel reduces max s (plus an any-NaN flag: Julia's min propagates NaN) and
 // the final kernel applies f once.
-__global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
+//
+// The three IEEE divisions per node dominate this kernel (VALU-bound), so analytic coefficients
+// use TWO passes: pass 0 reduces an approximate s~ = Σ|u_d|·(1/h_d) (|s~ - s| <= 1e-15·s); pass 1
+// recomputes s~ and evaluates the exact, division-based s only at nodes with s~ >= (1-1e-13)·max s~.
+// The true arg-max is always among those candidates, so the result is still exact; typically a
+// handful of nodes take the slow branch.  FIELD coefficients (HBM-bound) use the exact pass alone.
+template <int NDIM, int TKIND, int CKIND>
+__global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, const double* thresh_ptr) {
+    constexpr int NCOMP = TKIND == LSM_TERM_ADVECTION ? NDIM : 1;
+    const double thresh = pass == 1 && thresh_ptr ? *thresh_ptr : 0.0;
+    const double ih0 = 1.0 / a.h[0], ih1 = 1.0 / a.h[1], ih2 = 1.0 / a.h[2];
     // one thread per column of the LAST dimension (x fastest across lanes: coalesced FIELD reads);
     // everything that does not depend on the last index is hoisted out of the march.
-    const int nlast = a.n[ndim - 1];
-    const long long ncol = ndim == 1 ? 1 : (ndim == 2 ? a.n[0] : (long long)a.n[0] * a.n[1]);
-    const long long slast = ndim == 1 ? 1 : (ndim == 2 ? a.s1 : a.s2);
-    const int ncomp = a.term_kind == LSM_TERM_ADVECTION ? ndim : 1;
+    const int nlast = a.n[NDIM - 1];
+    const long long ncol = NDIM == 1 ? a.n[0] : (NDIM == 2 ? a.n[0] : (long long)a.n[0] * a.n[1]);
+    const long long slast = NDIM == 1 ? 1 : (NDIM == 2 ? a.s1 : a.s2);
     double best = 0.0;   // s >= 0
     int sawnan = 0;
-    for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < (ndim == 1 ? nlast : ncol);
-         col += (long long)gridDim.x * blockDim.x) {
-        // ndim == 1: the "column" is a single node index along x
-        const int i0 = ndim == 1 ? (int)col : (int)(col % a.n[0]);
-        const int i1 = ndim == 3 ? (int)(col / a.n[0]) : 0;
+    // the march range is split over gridDim.y chunks for occupancy; the march-axis table entries of
+    // the chunk are staged in LDS once (wave-uniform look-ups inside the loop become LDS broadcasts)
+    const int mcount = NDIM == 1 ? 1 : nlast;
+    const int chunk = (mcount + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int mb = (int)blockIdx.y * chunk, me = mb + chunk < mcount ? mb + chunk : mcount;
+    __shared__ double tab[3 * CFL_MAX_CHUNK];
+    const CoeffArgs& c = a.coeff;
+    if constexpr (CKIND == LSM_COEFF_SEPARABLE && NDIM > 1) {
+        const int toff = (NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + a.goff[NDIM - 1];
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k)
+            for (int j = threadIdx.x; j < me - mb; j += blockDim.x) tab[k * CFL_MAX_CHUNK + j] = c.sep[k][toff + mb + j];
+        __syncthreads();
+    }
+    for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < ncol; col += (long long)gridDim.x * blockDim.x) {
+        const int i0 = NDIM == 3 ? (int)(col % a.n[0]) : (int)col;
+        const int i1 = NDIM == 3 ? (int)(col / a.n[0]) : 0;
         const int g0 = i0 + a.goff[0], g1 = i1 + a.goff[1];
-        const long long cbase = a.origin + i0 + (ndim == 3 ? i1 * a.s1 : 0);
+        const long long cbase = a.origin + i0 + (NDIM == 3 ? i1 * a.s1 : 0);
         double pre[3] = {0, 0, 0};
-        const CoeffArgs& c = a.coeff;
-        if (c.kind == LSM_COEFF_SEPARABLE) {
-            for (int k = 0; k < ncomp; ++k) {
+        if constexpr (CKIND == LSM_COEFF_SEPARABLE) {
+#pragma unroll
+            for (int k = 0; k < NCOMP; ++k) {
                 double p = c.sep[k][g0];
-                if (ndim == 3) p = p * c.sep[k][a.gn[0] + g1];
+                if (NDIM == 3) p = p * c.sep[k][a.gn[0] + g1];
                 pre[k] = p;
             }
-        } else if (c.kind == LSM_COEFF_ROTATION) {
+        } else if constexpr (CKIND == LSM_COEFF_ROTATION) {
             const double x1 = a.lc[0] + (double)g0 * a.h[0];
             pre[1] = c.v[0] * (x1 - c.v[1]);
-            if (ndim == 3) pre[0] = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
+            if (NDIM == 3) pre[0] = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
         }
-        // the march range is split over gridDim.y chunks for occupancy
-        const int mcount = ndim == 1 ? 1 : nlast;
-        const int chunk = (mcount + (int)gridDim.y - 1) / (int)gridDim.y;
-        const int mb = (int)blockIdx.y * chunk, me = mb + chunk < mcount ? mb + chunk : mcount;
-#pragma unroll 4
+#pragma unroll 2
         for (int m = mb; m < me; ++m) {
-            const int gm = m + a.goff[ndim - 1];
             double u[3] = {0, 0, 0};
-            if (c.kind == LSM_COEFF_CONST) {
-                for (int k = 0; k < ncomp; ++k) u[k] = c.v[k];
-            } else if (c.kind == LSM_COEFF_SEPARABLE) {
-                for (int k = 0; k < ncomp; ++k) {
+            if constexpr (CKIND == LSM_COEFF_CONST) {
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) u[k] = c.v[k];
+            } else if constexpr (CKIND == LSM_COEFF_SEPARABLE) {
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) {
                     double p = pre[k];
-                    if (ndim > 1) p = p * c.sep[k][(ndim == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gm];
+                    if (NDIM > 1) p = p * tab[k * CFL_MAX_CHUNK + (m - mb)];
                     u[k] = p * c.tfac;
                 }
-            } else if (c.kind == LSM_COEFF_ROTATION) {
-                u[0] = ndim == 2 ? -(c.v[0] * ((a.lc[1] + (double)gm * a.h[1]) - c.v[2])) : pre[0];
+            } else if constexpr (CKIND == LSM_COEFF_ROTATION) {
+                const int gm = m + a.goff[NDIM - 1];
+                u[0] = NDIM == 2 ? -(c.v[0] * ((a.lc[1] + (double)gm * a.h[1]) - c.v[2])) : pre[0];
                 u[1] = pre[1];
             } else {
-                for (int k = 0; k < ncomp; ++k) u[k] = c.f[k][cbase + (ndim == 1 ? 0 : m * slast)];
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) u[k] = c.f[k][cbase + (NDIM == 1 ? 0 : m * slast)];
             }
-            double sv;
-            if (a.term_kind == LSM_TERM_ADVECTION) {
-                sv = __builtin_fabs(u[0]) / a.h[0];
-                if (ndim > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
-                if (ndim > 2) sv = sv + __builtin_fabs(u[2]) / a.h[2];
-            } else if (a.term_kind == LSM_TERM_NORMAL_MOTION) {
-                sv = __builtin_fabs(u[0]) / a.h[0];
-                if (ndim > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
-                if (ndim > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
+            if (u[0] != u[0] || u[1] != u[1] || u[2] != u[2]) sawnan = 1;
+            double sv;   // approximate first
+            if constexpr (TKIND == LSM_TERM_ADVECTION) {
+                sv = __builtin_fabs(u[0]) * ih0;
+                if (NDIM > 1) sv = sv + __builtin_fabs(u[1]) * ih1;
+                if (NDIM > 2) sv = sv + __builtin_fabs(u[2]) * ih2;
+            } else if constexpr (TKIND == LSM_TERM_NORMAL_MOTION) {
+                sv = __builtin_fabs(u[0]) * ih0;
+                if (NDIM > 1) sv = sv + __builtin_fabs(u[0]) * ih1;
+                if (NDIM > 2) sv = sv + __builtin_fabs(u[0]) * ih2;
             } else {
                 sv = __builtin_fabs(u[0]);
             }
-            if (sv != sv) sawnan = 1;
-            else best = sv > best ? sv : best;
+            if (pass == 1 && sv >= thresh) {   // candidate: exact value with the reference's divisions
+                if constexpr (TKIND == LSM_TERM_ADVECTION) {
+                    sv = __builtin_fabs(u[0]) / a.h[0];
+                    if (NDIM > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
+                    if (NDIM > 2) sv = sv + __builtin_fabs(u[2]) / a.h[2];
+                } else if constexpr (TKIND == LSM_TERM_NORMAL_MOTION) {
+                    sv = __builtin_fabs(u[0]) / a.h[0];
+                    if (NDIM > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
+                    if (NDIM > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
+                }
+            } else if (pass == 1) {
+                sv = 0.0;   // not a candidate
+            }
+            if (sv == sv) best = sv > best ? sv : best;
         }
     }
     best = wave_max(best);
@@ -200,7 +211,7 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int ndim) {
 }
 
 __global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, int nblocks, const int* nanflag, double* out,
-                                                        int term_kind, double dxmin) {
+                                                        int term_kind, double dxmin, int pass) {
     double best = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) best = partial[i] > best ? partial[i] : best;
     best = wave_max(best);
@@ -211,25 +222,52 @@ __global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, i
     if (threadIdx.x == 0) {
         double m = smax[0];
         for (int w = 1; w < 4; ++w) m = smax[w] > m ? smax[w] : m;
-        const double cfl = term_kind == LSM_TERM_CURVATURE ? (dxmin * dxmin) / (2 * m) : 1 / m;
-        out[0] = *nanflag ? __builtin_nan("") : cfl;
+        if (pass == 0) {
+            out[1] = m * (1.0 - 1.0e-13);       // candidate threshold for pass 1
+        } else {
+            const double cfl = term_kind == LSM_TERM_CURVATURE ? (dxmin * dxmin) / (2 * m) : 1 / m;
+            out[0] = *nanflag ? __builtin_nan("") : cfl;
+        }
     }
 }
 
-static const int CFL_CHUNKS = 4;
+static int cfl_chunks(int ndim, const int n[3]) {
+    if (ndim == 1) return 1;
+    int c = 4;
+    while ((n[ndim - 1] + c - 1) / c > CFL_MAX_CHUNK) c *= 2;
+    return c;
+}
 int cfl_blocks(int ndim, const int n[3]) {
     const long long cols = ndim == 1 ? n[0] : (ndim == 2 ? n[0] : (long long)n[0] * n[1]);
     const long long b = (cols + 255) / 256;
     const int bx = (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
-    return bx * (ndim == 1 ? 1 : CFL_CHUNKS);   // number of partials
+    return bx * cfl_chunks(ndim, n);   // number of partials
 }
-void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s) {
-    const int chunks = ndim == 1 ? 1 : CFL_CHUNKS;
-    hipLaunchKernelGGL(cfl_kernel, dim3(nblocks / chunks, chunks), dim3(256), 0, s, a, ndim);
+template <int NDIM, int TKIND>
+static void launch_cfl_ck(const CflArgs& a, dim3 grid, int pass, const double* thresh, hipStream_t s) {
+    switch (a.coeff.kind) {
+    case LSM_COEFF_CONST: hipLaunchKernelGGL((cfl_kernel<NDIM, TKIND, LSM_COEFF_CONST>), grid, dim3(256), 0, s, a, pass, thresh); break;
+    case LSM_COEFF_ROTATION: hipLaunchKernelGGL((cfl_kernel<NDIM, TKIND, LSM_COEFF_ROTATION>), grid, dim3(256), 0, s, a, pass, thresh); break;
+    case LSM_COEFF_SEPARABLE: hipLaunchKernelGGL((cfl_kernel<NDIM, TKIND, LSM_COEFF_SEPARABLE>), grid, dim3(256), 0, s, a, pass, thresh); break;
+    default: hipLaunchKernelGGL((cfl_kernel<NDIM, TKIND, LSM_COEFF_FIELD>), grid, dim3(256), 0, s, a, pass, thresh);
+    }
+}
+template <int NDIM>
+static void launch_cfl_nd(const CflArgs& a, dim3 grid, int pass, const double* thresh, hipStream_t s) {
+    if (a.term_kind == LSM_TERM_ADVECTION) launch_cfl_ck<NDIM, LSM_TERM_ADVECTION>(a, grid, pass, thresh, s);
+    else if (a.term_kind == LSM_TERM_NORMAL_MOTION) launch_cfl_ck<NDIM, LSM_TERM_NORMAL_MOTION>(a, grid, pass, thresh, s);
+    else launch_cfl_ck<NDIM, LSM_TERM_CURVATURE>(a, grid, pass, thresh, s);
+}
+void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s) {
+    const int chunks = cfl_chunks(ndim, a.n);
+    const dim3 grid(nblocks / chunks, chunks);
+    if (ndim == 1) launch_cfl_nd<1>(a, grid, pass, thresh, s);
+    else if (ndim == 2) launch_cfl_nd<2>(a, grid, pass, thresh, s);
+    else launch_cfl_nd<3>(a, grid, pass, thresh, s);
 }
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(cfl_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, nanflag, out, term_kind, dxmin);
+                      int pass, hipStream_t s) {
+    hipLaunchKernelGGL(cfl_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, nanflag, out, term_kind, dxmin, pass);
 }
 
 // ---------------------------------------------------------------------------------------------

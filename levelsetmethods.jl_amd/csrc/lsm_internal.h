@@ -89,9 +89,9 @@ bool combo_available(const Combo& c);
 // small kernels (lsm_aux.hip)
 void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s);
 int cfl_blocks(int ndim, const int n[3]);
-void launch_cfl(int ndim, const CflArgs& a, int nblocks, hipStream_t s);
+void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
-                      hipStream_t s);
+                      int pass, hipStream_t s);
 void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const double* v,
                     double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s);
 void launch_eikonal_sign(int ndim, const int n[3], long long s1, long long s2, long long origin, double dxmin,

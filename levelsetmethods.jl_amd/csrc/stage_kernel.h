@@ -468,6 +468,9 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) tile[slot * HW + hl[h]] = ldg(P, hg[h]);
         }
+#ifdef LSM_UNROLL_M
+#pragma unroll LSM_UNROLL_M
+#endif
         for (int m = m0; m < m1; ++m) {
             // issue the next plane's global loads early; they land in LDS after this plane's arithmetic
             const double nxt = ldg(plane(m + 1 + G), ocol);
@@ -510,7 +513,7 @@ struct TileCfg<2> { static constexpr int TX = 256, TY = 1, MC = 32; };
 #define LSM_TY3 8
 #endif
 #ifndef LSM_MC3
-#define LSM_MC3 32
+#define LSM_MC3 64
 #endif
 template <>
 struct TileCfg<3> { static constexpr int TX = LSM_TX3, TY = LSM_TY3, MC = LSM_MC3; };
