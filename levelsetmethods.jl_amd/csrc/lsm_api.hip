@@ -39,6 +39,7 @@ struct LsmHandle {
     double w[3][2][LSM_GHOST][8];
     hipStream_t stream;
     bool own_stream;
+    double* d_w;         // device copy of w
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
     double* d_result;    // 2 doubles
@@ -168,6 +169,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->own_stream = true;
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_partial, sizeof(double) * 2 * MAXB);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_w, sizeof(h->w));
+    if (e == hipSuccess) e = hipMemcpy(h->d_w, h->w, sizeof(h->w), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 2);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 2, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -187,6 +190,7 @@ void lsm_destroy(LsmHandle* h) {
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_flag);
+    (void)hipFree(h->d_w);
     (void)hipFree(h->d_result);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -241,6 +245,24 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
     if (!h || !field) return LSM_ERR_INVALID;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const int N = h->grid.ndim;
+    static const bool per_dim_env = getenv("LSM_GHOST_PER_DIM") != nullptr;   // A/B switch
+    if ((dim_mask & ((1 << N) - 1)) == ((1 << N) - 1) && !per_dim_env) {
+        // all dimensions: one fused launch (bit-identical to the per-dimension passes below)
+        bool lower_none = false;
+        for (int d = 0; d < N - 1; ++d) lower_none |= h->bc[d][0].kind == LSM_BC_NONE || h->bc[d][1].kind == LSM_BC_NONE;
+        if (!lower_none) {
+            GhostAllArgs a;
+            for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
+            a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+            for (int d = 0; d < 3; ++d)
+                for (int sd = 0; sd < 2; ++sd) { a.kind[d][sd] = h->bc[d][sd].kind; a.degree[d][sd] = h->bc[d][sd].degree; }
+            a.w = h->d_w;
+            a.v = (double*)field;
+            launch_ghost_fill_all(N, a, s);
+            LSM_HIP(h, hipGetLastError());
+            return LSM_OK;
+        }
+    }
     for (int d = 0; d < N; ++d) {
         if (!((dim_mask >> d) & 1)) continue;
         if (h->bc[d][0].kind == LSM_BC_NONE && h->bc[d][1].kind == LSM_BC_NONE) continue;

@@ -66,6 +66,99 @@ void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused ghost fill: ALL dimensions in one launch, one thread per ghost node.  A ghost that is out
+// of range in several dimensions evaluates the nested sums of the recursion directly,
+//   ghost = Σ_jz w_jz ( Σ_jy w_jy ( Σ_jx w_jx ϕ[interior] ) ),
+// in exactly the order of _getindexbc (highest dimension outermost, acc = 0; acc += w·value), so
+// the values are bit-identical to three sequential per-dimension passes — but every thread reads
+// interior nodes only, hence no dependency between threads and a single launch.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double ghost_resolve(const GhostAllArgs& a, int I0, int I1, int I2) {
+    if constexpr (D < 0) {
+        return a.v[a.origin + I0 + I1 * a.s1 + I2 * a.s2];
+    } else {
+        const int i = D == 0 ? I0 : (D == 1 ? I1 : I2);
+        const int n = a.n[D];
+        if (i >= 0 && i < n) return ghost_resolve<D - 1>(a, I0, I1, I2);
+        const int side = i < 0 ? 0 : 1;
+        const int k = side == 0 ? -i : i - (n - 1);
+        const int b = side == 0 ? 0 : n - 1;
+        const int dir = side == 0 ? 1 : -1;
+        const int kind = side ? a.kind[D][1] : a.kind[D][0];
+        const int deg = side ? a.degree[D][1] : a.degree[D][0];
+        const double* w = a.w + ((D * 2 + side) * LSM_GHOST + (k - 1)) * 8;
+        auto at = [&](int j) {
+            return D == 0 ? ghost_resolve<D - 1>(a, j, I1, I2) : (D == 1 ? ghost_resolve<D - 1>(a, I0, j, I2) : ghost_resolve<D - 1>(a, I0, I1, j));
+        };
+        double acc = 0.0;
+        if (kind == LSM_BC_PERIODIC) {
+            acc += 1.0 * at(side == 0 ? (n - 1) - k : k);
+        } else if (kind == LSM_BC_EXTRAPOLATION) {
+            for (int j = 0; j <= deg; ++j) acc += w[j] * at(b + dir * j);
+        } else {
+            acc += 1.0 * at(b + dir * k);
+        }
+        return acc;
+    }
+}
+
+template <int NDIM>
+__global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs a) {
+    constexpr int G = LSM_GHOST;
+    const int P0 = a.n[0] + 2 * G, P1 = NDIM > 1 ? a.n[1] + 2 * G : 1;
+    // region sizes: (A) ghosts of the last dim over the full padded lower dims, (B) [3-D only] y ghosts
+    // over padded x and interior z, (C) x ghosts over interior y,z
+    const bool lastL = a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.kind[NDIM - 1][1] != LSM_BC_NONE;
+    const int nlastg = (lastL ? G : 0) + (lastR ? G : 0);
+    long long nA, nB, nC;
+    if (NDIM == 1) { nA = nlastg; nB = 0; nC = 0; }
+    else if (NDIM == 2) { nA = (long long)nlastg * P0; nB = 0; nC = (long long)a.n[1] * 2 * G; }
+    else { nA = (long long)nlastg * P0 * P1; nB = (long long)a.n[2] * 2 * G * P0; nC = (long long)a.n[2] * a.n[1] * 2 * G; }
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nA + nB + nC) return;
+    int I0 = 0, I1 = 0, I2 = 0;
+    auto ghost_index = [&](int g, int n, bool left_on) {   // g-th ghost of a dim: left block first (if present)
+        if (left_on && g < G) return g - G;
+        return n + (g - (left_on ? G : 0));
+    };
+    if (t < nA) {
+        if (NDIM == 1) { I0 = ghost_index((int)t, a.n[0], lastL); }
+        else if (NDIM == 2) { I0 = (int)(t % P0) - G; I1 = ghost_index((int)(t / P0), a.n[1], lastL); }
+        else { I0 = (int)(t % P0) - G; I1 = (int)((t / P0) % P1) - G; I2 = ghost_index((int)(t / ((long long)P0 * P1)), a.n[2], lastL); }
+    } else if (t < nA + nB) {   // 3-D only
+        const long long u = t - nA;
+        I0 = (int)(u % P0) - G;
+        const int g = (int)((u / P0) % (2 * G));
+        I1 = g < G ? g - G : a.n[1] + (g - G);
+        I2 = (int)(u / ((long long)P0 * 2 * G));
+    } else {
+        const long long u = t - nA - nB;
+        const int g = (int)(u % (2 * G));
+        I0 = g < G ? g - G : a.n[0] + (g - G);
+        if (NDIM == 2) { I1 = (int)(u / (2 * G)); }
+        else { I1 = (int)((u / (2 * G)) % a.n[1]); I2 = (int)(u / ((long long)2 * G * a.n[1])); }
+    }
+    const double val = ghost_resolve<NDIM - 1>(a, I0, I1, I2);
+    a.v[a.origin + I0 + I1 * a.s1 + I2 * a.s2] = val;
+}
+
+void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
+    const int G = LSM_GHOST;
+    const long long P0 = a.n[0] + 2 * G, P1 = ndim > 1 ? a.n[1] + 2 * G : 1;
+    const int nlastg = (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0);
+    long long total;
+    if (ndim == 1) total = nlastg;
+    else if (ndim == 2) total = nlastg * P0 + (long long)a.n[1] * 2 * G;
+    else total = nlastg * P0 * P1 + (long long)a.n[2] * 2 * G * P0 + (long long)a.n[2] * a.n[1] * 2 * G;
+    if (total <= 0) return;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (ndim == 1) hipLaunchKernelGGL(ghost_fill_all_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    else if (ndim == 2) hipLaunchKernelGGL(ghost_fill_all_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ghost_fill_all_kernel<3>, dim3(grid), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
 // NaN-propagating min reduction helpers (Julia's min(x, NaN) = NaN, src/levelsetterms.jl:31-38).
 // The minimum over non-NaN values and an "any NaN" flag are reduced separately.
 // ---------------------------------------------------------------------------------------------

@@ -60,6 +60,16 @@ struct GhostArgs {
     double* v;
 };
 
+// all dimensions at once (fused ghost fill)
+struct GhostAllArgs {
+    int n[3];
+    long long s1, s2, origin;
+    int kind[3][2];
+    int degree[3][2];
+    const double* w;   // device copy of the Lagrange weights [3][2][LSM_GHOST][8] (no dynamic kernarg indexing)
+    double* v;
+};
+
 struct CflArgs {
     int n[3];
     int goff[3];
@@ -88,6 +98,7 @@ bool combo_available(const Combo& c);
 
 // small kernels (lsm_aux.hip)
 void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s);
+void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s);
 int cfl_blocks(int ndim, const int n[3]);
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
