@@ -21,6 +21,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this pool (see task notes)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -112,6 +113,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # multi-GPU self-check (outside the timed region): one step with the exchange overlapped behind the
+    # interior update must equal one step with the plain stage -> halo sequence BIT FOR BIT; otherwise
+    # fall back to the plain sequence and say so.
+    overlap_note = "n/a"
+    if world > 1:
+        overlap_note = "off"
+        if eq.overlap:
+            keep = eq.state.buf.clone()
+            eq.overlap = True
+            one_step(eq, 0.0)
+            a_res = eq.state.buf.clone()
+            eq.state.buf.copy_(keep)
+            eq.state.ghosts_dirty = True
+            eq.overlap = False
+            one_step(eq, 0.0)
+            same = torch.tensor([1.0 if torch.equal(a_res, eq.state.buf) else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            eq.state.buf.copy_(keep)
+            eq.state.ghosts_dirty = True
+            eq.overlap = bool(same.item() == 1.0)
+            overlap_note = "on (self-check passed)" if eq.overlap else "off (self-check mismatch)"
+            del keep, a_res
+
     tc = 0.0
     for _ in range(args.warmup):
         tc = one_step(eq, tc)
@@ -151,7 +175,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "grid": list(n), "cells": cells, "integrator": "RK3", "cfl": 0.5,
-                   "arithmetic_mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single"},
+                   "arithmetic_mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single",
+                   "halo_overlap": overlap_note},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "stage_kernel<3,WENO5 adv,Eikonal> (fused RK3 stage)",

@@ -157,6 +157,15 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream);
 int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin,
               void* out, void* out2, int base_mode, double cdt, double cdt2, double t_stage, void* stream);
 
+/* The same two calls restricted to planes [m_begin, m_end) of the LAST dimension, so a slab can
+ * update and ghost-fill its boundary planes first, start the halo exchange, and update the interior
+ * while the planes travel (ndim >= 2).  lsm_fill_ghosts_planes fills the ghosts of dimensions
+ * 1..N-1 on those planes and, if fill_last != 0, the physical (non-NONE) ghost planes of dimension N. */
+int lsm_stage_planes(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin,
+                     void* out, void* out2, int base_mode, double cdt, double cdt2, double t_stage,
+                     int64_t m_begin, int64_t m_end, void* stream);
+int lsm_fill_ghosts_planes(LsmHandle* h, void* field, int64_t m_begin, int64_t m_end, int fill_last, void* stream);
+
 /* ---- compute_cfl (src/levelsetterms.jl:22-38,90-96,123-127,172-178,250).  *dt_out is the raw
  *      minimum (Inf, NaN and <=0 possible): the CALLER raises the reference's ArgumentError. */
 int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, double t, double* dt_out);

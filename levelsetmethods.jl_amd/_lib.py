@@ -70,6 +70,9 @@ _SIGS = [
     ("lsm_fill_ghosts", C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     ("lsm_stage", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                             C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    ("lsm_stage_planes", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_void_p]),
+    ("lsm_fill_ghosts_planes", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("lsm_compute_cfl", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_double)]),
     ("lsm_cfl_cache", C.c_int, [_H, C.c_int]),
     ("lsm_advance_fe", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double,

@@ -252,6 +252,7 @@ class ROCMeshField:
     def __init__(self, backend, mesh, bcs, buf=None):
         self.backend, self.mesh, self.bcs = backend, mesh, bcs
         self.buf = backend.alloc() if buf is None else buf
+        self.ghosts_dirty = True    # set whenever the interior is rewritten from outside a step
 
     @classmethod
     def from_host(cls, backend, mf, bcs=None, local=None):
@@ -278,6 +279,7 @@ class ROCMeshField:
             self.backend.copy_(self.buf, src.buf)
         else:
             self.backend.upload(self.buf, src.vals if isinstance(src, MeshField) else src)
+        self.ghosts_dirty = True
         return self
 
     def extrema(self):
@@ -583,6 +585,8 @@ class LevelSetEquation:
             term._bind(grid, self.backend, self.slab)
         self._bufs = None
         self._hook_keep = None
+        import os as _os
+        self.overlap = _os.environ.get("LSM_SLAB_OVERLAP", "1") != "0"   # boundary-first stages overlapping the halo exchange
         if any(t.update_func is not None for t in terms) and hasattr(self.backend, "cfl_cache"):
             self.backend.cfl_cache(False)   # hooks may mutate coefficients in place
 
@@ -667,40 +671,65 @@ class LevelSetEquation:
             return
         # slab mode: stage by stage with ghost-plane exchange between stages
         fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)
-        self._halo(phi)
+        if self.state.ghosts_dirty:
+            self._halo(phi)
+            self.state.ghosts_dirty = False
+        T = lambda: _terms_c(self.terms)
         if name == "fe":
             self._update_terms(self.state, tc)
-            b.stage(_terms_c(self.terms), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
-            b.copy_(phi, b1)
-            self._halo(phi)
+            self._stage_slab(T(), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            b.copy_(phi, b1)                       # copy!(ϕ, dst): ghosts travel with the padded buffer
         elif name == "rk2":
             self._update_terms(self.state, tc)
-            b.stage(_terms_c(self.terms), n, phi, None, b1, b2, L.BASE_PSI, dt, 0.5 * dt, tc)
-            self._halo(b1)
+            self._stage_slab(T(), n, phi, None, b1, b2, L.BASE_PSI, dt, 0.5 * dt, tc)
             self._update_terms(fld(b1), tc + dt)
-            b.stage(_terms_c(self.terms), n, b1, b2, phi, None, L.BASE_OTHER, 0.5 * dt, 0.0, tc + dt)
-            self._halo(phi)
+            self._stage_slab(T(), n, b1, b2, phi, None, L.BASE_OTHER, 0.5 * dt, 0.0, tc + dt)
         else:
             self._update_terms(self.state, tc)
-            b.stage(_terms_c(self.terms), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
-            self._halo(b1)
+            self._stage_slab(T(), n, phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
             self._update_terms(fld(b1), tc + dt)
-            b.stage(_terms_c(self.terms), n, b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
-            self._halo(b2)
+            self._stage_slab(T(), n, b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
             self._update_terms(fld(b2), tc + 0.5 * dt)
-            b.stage(_terms_c(self.terms), n, b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
-            self._halo(phi)
+            self._stage_slab(T(), n, b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
+
+    def _stage_slab(self, arr, n, psi, phin, out, out2, mode, cdt, cdt2, t):
+        """One stage of a slab followed by its ghost resolution.  With overlap, the G+1 planes next to
+        each slab interface are updated and ghost-filled first, their exchange is started, and the
+        interior is updated while the planes travel over xGMI (the results are identical: every node is
+        computed by the same kernel from the same inputs)."""
+        b = self.backend
+        N = self.mesh_.ndim
+        nloc = int(b.lay.n[N - 1])
+        B = L.GHOST + 1                      # +1: the periodic wrap sends planes shifted by one node
+        if not (self.overlap and self.world > 1 and N >= 2 and nloc >= 2 * B + 1 and hasattr(b, "stage_planes")):
+            b.stage(arr, n, psi, phin, out, out2, mode, cdt, cdt2, t)
+            self._halo(out)
+            return
+        for m0, m1 in ((0, B), (nloc - B, nloc)):
+            b.stage_planes(arr, n, psi, phin, out, out2, mode, cdt, cdt2, t, m0, m1)
+            b.fill_ghosts_planes(out, m0, m1)
+        reqs = self._exchange_start(out)
+        b.stage_planes(arr, n, psi, phin, out, out2, mode, cdt, cdt2, t, B, nloc - B)
+        b.fill_ghosts_planes(out, B, nloc - B)
+        for w in reqs:
+            w.wait()
+        b.fill_ghosts(out, 1 << (N - 1))     # physical BC ghost planes of the end ranks (slab interfaces are skipped)
 
     def _halo(self, buf):
         """Ghost resolution for a slab: BC fill of every dimension (slab interfaces are skipped by
         the library), then exchange of LSM_GHOST full padded planes with the neighbouring ranks.
         Because the exchanged planes carry their own dim-1..N-1 ghosts, the corner composition of
         _getindexbc (src/meshfield.jl:248-260) is preserved."""
+        self.backend.fill_ghosts(buf, 7)
+        for w in self._exchange_start(buf):
+            w.wait()
+
+    def _exchange_start(self, buf):
+        """Post the ghost-plane sends/receives of one field; returns the pending works."""
         import torch.distributed as dist
-        b = self.backend
-        b.fill_ghosts(buf, 7)
         if self.world == 1:
-            return
+            return []
+        b = self.backend
         N = self.mesh_.ndim
         G = L.GHOST
         sl = int(b.lay.stride[N - 1])          # elements per padded plane
@@ -725,9 +754,7 @@ class LevelSetEquation:
             ops.append(dist.P2POp(dist.isend, plane(s0, s0 + G), dn, group=self.comm))
         if up is not None:
             ops.append(dist.P2POp(dist.irecv, plane(nloc, nloc + G), up, group=self.comm))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def gather_state(self):
         """Full-grid host copy of the state on every rank (tests / diagnostics)."""

@@ -95,6 +95,14 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_stage(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out),
                                            self.ptr(out2), base_mode, cdt, cdt2, t, None), "lsm_stage")
 
+    def stage_planes(self, terms_c, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, m0, m1):
+        L.check(self.h, self.lib.lsm_stage_planes(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out),
+                                                  self.ptr(out2), base_mode, cdt, cdt2, t, m0, m1, None), "lsm_stage_planes")
+
+    def fill_ghosts_planes(self, t, m0, m1, fill_last=False):
+        L.check(self.h, self.lib.lsm_fill_ghosts_planes(self.h, self.ptr(t), m0, m1, 1 if fill_last else 0, None),
+                "lsm_fill_ghosts_planes")
+
     def compute_cfl_local(self, terms_c, nterms, phi, t):
         dt = C.c_double(0.0)
         L.check(self.h, self.lib.lsm_compute_cfl(self.h, terms_c, nterms, self.ptr(phi), t, C.byref(dt)), "lsm_compute_cfl")

@@ -241,28 +241,28 @@ int lsm_download(LsmHandle* h, const void* dev_padded, void* host_dense) {
     return copy_interior(h, (void*)dev_padded, host_dense, false);
 }
 
+static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s) {
+    const int N = h->grid.ndim;
+    GhostAllArgs a;
+    for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
+    a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+    for (int d = 0; d < 3; ++d)
+        for (int sd = 0; sd < 2; ++sd) { a.kind[d][sd] = h->bc[d][sd].kind; a.degree[d][sd] = h->bc[d][sd].degree; }
+    a.w = h->d_w;
+    a.v = (double*)field;
+    a.mb = mb; a.me = me; a.fill_last = fill_last;
+    launch_ghost_fill_all(N, a, s);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
 int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
     if (!h || !field) return LSM_ERR_INVALID;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const int N = h->grid.ndim;
     static const bool per_dim_env = getenv("LSM_GHOST_PER_DIM") != nullptr;   // A/B switch
-    if ((dim_mask & ((1 << N) - 1)) == ((1 << N) - 1) && !per_dim_env) {
-        // all dimensions: one fused launch (bit-identical to the per-dimension passes below)
-        bool lower_none = false;
-        for (int d = 0; d < N - 1; ++d) lower_none |= h->bc[d][0].kind == LSM_BC_NONE || h->bc[d][1].kind == LSM_BC_NONE;
-        if (!lower_none) {
-            GhostAllArgs a;
-            for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
-            a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
-            for (int d = 0; d < 3; ++d)
-                for (int sd = 0; sd < 2; ++sd) { a.kind[d][sd] = h->bc[d][sd].kind; a.degree[d][sd] = h->bc[d][sd].degree; }
-            a.w = h->d_w;
-            a.v = (double*)field;
-            launch_ghost_fill_all(N, a, s);
-            LSM_HIP(h, hipGetLastError());
-            return LSM_OK;
-        }
-    }
+    if ((dim_mask & ((1 << N) - 1)) == ((1 << N) - 1) && !per_dim_env)
+        return fill_ghosts_fused(h, field, 0, h->nloc[N - 1], 1, s);   // one launch, bit-identical to the passes below
     for (int d = 0; d < N; ++d) {
         if (!((dim_mask >> d) & 1)) continue;
         if (h->bc[d][0].kind == LSM_BC_NONE && h->bc[d][1].kind == LSM_BC_NONE) continue;
@@ -277,6 +277,13 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
     }
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
+}
+
+int lsm_fill_ghosts_planes(LsmHandle* h, void* field, int64_t m_begin, int64_t m_end, int fill_last, void* stream) {
+    if (!h || !field) return LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    if (m_begin < 0 || m_end > h->nloc[N - 1] || m_begin > m_end) return fail(h, LSM_ERR_INVALID, "lsm_fill_ghosts_planes: bad plane range");
+    return fill_ghosts_fused(h, field, (int)m_begin, (int)m_end, fill_last, stream ? (hipStream_t)stream : h->stream);
 }
 
 static void fill_coeff(const LsmCoeff& c, double t, CoeffArgs& o) {
@@ -322,8 +329,8 @@ static int profile_pair(LsmHandle* h, hipEvent_t* a, hipEvent_t* b) {
     return LSM_OK;
 }
 
-int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
-              int base_mode, double cdt, double cdt2, double t_stage, void* stream) {
+static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+                      int base_mode, double cdt, double cdt2, double t_stage, int mb, int me, void* stream) {
     if (!h || !terms || !psi || !out) return h ? fail(h, LSM_ERR_INVALID, "lsm_stage: null argument") : LSM_ERR_INVALID;
     if (nterms < 1 || nterms > LSM_MAX_TERMS) return fail(h, LSM_ERR_INVALID, "lsm_stage: nterms must be in 1..8");
     if (base_mode != LSM_BASE_PSI && !phin) return fail(h, LSM_ERR_INVALID, "lsm_stage: phin required for this base mode");
@@ -367,6 +374,7 @@ int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, c
         a.out = (double*)out;
         a.out2 = (double*)out2;
         a.cdt = cdt; a.cdt2 = cdt2;
+        a.mb = mb; a.me = me;
         if (first) { a.base_mode = base_mode; a.phin = (const double*)phin; a.out2_accum = 0; }
         else       { a.base_mode = LSM_BASE_OTHER; a.phin = (const double*)out; a.out2_accum = 1; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -382,6 +390,22 @@ int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, c
     }
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
+}
+
+int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+              int base_mode, double cdt, double cdt2, double t_stage, void* stream) {
+    if (!h) return LSM_ERR_INVALID;
+    return stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, 0, h->nloc[h->grid.ndim - 1], stream);
+}
+
+int lsm_stage_planes(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+                     int base_mode, double cdt, double cdt2, double t_stage, int64_t m_begin, int64_t m_end, void* stream) {
+    if (!h) return LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    if (N < 2) return fail(h, LSM_ERR_INVALID, "lsm_stage_planes: needs ndim >= 2");
+    if (m_begin < 0 || m_end > h->nloc[N - 1] || m_begin > m_end) return fail(h, LSM_ERR_INVALID, "lsm_stage_planes: bad plane range");
+    if (m_begin == m_end) return LSM_OK;
+    return stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, (int)m_begin, (int)m_end, stream);
 }
 
 // Julia's min: NaN-propagating

@@ -109,12 +109,13 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     const int P0 = a.n[0] + 2 * G, P1 = NDIM > 1 ? a.n[1] + 2 * G : 1;
     // region sizes: (A) ghosts of the last dim over the full padded lower dims, (B) [3-D only] y ghosts
     // over padded x and interior z, (C) x ghosts over interior y,z
-    const bool lastL = a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.kind[NDIM - 1][1] != LSM_BC_NONE;
+    const bool lastL = a.fill_last && a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.fill_last && a.kind[NDIM - 1][1] != LSM_BC_NONE;
     const int nlastg = (lastL ? G : 0) + (lastR ? G : 0);
+    const int np = a.me - a.mb;   // planes (rows in 2-D) of the last dimension handled by regions B and C
     long long nA, nB, nC;
     if (NDIM == 1) { nA = nlastg; nB = 0; nC = 0; }
-    else if (NDIM == 2) { nA = (long long)nlastg * P0; nB = 0; nC = (long long)a.n[1] * 2 * G; }
-    else { nA = (long long)nlastg * P0 * P1; nB = (long long)a.n[2] * 2 * G * P0; nC = (long long)a.n[2] * a.n[1] * 2 * G; }
+    else if (NDIM == 2) { nA = (long long)nlastg * P0; nB = 0; nC = (long long)np * 2 * G; }
+    else { nA = (long long)nlastg * P0 * P1; nB = (long long)np * 2 * G * P0; nC = (long long)np * a.n[1] * 2 * G; }
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nA + nB + nC) return;
     int I0 = 0, I1 = 0, I2 = 0;
@@ -131,13 +132,13 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
         I0 = (int)(u % P0) - G;
         const int g = (int)((u / P0) % (2 * G));
         I1 = g < G ? g - G : a.n[1] + (g - G);
-        I2 = (int)(u / ((long long)P0 * 2 * G));
+        I2 = a.mb + (int)(u / ((long long)P0 * 2 * G));
     } else {
         const long long u = t - nA - nB;
         const int g = (int)(u % (2 * G));
         I0 = g < G ? g - G : a.n[0] + (g - G);
-        if (NDIM == 2) { I1 = (int)(u / (2 * G)); }
-        else { I1 = (int)((u / (2 * G)) % a.n[1]); I2 = (int)(u / ((long long)2 * G * a.n[1])); }
+        if (NDIM == 2) { I1 = a.mb + (int)(u / (2 * G)); }
+        else { I1 = (int)((u / (2 * G)) % a.n[1]); I2 = a.mb + (int)(u / ((long long)2 * G * a.n[1])); }
     }
     const double val = ghost_resolve<NDIM - 1>(a, I0, I1, I2);
     a.v[a.origin + I0 + I1 * a.s1 + I2 * a.s2] = val;
@@ -146,11 +147,12 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
 void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const int G = LSM_GHOST;
     const long long P0 = a.n[0] + 2 * G, P1 = ndim > 1 ? a.n[1] + 2 * G : 1;
-    const int nlastg = (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0);
+    const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
+    const long long np = a.me - a.mb;
     long long total;
     if (ndim == 1) total = nlastg;
-    else if (ndim == 2) total = nlastg * P0 + (long long)a.n[1] * 2 * G;
-    else total = nlastg * P0 * P1 + (long long)a.n[2] * 2 * G * P0 + (long long)a.n[2] * a.n[1] * 2 * G;
+    else if (ndim == 2) total = nlastg * P0 + np * 2 * G;
+    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * 2 * G;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (ndim == 1) hipLaunchKernelGGL(ghost_fill_all_kernel<1>, dim3(grid), dim3(256), 0, s, a);

@@ -48,6 +48,7 @@ struct StageArgs {
     CoeffArgs adv, nm, curv;
     const double* s0;  // Eikonal frozen sign (NULL = current-sign mode)
     unsigned nb[3];    // tiles along x, y (3-D only) and march chunks — set by the launcher
+    int mb, me;        // range [mb, me) of the march (last) dimension to update
 };
 
 struct GhostArgs {
@@ -68,6 +69,8 @@ struct GhostAllArgs {
     int degree[3][2];
     const double* w;   // device copy of the Lagrange weights [3][2][LSM_GHOST][8] (no dynamic kernarg indexing)
     double* v;
+    int mb, me;        // planes [mb, me) of the last dimension whose lower-dimension ghosts are filled
+    int fill_last;     // also fill the (physical) ghosts of the last dimension
 };
 
 struct CflArgs {

@@ -398,8 +398,8 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
     const unsigned ocol = 8u * ((unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
-    const int m0 = MARCH ? (int)tbm * MC : 0;
-    const int m1 = MARCH ? (m0 + MC < nm ? m0 + MC : nm) : 1;
+    const int m0 = MARCH ? a.mb + (int)tbm * MC : 0;
+    const int m1 = MARCH ? (m0 + MC < a.me ? m0 + MC : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
     auto plane = [&](int p) { return a.psi + (corner + (long long)clampM(p) * sm); };
@@ -525,7 +525,8 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     StageArgs b = a;
     b.nb[0] = (a.n[0] + T::TX - 1) / T::TX;
     b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
-    b.nb[2] = NDIM >= 2 ? (a.n[NDIM - 1] + T::MC - 1) / T::MC : 1;
+    b.nb[2] = NDIM >= 2 ? (a.me - a.mb + T::MC - 1) / T::MC : 1;
+    if (NDIM >= 2 && a.me <= a.mb) return;
     const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
     hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, b);

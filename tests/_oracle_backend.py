@@ -73,6 +73,21 @@ class OracleBackend:
         orc.lib().orc_stage_padded(C.byref(self.grid.c), self.bc, slab, C.byref(self.lay), self._terms(terms_c, nterms), nterms,
                                    self._dp(psi), self._dp(phin), self._dp(out), self._dp(out2), base_mode, cdt, cdt2, t)
 
+    def stage_planes(self, terms_c, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, m0, m1):
+        """Plane-restricted stage: evaluate the whole stage into scratch, keep planes [m0, m1)."""
+        tmp = out.clone()
+        tmp2 = out2.clone() if out2 is not None else None
+        self.stage(terms_c, nterms, psi, phin if phin is not out else tmp, tmp, tmp2, base_mode, cdt, cdt2, t)
+        g = orc.GHOST
+        sl = int(self.lay.stride[self.ndim - 1])
+        out[(m0 + g) * sl:(m1 + g) * sl] = tmp[(m0 + g) * sl:(m1 + g) * sl]
+        if out2 is not None:
+            out2[(m0 + g) * sl:(m1 + g) * sl] = tmp2[(m0 + g) * sl:(m1 + g) * sl]
+
+    def fill_ghosts_planes(self, t, m0, m1, fill_last=False):
+        # lower-dimension ghosts of every plane (idempotent; planes updated later are refilled later)
+        self.fill_ghosts(t, mask=((1 << (self.ndim - 1)) - 1) | ((1 << (self.ndim - 1)) if fill_last else 0))
+
     def compute_cfl_local(self, terms_c, nterms, phi, t):
         slab = C.byref(orc.LsmSlab(*self.slab)) if self.slab is not None else None
         return orc.lib().orc_cfl_padded(C.byref(self.grid.c), self.bc, slab, C.byref(self.lay), self._terms(terms_c, nterms),

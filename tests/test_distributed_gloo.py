@@ -25,11 +25,11 @@ def _free_port():
 
 CASES = {
     # name: (shape, lc, hc, bc, integrator, terms, nsteps)
-    "3d_neumann_rk3": ((14, 12, 17), "neumann", "rk3", "adv+eik"),
-    "3d_periodic_rk3": ((12, 10, 16), "periodic", "rk3", "adv+eik"),
+    "3d_neumann_rk3": ((14, 12, 19), "neumann", "rk3", "adv+eik"),      # 10 + 9 planes: overlapped stages on both ranks
+    "3d_periodic_rk3": ((12, 10, 20), "periodic", "rk3", "adv+eik"),    # 2 ranks: overlapped; 3 ranks: 7+7+6, plain path
     "3d_mixed_rk2": ((10, 9, 13), "mixed", "rk2", "nm+curv"),
-    "2d_periodic_fe": ((20, 15), "periodic", "fe", "adv"),
-    "2d_extrap_rk3": ((18, 14), "extrap2", "rk3", "all"),
+    "2d_periodic_fe": ((20, 19), "periodic", "fe", "adv"),
+    "2d_extrap_rk3": ((18, 21), "extrap2", "rk3", "all"),
 }
 
 

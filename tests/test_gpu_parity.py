@@ -282,3 +282,28 @@ def test_errors_are_reported_not_thrown(hip):
         c.be.stage(arr, 1, t, None, t, None, 0, 1e-3, 0.0, 0.0)   # out aliases psi
     with pytest.raises(L.LsmError):
         c.be.stage(arr, 1, t, None, c.be.alloc(), None, 1, 1e-3, 0.0, 0.0)   # RK3_S2 without phin
+
+
+@pytest.mark.parametrize("shape,bcspec", [((40, 33), "periodic"), ((21, 19, 23), ("extrapolation", 2))])
+def test_plane_range_stages_compose_to_the_full_stage(hip, orc, shape, bcspec):
+    """lsm_stage_planes / lsm_fill_ghosts_planes (used to overlap the halo exchange): boundary planes
+    first, interior afterwards == one full stage + full ghost fill, bit for bit."""
+    nd = len(shape)
+    c = hip.Case(shape, bcspec, mode="fast")
+    phi = _rand_field(shape, 21)
+    specs = _fix_specs(FUSED["all4_multipass"], nd, phi)
+    _, arr = c.terms(specs)
+    psi = c.to_dev(c.pad(phi))
+    phin = c.to_dev(c.pad(np.asfortranarray(0.9 * phi)))
+    full, part = c.be.alloc(), c.be.alloc()
+    args = (2, 1.3e-3, 0.0, 0.25)
+    c.be.stage(arr, len(specs), psi, phin, full, None, *args)
+    c.be.fill_ghosts(full)
+    n, B = shape[-1], 4
+    for m0, m1 in ((0, B), (n - B, n)):
+        c.be.stage_planes(arr, len(specs), psi, phin, part, None, *args, m0, m1)
+        c.be.fill_ghosts_planes(part, m0, m1)
+    c.be.stage_planes(arr, len(specs), psi, phin, part, None, *args, B, n - B)
+    c.be.fill_ghosts_planes(part, B, n - B)
+    c.be.fill_ghosts(part, 1 << (nd - 1))
+    assert np.array_equal(c.to_host(part), c.to_host(full))
