@@ -159,7 +159,9 @@ def main():
     local_cells = cells // world
     bytes_per_launch = local_cells * 64.0 / 3.0
     avg_launch_s = stage_ms / max(1, n_launch) * 1e-3
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if n_launch else 0.0
+    # = bytes_per_launch / avg launch duration at N = 1 (3 launches per step); in slab mode a stage is
+    # split into boundary + interior launches, so use the step's bytes over the step's stage time
+    achieved = local_cells * 64.0 * args.steps / (stage_ms * 1e-3) / 1e9 if n_launch else 0.0
     # fp64 VALU view of the same kernel (the binding resource): ≈1.0 kflop/node-stage
     out = {
         "metric": "Mcells/s per RK3 step (WENO5 advect+reinit), 512^3 fp64; HBM GB/s vs peak",

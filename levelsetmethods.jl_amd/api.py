@@ -701,7 +701,8 @@ class LevelSetEquation:
         N = self.mesh_.ndim
         nloc = int(b.lay.n[N - 1])
         B = L.GHOST + 1                      # +1: the periodic wrap sends planes shifted by one node
-        if not (self.overlap and self.world > 1 and N >= 2 and nloc >= 2 * B + 1 and hasattr(b, "stage_planes")):
+        if not (self.overlap and (self.world > 1 or getattr(self, "_force_overlap", False)) and N >= 2 and nloc >= 2 * B + 1
+                and hasattr(b, "stage_planes")):
             b.stage(arr, n, psi, phin, out, out2, mode, cdt, cdt2, t)
             self._halo(out)
             return

@@ -144,3 +144,33 @@ def test_state_is_a_copy_and_hooks_can_mutate(lsm):
     lsm.integrate_(one, last)
     # with the state reset before every step, the final state is ONE step of size `last` from ic
     assert np.allclose(eq.current_state().values(), one.current_state().values(), atol=1e-12)
+
+
+def test_slab_code_path_on_one_gpu_matches_single_device_path(lsm):
+    """The slab driver (stage-by-stage with lsm_stage_planes / lsm_fill_ghosts_planes, RCCL group of
+    one rank) must reproduce lsm_advance_rk3 bit for bit — with and without the boundary-first split."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (40, 36, 44))
+        ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+        mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()),
+                                                      lsm.EikonalReinitializationTerm()), ic=ic, bc=lsm.NeumannBC(),
+                                               integrator=lsm.RK3(), **kw)
+        ref = mk()
+        lsm.integrate_(ref, 0.02)
+        want = ref.current_state().values()
+        for force in (False, True):
+            eq = mk(comm=dist.group.WORLD)
+            eq._force_overlap = force
+            lsm.integrate_(eq, 0.02)
+            assert np.array_equal(eq.gather_state(), want), force
+    finally:
+        if created:
+            dist.destroy_process_group()
