@@ -505,7 +505,13 @@ struct TileCfg;
 template <>
 struct TileCfg<1> { static constexpr int TX = 256, TY = 1, MC = 1; };
 template <>
-struct TileCfg<2> { static constexpr int TX = 256, TY = 1, MC = 32; };
+#ifndef LSM_TX2
+#define LSM_TX2 256
+#endif
+#ifndef LSM_MC2
+#define LSM_MC2 8
+#endif
+struct TileCfg<2> { static constexpr int TX = LSM_TX2, TY = 1, MC = LSM_MC2; };
 #ifndef LSM_TX3
 #define LSM_TX3 32
 #endif
