@@ -191,6 +191,13 @@ int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream)
 /* ---- min/max of the interior, for show (src/meshfield.jl:300-303) ---- */
 int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax);
 
+/* ---- volume(ϕ) = prod(h)·Σ H(-ϕ) and perimeter(ϕ) = prod(h)·Σ δ(ϕ)‖∇ϕ‖ with the smoothed Heaviside /
+ *      Dirac delta of width min(h) (src/levelsetops.jl:27-33,139-149,171-183) over the local slab;
+ *      the usual posthook diagnostics.  lsm_perimeter refills phi's ghost layers (centred gradient).
+ *      Synchronous. */
+int lsm_volume(LsmHandle* h, const void* phi, double* out);
+int lsm_perimeter(LsmHandle* h, void* phi, double* out);
+
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
 int lsm_profile_enable(LsmHandle* h, int on);
 int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total);   /* synchronises; resets */

@@ -10,12 +10,13 @@ from ._lib import LsmError, build
 from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm, EikonalReinitializationTerm,
                   ExtrapolationBC, ForwardEuler, LazyMeshField, LevelSetEquation, LevelSetTerm, LinearExtrapolationBC, MeshField,
                   NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField, SeparableCoefficient,
-                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, integrate_, vortex_deformation)
+                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, integrate_, perimeter, volume,
+                  vortex_deformation)
 
 __all__ = [
     "AdvectionTerm", "BoundaryCondition", "CartesianGrid", "CurvatureTerm", "EikonalReinitializationTerm",
     "ExtrapolationBC", "ForwardEuler", "LazyMeshField", "LevelSetEquation", "LevelSetTerm", "LinearExtrapolationBC", "MeshField",
     "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3", "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
-    "integrate_", "vortex_deformation", "LsmError", "build",
+    "integrate_", "vortex_deformation", "volume", "perimeter", "LsmError", "build",
 ]

@@ -285,6 +285,22 @@ class ROCMeshField:
     def extrema(self):
         return self.backend.extrema(self.buf)
 
+    def _offset(self, I):
+        I = tuple(I) if not isinstance(I, int) else (I,)
+        lay = self.backend.lay
+        if not all(0 <= I[d] < int(lay.n[d]) for d in range(len(I))):
+            raise IndexError(f"index {I} is outside the (local) grid; ghost values are resolved inside the kernels")
+        return int(lay.origin) + sum(int(I[d]) * int(lay.stride[d]) for d in range(len(I)))
+
+    def __getitem__(self, I):
+        """ϕ[I] (0-based, in-grid): scalar device read — slow, for tests and hooks (src/meshfield.jl:213-217)."""
+        return float(self.buf[self._offset(I)].item())
+
+    def __setitem__(self, I, val):
+        """ϕ[I] = v (src/meshfield.jl:263-266): scalar device write; marks the ghost layers stale."""
+        self.buf[self._offset(I)] = float(val)
+        self.ghosts_dirty = True
+
     def __repr__(self):
         lo, hi = self.extrema()
         return f"ROCMeshField on {self.mesh!r}\n  values: min = {lo:.4g},  max = {hi:.4g}"
@@ -789,6 +805,29 @@ def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
             posthook(ls)
     ls.t = tf
     return ls
+
+
+def _sum_over_ranks(ls, x):
+    if ls.comm is None or ls.world == 1:
+        return x
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=ls.state.buf.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ls.comm)
+    return float(t.item())
+
+
+def volume(ls):
+    """volume(eq) — measure of {ϕ ≤ 0} with the smoothed Heaviside (src/levelsetops.jl:27-33,
+    src/levelsetequation.jl:165); the standard posthook diagnostic (docs/src/levelset-equation.md:142-149)."""
+    return _sum_over_ranks(ls, ls.backend.volume_local(ls.state.buf))
+
+
+def perimeter(ls):
+    """perimeter(eq) — measure of {ϕ = 0} with the smoothed Dirac delta (src/levelsetops.jl:139-149)."""
+    if ls.comm is not None and ls.world > 1:
+        ls._halo(ls.state.buf)          # slab interfaces: the centred gradient needs the neighbours' planes
+    return _sum_over_ranks(ls, ls.backend.perimeter_local(ls.state.buf))
 
 
 def current_state(ls):

@@ -129,6 +129,16 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_extrema(self.h, self.ptr(t), C.byref(lo), C.byref(hi)), "lsm_extrema")
         return lo.value, hi.value
 
+    def volume_local(self, t):
+        out = C.c_double()
+        L.check(self.h, self.lib.lsm_volume(self.h, self.ptr(t), C.byref(out)), "lsm_volume")
+        return out.value
+
+    def perimeter_local(self, t):
+        out = C.c_double()
+        L.check(self.h, self.lib.lsm_perimeter(self.h, self.ptr(t), C.byref(out)), "lsm_perimeter")
+        return out.value
+
     def sync(self):
         L.check(self.h, self.lib.lsm_sync(self.h), "lsm_sync")
 

@@ -565,6 +565,25 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     return LSM_OK;
 }
 
+// volume / perimeter of the LOCAL slab (src/levelsetops.jl:27-33,139-149); mode 0 / 1
+static int measure(LsmHandle* h, int mode, void* phi, double* out) {
+    if (!h || !phi || !out) return LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    if (mode == 1) { int r = lsm_fill_ghosts(h, phi, 7, nullptr); if (r) return r; }   // D⁰ reaches one ghost layer
+    int nb = cfl_blocks(N, h->nloc);
+    if (nb > MAXB) nb = MAXB;
+    double scale = 1.0;
+    for (int d = 0; d < N; ++d) scale = d == 0 ? h->h[0] : scale * h->h[d];            // prod(δ)
+    launch_measure(mode, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, h->dxmin, scale,
+                   (const double*)phi, h->d_partial, nb, h->d_result, h->stream);
+    LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0];
+    return LSM_OK;
+}
+int lsm_volume(LsmHandle* h, const void* phi, double* out) { return measure(h, 0, (void*)phi, out); }
+int lsm_perimeter(LsmHandle* h, void* phi, double* out) { return measure(h, 1, phi, out); }
+
 int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;

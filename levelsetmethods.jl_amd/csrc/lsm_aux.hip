@@ -418,6 +418,72 @@ void launch_extrema(int /*ndim*/, const int n[3], long long s1, long long s2, lo
 }
 
 // ---------------------------------------------------------------------------------------------
+// volume / perimeter (src/levelsetops.jl:27-33,139-149,171-183): grid sums of the smoothed
+// Heaviside H(-ϕ) resp. of δ(ϕ)·‖∇ϕ‖ (centred differences, ghosts through the field's BCs),
+// times prod(h).  One partial sum per workgroup (wave shuffles + LDS, fixed order), summed by a
+// second tiny kernel: deterministic, and equal to the reference's pairwise sum up to rounding.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double smooth_heaviside(double x, double alpha) {   // src/levelsetops.jl:171-179
+    if (x > alpha) return 1.0;
+    if (x < -alpha) return 0.0;
+    return 0.5 * (1.0 + x / alpha + 1.0 / M_PI * sin(M_PI * x / alpha));
+}
+__device__ __forceinline__ double smooth_delta(double x, double alpha) {       // src/levelsetops.jl:181-183
+    return __builtin_fabs(x) > alpha ? 0.0 : 0.5 / alpha * (1.0 + cos(M_PI * x / alpha));
+}
+// mode 0: volume, 1: perimeter
+__global__ void __launch_bounds__(256) measure_kernel(int mode, int ndim, int n0, int n1, int n2, long long s1, long long s2,
+                                                      long long origin, double h0, double h1, double h2, double dmin,
+                                                      const double* v, double* partial) {
+    const long long total = (long long)n0 * n1 * n2;
+    double acc = 0.0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
+        const long long q = origin + i0 + i1 * s1 + i2 * s2;
+        const double c = v[q];
+        if (mode == 0) {
+            acc += smooth_heaviside(-c, dmin);
+        } else {
+            const double d = smooth_delta(c, dmin);
+            if (d != 0.0) {   // ‖∇ϕ‖ from D⁰ (src/levelsetops.jl:212-215), only inside the delta's support
+                double g0 = (v[q + 1] - v[q - 1]) / (2 * h0);
+                double nrm2 = g0 * g0;
+                if (ndim > 1) { double g1 = (v[q + s1] - v[q - s1]) / (2 * h1); nrm2 = nrm2 + g1 * g1; }
+                if (ndim > 2) { double g2 = (v[q + s2] - v[q - s2]) / (2 * h2); nrm2 = nrm2 + g2 * g2; }
+                acc += d * __builtin_sqrt(nrm2);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ double ssum[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) ssum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+}
+__global__ void __launch_bounds__(256) measure_final_kernel(const double* partial, int nblocks, double scale, double* out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    __shared__ double ssum[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) ssum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = scale * ((ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
+}
+void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
+                    double dmin, double scale, const double* v, double* partial, int nblocks, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(measure_kernel, dim3(nblocks), dim3(256), 0, s, mode, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2],
+                       dmin, v, partial);
+    hipLaunchKernelGGL(measure_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, scale, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // EikonalReinitializationTerm(ϕ₀): S₀ = v / sqrt(v² + Δx²) on the interior (src/levelsetterms.jl:217-221)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eikonal_sign_kernel(int n0, int n1, int n2, long long s1, long long s2,

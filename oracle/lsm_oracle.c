@@ -433,6 +433,47 @@ void orc_eikonal_sign(const LsmGrid* g, const double* v, double* s0) {
     for (int64_t i = 0; i < C; ++i) s0[i] = v[i] / sqrt(v[i] * v[i] + dx * dx);
 }
 
+/* ------------------------------------------------------------------ volume / perimeter
+ * src/levelsetops.jl:27-33 (volume), :139-149 (perimeter), :171-183 (smooth_heaviside / smooth_delta).
+ * Julia's sum() is pairwise (blocks of 1024, SIMD inside a block), so the last digits of these sums
+ * are order-dependent in the reference itself; the oracle sums pairwise with the same block size,
+ * sequentially inside a block.  Known answers: jldoctests at src/levelsetops.jl:14-25,126-137. */
+static double smooth_heaviside(double x, double alpha) {
+    if (x > alpha) return 1.0;
+    if (x < -alpha) return 0.0;
+    return 0.5 * (1.0 + x / alpha + 1.0 / M_PI * sin(M_PI * x / alpha));
+}
+static double smooth_delta(double x, double alpha) { return fabs(x) > alpha ? 0.0 : 0.5 / alpha * (1.0 + cos(M_PI * x / alpha)); }
+
+static double measure_node(int mode, const F* f, int64_t q, double dmin) {
+    const LsmGrid* g = f->g;
+    int64_t I[3];
+    I[0] = q % g->n[0]; I[1] = (q / g->n[0]) % g->n[1]; I[2] = q / (g->n[0] * g->n[1]);
+    if (mode == 0) return smooth_heaviside(-f->v[q], dmin);
+    double nrm2 = 0.0;
+    for (int d = 0; d < g->ndim; ++d) {
+        double gd = D0(f, I, d);
+        nrm2 = d == 0 ? gd * gd : nrm2 + gd * gd;
+    }
+    return smooth_delta(fget(f, I), dmin) * sqrt(nrm2);
+}
+static double pairwise(int mode, const F* f, int64_t lo, int64_t hi, double dmin) {   /* [lo, hi) */
+    if (hi - lo <= 1024) {
+        double v = measure_node(mode, f, lo, dmin);
+        for (int64_t q = lo + 1; q < hi; ++q) v += measure_node(mode, f, q, dmin);
+        return v;
+    }
+    int64_t mid = lo + ((hi - lo - 1) >> 1) + 1;   /* Base.mapreduce_impl: imid = ifirst + (ilast - ifirst) >> 1 (inclusive) */
+    return pairwise(mode, f, lo, mid, dmin) + pairwise(mode, f, mid, hi, dmin);
+}
+/* mode 0: volume, 1: perimeter (bc used for the centred gradient at the border) */
+double orc_measure(int mode, const LsmGrid* g, const LsmBc bc[3][2], const double* v) {
+    F f; make_field(&f, g, bc, 1, v);
+    double vol = meshsize(g, 0);
+    for (int d = 1; d < g->ndim; ++d) vol = vol * meshsize(g, d);
+    return vol * pairwise(mode, &f, 0, g->n[0] * g->n[1] * g->n[2], min_meshsize(g));
+}
+
 /* ------------------------------------------------------------------ CFL (src/levelsetterms.jl:22-38) */
 
 static double cfl_sweep(const LsmTerm* terms, int nterms, const F* f, double t) {

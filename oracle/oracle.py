@@ -102,6 +102,8 @@ def lib():
         L.orc_cfl_padded.restype = C.c_double
         L.orc_cfl_padded.argtypes = [C.POINTER(LsmGrid), BcArray, C.POINTER(LsmSlab), C.POINTER(LsmLayout),
                                      C.POINTER(LsmTerm), C.c_int, dp, C.c_double]
+        L.orc_measure.restype = C.c_double
+        L.orc_measure.argtypes = [C.c_int, C.POINTER(LsmGrid), BcArray, dp]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -308,6 +310,16 @@ def eikonal_sign(grid, v):
     s0 = np.empty_like(v, order="F")
     lib().orc_eikonal_sign(C.byref(grid.c), _dp(v), _dp(s0))
     return s0
+
+
+def volume(grid, v):
+    """volume(ϕ) — src/levelsetops.jl:27-33."""
+    return lib().orc_measure(0, C.byref(grid.c), make_bc("linear", grid.ndim), _dp(v))
+
+
+def perimeter(grid, v, bc=None):
+    """perimeter(ϕ) — src/levelsetops.jl:139-149 (LinearExtrapolationBC when the field has none)."""
+    return lib().orc_measure(1, C.byref(grid.c), bc if bc is not None else make_bc("linear", grid.ndim), _dp(v))
 
 
 def compute_cfl(grid, bc, v, terms, t=0.0):

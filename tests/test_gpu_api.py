@@ -174,3 +174,24 @@ def test_slab_code_path_on_one_gpu_matches_single_device_path(lsm):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_volume_perimeter_known_answers_and_parity(lsm, orc):
+    """jldoctests src/levelsetops.jl:14-25,126-137 (200² circle) through the device reductions, plus
+    oracle parity on a 3-D field; sums are order-dependent in the reference itself: 1e-12 relative."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (200, 200))
+    ic = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2) - 0.5, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=ic, bc=lsm.LinearExtrapolationBC())
+    assert lsm.volume(eq) == pytest.approx(0.7854362890190668, rel=1e-12)
+    assert lsm.perimeter(eq) == pytest.approx(3.1426415491430384, rel=1e-12)
+    g3 = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (40, 36, 32))
+    f3 = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.55, g3)
+    e3 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=f3, bc=lsm.NeumannBC())
+    og = orc.Grid((-1, -1, -1), (1, 1, 1), (40, 36, 32))
+    assert lsm.volume(e3) == pytest.approx(orc.volume(og, f3.vals), rel=1e-12)
+    assert lsm.perimeter(e3) == pytest.approx(orc.perimeter(og, f3.vals, orc.make_bc("neumann", 3)), rel=1e-12)
+    # scalar getindex / setindex! on the device field (src/meshfield.jl:213-217,263-266)
+    st = e3.current_state()
+    assert st[(3, 4, 5)] == f3.vals[3, 4, 5]
+    st[(3, 4, 5)] = 7.5
+    assert st.values()[3, 4, 5] == 7.5 and st.ghosts_dirty

@@ -256,3 +256,13 @@ def test_3d_forward_euler_normal_motion_then_eikonal(orc):
     near = np.abs(r - 0.52) < 0.15
     assert np.abs(phi - (r - 0.52))[near].max() < 0.03
     assert not np.isnan(phi).any()
+
+
+# ------------------------------------------------------------ jldoctests src/levelsetops.jl:14-25,126-137
+def test_volume_perimeter_doctest_known_answers(orc):
+    """The only numeric known answers in the reference: a 200² circle of radius 0.5.  Julia's sum is
+    pairwise with SIMD inside 1024-blocks, so the last digits are order-dependent there too."""
+    grid = orc.Grid((-1, -1), (1, 1), (200, 200))
+    phi = grid.sample(lambda x, y: np.sqrt(x * x + y * y) - 0.5)
+    assert orc.volume(grid, phi) == pytest.approx(0.7854362890190668, rel=1e-13)
+    assert orc.perimeter(grid, phi) == pytest.approx(3.1426415491430384, rel=1e-13)
