@@ -129,6 +129,38 @@ struct NodeView {
     }
 };
 
+#if !LSM_STRICT
+// FAST: u_d·weno5^{∓}(ϕ) = |u_d|/h_d · W(undivided, upwind-ordered differences) for either sign of u_d
+// (the flipped stencil negates every difference and W is odd), so neither h nor the result needs a
+// sign select; the stencil itself is chosen with a sign-bit mask and v_bfi_b32 (≈1.9 ns) instead of
+// v_cmp + v_cndmask (≈3 ns each on gfx950).  u_d = +0 takes the left-biased stencil, where the
+// reference takes the right-biased one — the term is |0|·W = 0 either way.
+LSM_DEV double sel64(int m, double x, double y) {   // m = all-ones ? x : y
+    return __hiloint2double((__double2hiint(x) & m) | (__double2hiint(y) & ~m), (__double2loint(x) & m) | (__double2loint(y) & ~m));
+}
+template <int NDIM, int D, int G, int W, class NV>
+LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v) {
+    const int m = ~(__double2hiint(v) >> 31);   // all ones when the sign bit of u_d is clear
+    double q[6];
+    if constexpr (D == 0 || (D == 1 && NDIM == 3)) {
+        constexpr int st = D == 0 ? 1 : W;
+        const int ss = (st & m) | (-st & ~m);
+        q[0] = nv.T0[-3 * ss]; q[1] = nv.T0[-2 * ss]; q[2] = nv.T0[-ss];
+        q[3] = nv.c;
+        q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
+    } else {
+        q[0] = sel64(m, nv.zl[G - 3], nv.zl[G + 3]);
+        q[1] = sel64(m, nv.zl[G - 2], nv.zl[G + 2]);
+        q[2] = sel64(m, nv.zl[G - 1], nv.zl[G + 1]);
+        q[3] = nv.c;
+        q[4] = sel64(m, nv.zl[G + 1], nv.zl[G - 1]);
+        q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
+    }
+    const double w = weno5_undivided(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], 1.0e-99 * a.h2[D]);
+    return (__builtin_fabs(v) * a.inv_h[D]) * w;
+}
+#endif
+
 template <int NDIM, int D, int G, int W, class NV>
 LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
     const bool up = v > 0;
@@ -167,7 +199,11 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
             const double v = u[D];
             double der;
             if constexpr (ADV == 2) {
+#if LSM_STRICT
                 der = weno_dim<NDIM, D, G, W>(nv, a, v);
+#else
+                return weno_term<NDIM, D, G, W>(nv, a, v);
+#endif
             } else {
 #if LSM_STRICT
                 der = v > 0 ? (c - nv.template at<D>(-1)) / a.h[D] : (nv.template at<D>(1) - c) / a.h[D];
