@@ -186,6 +186,22 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "stage_time_fraction_of_step": round(stage_ms / (el * 1e3), 4)},
     }
+    # HBM traffic of the stage kernel: PMC counters cannot be collected from inside this process, so the
+    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/r1/,
+    # tools_profile.sh), corrected as calibrated on gfx950 with known-traffic kernels of the same access
+    # width (tools_configs.py calib): FETCH_SIZE counts 1/2 of 8-byte-per-lane reads, WRITE_SIZE is exact.
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch.json")))
+        st = next(v for k, v in pj.items() if "stage_kernel<3, 2, 0, 0, 2" in k)
+        out["roofline"]["traffic"] = round((2.0 * st["FETCH_SIZE"] + st["WRITE_SIZE"]) * 1024.0)
+        out["roofline"]["traffic_source"] = "profiles/r1/pmc_per_dispatch.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> B, per 512^3 launch)"
+    except Exception:
+        pass
+    # the binding resource is the fp64 vector pipe: ~300 fp64 VALU instructions (~450 flop) per node-stage
+    flop_per_node_stage = 450.0
+    out["fp64_vector"] = {"achieved_tflops": round(local_cells * 3 * args.steps * flop_per_node_stage / (stage_ms * 1e-3) / 1e12, 2)
+                          if n_launch else 0.0, "peak_tflops": FP64_PEAK_TFLOPS,
+                          "note": "algorithmic flop estimate from the ISA of the fused stage kernel (DESIGN.md §3.1)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         v1, t1 = cpu_baseline(args.cpu_sample, 1)

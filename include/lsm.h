@@ -198,6 +198,16 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax);
 int lsm_volume(LsmHandle* h, const void* phi, double* out);
 int lsm_perimeter(LsmHandle* h, void* phi, double* out);
 
+/* ---- extend_along_normals!(F, ϕ; nb_iters, cfl, frozen, interface_band, min_norm)
+ *      (src/velocityextension.jl:20-67): extends the speed F off the interface of ϕ by nb_iters
+ *      first-order upwind sweeps of ∂τF + sign(ϕ) n·∇F = 0, frozen nodes held fixed.  F, phi and the
+ *      work buffers (ndim+1 of them) are padded device arrays; frozen is NULL (band rule
+ *      |ϕ| <= interface_band·Δ) or a padded array whose non-zero entries are frozen nodes.
+ *      Ghosts of F are resolved with the handle's boundary conditions, as the reference does. */
+int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* frozen, void* work0, void* work1,
+                             void* work2, void* work3, int nb_iters, double cfl, double interface_band,
+                             double min_norm);
+
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
 int lsm_profile_enable(LsmHandle* h, int on);
 int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total);   /* synchronises; resets */

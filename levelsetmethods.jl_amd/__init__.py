@@ -10,7 +10,8 @@ from ._lib import LsmError, build
 from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm, EikonalReinitializationTerm,
                   ExtrapolationBC, ForwardEuler, LazyMeshField, LevelSetEquation, LevelSetTerm, LinearExtrapolationBC, MeshField,
                   NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField, SeparableCoefficient,
-                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, integrate_, perimeter, volume,
+                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_,
+                  perimeter, volume,
                   vortex_deformation)
 
 __all__ = [
@@ -18,5 +19,5 @@ __all__ = [
     "ExtrapolationBC", "ForwardEuler", "LazyMeshField", "LevelSetEquation", "LevelSetTerm", "LinearExtrapolationBC", "MeshField",
     "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3", "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
-    "integrate_", "vortex_deformation", "volume", "perimeter", "LsmError", "build",
+    "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "LsmError", "build",
 ]

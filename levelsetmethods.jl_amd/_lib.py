@@ -83,6 +83,8 @@ _SIGS = [
                                   C.c_double, StageHook, C.c_void_p]),
     ("lsm_eikonal_sign", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("lsm_extend_along_normals", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_double, C.c_double, C.c_double]),
     ("lsm_volume", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double)]),
     ("lsm_perimeter", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double)]),
     ("lsm_profile_enable", C.c_int, [_H, C.c_int]),

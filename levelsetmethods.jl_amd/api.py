@@ -830,6 +830,38 @@ def perimeter(ls):
     return _sum_over_ranks(ls, ls.backend.perimeter_local(ls.state.buf))
 
 
+def extend_along_normals_(F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_band=1.5, min_norm=1.0e-14):
+    """extend_along_normals!(F, ϕ; nb_iters, cfl, frozen, interface_band, min_norm) —
+    src/velocityextension.jl:20-76.  `F` and `phi` are device fields (ROCMeshField) on the same mesh;
+    `frozen` is None (band rule) or a boolean/0-1 host array or device field.  F is updated in place."""
+    if not (isinstance(F, ROCMeshField) and isinstance(phi, ROCMeshField)):
+        raise ValueError("F and ϕ must be device fields (ROCMeshField) of the same equation/backend")
+    if F.mesh.n != phi.mesh.n:
+        raise ValueError("F and ϕ must be defined on the same mesh")
+    if nb_iters < 0:
+        raise ValueError("nb_iters must be non-negative")
+    if not cfl > 0:
+        raise ValueError("cfl must be strictly positive")
+    if not interface_band >= 0:
+        raise ValueError("interface_band must be non-negative")
+    if not min_norm >= 0:
+        raise ValueError("min_norm must be non-negative")
+    b = phi.backend
+    fz = None
+    if frozen is not None:
+        if isinstance(frozen, ROCMeshField):
+            fz = frozen.buf
+        else:
+            a = np.asarray(frozen.vals if isinstance(frozen, MeshField) else frozen)
+            if a.shape != phi.mesh.n:
+                raise ValueError("frozen mask must have the same size as ϕ")
+            fz = b.alloc()
+            b.upload(fz, a.astype(np.float64))
+    b.extend_along_normals(F.buf, phi.buf, fz, int(nb_iters), float(cfl), float(interface_band), float(min_norm))
+    F.ghosts_dirty = True
+    return F
+
+
 def current_state(ls):
     return ls.current_state()
 

@@ -129,6 +129,13 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_extrema(self.h, self.ptr(t), C.byref(lo), C.byref(hi)), "lsm_extrema")
         return lo.value, hi.value
 
+    def extend_along_normals(self, F, phi, frozen, nb_iters, cfl, interface_band, min_norm):
+        work = [self.alloc() for _ in range(self.ndim + 1)]
+        w = [self.ptr(x) for x in work] + [None] * (4 - len(work))
+        L.check(self.h, self.lib.lsm_extend_along_normals(self.h, self.ptr(F), self.ptr(phi), self.ptr(frozen), w[0], w[1], w[2], w[3],
+                                                          nb_iters, cfl, interface_band, min_norm), "lsm_extend_along_normals")
+        self.sync()   # the work buffers are released on return
+
     def volume_local(self, t):
         out = C.c_double()
         L.check(self.h, self.lib.lsm_volume(self.h, self.ptr(t), C.byref(out)), "lsm_volume")

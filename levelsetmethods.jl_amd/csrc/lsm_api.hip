@@ -584,6 +584,45 @@ static int measure(LsmHandle* h, int mode, void* phi, double* out) {
 int lsm_volume(LsmHandle* h, const void* phi, double* out) { return measure(h, 0, (void*)phi, out); }
 int lsm_perimeter(LsmHandle* h, void* phi, double* out) { return measure(h, 1, phi, out); }
 
+// extend_along_normals! (src/velocityextension.jl:20-67): nb_iters first-order upwind pseudo-time
+// sweeps F <- F - τ Σ_d a_d (a_d>0 ? D⁻F : D⁺F) with a = sign-weighted unit normal of ϕ, frozen nodes
+// held fixed.  Each sweep is the fused stage kernel with an Upwind advection term whose velocity is
+// the (frozen-masked) normal field.
+int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* frozen, void* work0, void* work1, void* work2,
+                             void* work3, int nb_iters, double cfl, double interface_band, double min_norm) {
+    if (!h || !F || !phi || !work0 || !work1) return h ? fail(h, LSM_ERR_INVALID, "lsm_extend_along_normals: null argument") : LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    if ((N > 1 && !work2) || (N > 2 && !work3)) return fail(h, LSM_ERR_INVALID, "lsm_extend_along_normals: need ndim+1 work buffers");
+    if (nb_iters < 0) return fail(h, LSM_ERR_INVALID, "nb_iters must be non-negative");
+    if (!(cfl > 0)) return fail(h, LSM_ERR_INVALID, "cfl must be strictly positive");
+    if (!(interface_band >= 0)) return fail(h, LSM_ERR_INVALID, "interface_band must be non-negative");
+    if (!(min_norm >= 0)) return fail(h, LSM_ERR_INVALID, "min_norm must be non-negative");
+    LSM_TRY(check_single_device(h));
+    const double delta = h->dxmin;
+    const double tau = cfl * delta;
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
+    void* comp[3] = {work1, work2, work3};
+    launch_signed_normals(N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, delta, interface_band * delta,
+                          min_norm * min_norm, (const double*)phi, (const double*)frozen, (double*)comp[0], (double*)comp[1],
+                          (double*)comp[2], h->stream);
+    LSM_HIP(h, hipGetLastError());
+    LsmTerm term;
+    memset(&term, 0, sizeof(term));
+    term.kind = LSM_TERM_ADVECTION;
+    term.scheme = LSM_SCHEME_UPWIND;
+    term.coeff.kind = LSM_COEFF_FIELD;
+    for (int d = 0; d < N; ++d) term.coeff.field[d] = comp[d];
+    void* cur = F;
+    void* nxt = work0;
+    for (int it = 0; it < nb_iters; ++it) {
+        LSM_TRY(lsm_fill_ghosts(h, cur, 7, nullptr));
+        LSM_TRY(lsm_stage(h, &term, 1, cur, nullptr, nxt, nullptr, LSM_BASE_PSI, tau, 0.0, 0.0, nullptr));
+        void* t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != F) LSM_HIP(h, hipMemcpyAsync(F, cur, sizeof(double) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));
+    return LSM_OK;
+}
+
 int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;

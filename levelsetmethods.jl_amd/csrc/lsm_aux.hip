@@ -484,6 +484,51 @@ void launch_measure(int mode, int ndim, const int n[3], long long s1, long long 
 }
 
 // ---------------------------------------------------------------------------------------------
+// _signed_normal_components (src/velocityextension.jl:96-116) with the frozen mask
+// (_normalize_frozen_mask, :78-94) folded in: a_d = S·∂_dϕ/|∇ϕ| (centred differences, S = ϕ/√(ϕ²+Δ²)),
+// 0 where |∇ϕ|² <= min_norm² — and 0 on frozen nodes, which makes the upwind update of
+// extend_along_normals! leave them untouched exactly (F - τ·Σ 0·dF = F).
+// frozen: optional padded array (non-zero = frozen); NULL -> band rule |ϕ| <= band_width.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) signed_normals_kernel(int ndim, int n0, int n1, int n2, long long s1, long long s2,
+                                                             long long origin, double h0, double h1, double h2, double delta,
+                                                             double band_width, double min_norm2, const double* phi,
+                                                             const double* frozen, double* c0, double* c1, double* c2) {
+    const long long total = (long long)n0 * n1 * n2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
+        const long long q = origin + i0 + i1 * s1 + i2 * s2;
+        const double c = phi[q];
+        double g[3] = {0, 0, 0};
+        g[0] = (phi[q + 1] - phi[q - 1]) / (2 * h0);
+        double nrm2 = g[0] * g[0];
+        if (ndim > 1) { g[1] = (phi[q + s1] - phi[q - s1]) / (2 * h1); nrm2 = nrm2 + g[1] * g[1]; }
+        if (ndim > 2) { g[2] = (phi[q + s2] - phi[q - s2]) / (2 * h2); nrm2 = nrm2 + g[2] * g[2]; }
+        const bool fz = frozen ? frozen[q] != 0.0 : __builtin_fabs(c) <= band_width;
+        double a[3] = {0, 0, 0};
+        if (!fz && !(nrm2 <= min_norm2)) {
+            const double invnorm = 1.0 / __builtin_sqrt(nrm2);
+            const double S = c / __builtin_sqrt(c * c + delta * delta);
+            a[0] = S * g[0] * invnorm;
+            a[1] = S * g[1] * invnorm;
+            a[2] = S * g[2] * invnorm;
+        }
+        c0[q] = a[0];
+        if (ndim > 1) c1[q] = a[1];
+        if (ndim > 2) c2[q] = a[2];
+    }
+}
+void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double delta,
+                           double band_width, double min_norm2, const double* phi, const double* frozen, double* c0, double* c1,
+                           double* c2, hipStream_t s) {
+    const long long total = (long long)n[0] * n[1] * n[2];
+    long long b = (total + 255) / 256;
+    const int nb = (int)(b > 4096 ? 4096 : b);
+    hipLaunchKernelGGL(signed_normals_kernel, dim3(nb), dim3(256), 0, s, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2],
+                       delta, band_width, min_norm2, phi, frozen, c0, c1, c2);
+}
+
+// ---------------------------------------------------------------------------------------------
 // EikonalReinitializationTerm(ϕ₀): S₀ = v / sqrt(v² + Δx²) on the interior (src/levelsetterms.jl:217-221)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eikonal_sign_kernel(int n0, int n1, int n2, long long s1, long long s2,

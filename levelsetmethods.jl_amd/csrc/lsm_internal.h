@@ -110,6 +110,9 @@ void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long l
                     double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s);
 void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
                     double dmin, double scale, const double* v, double* partial, int nblocks, double* out, hipStream_t s);
+void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double delta,
+                           double band_width, double min_norm2, const double* phi, const double* frozen, double* c0, double* c1,
+                           double* c2, hipStream_t s);
 void launch_eikonal_sign(int ndim, const int n[3], long long s1, long long s2, long long origin, double dxmin,
                          const double* phi0, double* s0, hipStream_t s);
 

@@ -474,6 +474,50 @@ double orc_measure(int mode, const LsmGrid* g, const LsmBc bc[3][2], const doubl
     return vol * pairwise(mode, &f, 0, g->n[0] * g->n[1] * g->n[2], min_meshsize(g));
 }
 
+/* ------------------------------------------------------------------ extend_along_normals!
+ * src/velocityextension.jl:20-67 (sweeps), :78-94 (frozen mask), :96-116 (signed normal components).
+ * frozen: NULL (band rule) or a dense 0/1 double array.  F is updated in place. */
+void orc_extend_along_normals(const LsmGrid* g, const LsmBc bc[3][2], double* Fv, const double* phi, const double* frozen,
+                              int nb_iters, double cfl, double interface_band, double min_norm) {
+    int N = g->ndim;
+    int64_t C = g->n[0] * g->n[1] * g->n[2];
+    F fphi; make_field(&fphi, g, bc, 1, phi);
+    double delta = min_meshsize(g);
+    double tau = cfl * delta;
+    unsigned char* fz = (unsigned char*)malloc((size_t)C);
+    double* comp[3];
+    for (int d = 0; d < 3; ++d) comp[d] = (double*)calloc((size_t)C, sizeof(double));
+    double mn2 = min_norm * min_norm;
+    for (int64_t q = 0; q < C; ++q) {
+        int64_t I[3] = {q % g->n[0], (q / g->n[0]) % g->n[1], q / (g->n[0] * g->n[1])};
+        fz[q] = frozen ? (frozen[q] != 0.0) : (fabs(phi[q]) <= interface_band * delta);
+        double gr[3] = {0, 0, 0}, nrm2 = 0.0;
+        for (int d = 0; d < N; ++d) { gr[d] = D0(&fphi, I, d); nrm2 = d == 0 ? gr[d] * gr[d] : nrm2 + gr[d] * gr[d]; }
+        if (nrm2 <= mn2) continue;
+        double invnorm = 1.0 / sqrt(nrm2);
+        double S = phi[q] / sqrt(phi[q] * phi[q] + delta * delta);
+        for (int d = 0; d < N; ++d) comp[d][q] = S * gr[d] * invnorm;
+    }
+    double* Fnew = (double*)malloc(sizeof(double) * (size_t)C);
+    for (int it = 0; it < nb_iters; ++it) {
+        F fF; make_field(&fF, g, bc, 1, Fv);
+        for (int64_t q = 0; q < C; ++q) {
+            int64_t I[3] = {q % g->n[0], (q / g->n[0]) % g->n[1], q / (g->n[0] * g->n[1])};
+            if (fz[q]) { Fnew[q] = Fv[q]; continue; }
+            double adv = 0.0;
+            for (int d = 0; d < N; ++d) {
+                double a = comp[d][q];
+                double dF = a > 0 ? Dm(&fF, I, d) : Dp(&fF, I, d);
+                adv += a * dF;
+            }
+            Fnew[q] = Fv[q] - tau * adv;
+        }
+        memcpy(Fv, Fnew, sizeof(double) * (size_t)C);
+    }
+    free(Fnew); free(fz);
+    for (int d = 0; d < 3; ++d) free(comp[d]);
+}
+
 /* ------------------------------------------------------------------ CFL (src/levelsetterms.jl:22-38) */
 
 static double cfl_sweep(const LsmTerm* terms, int nterms, const F* f, double t) {

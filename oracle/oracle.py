@@ -102,6 +102,8 @@ def lib():
         L.orc_cfl_padded.restype = C.c_double
         L.orc_cfl_padded.argtypes = [C.POINTER(LsmGrid), BcArray, C.POINTER(LsmSlab), C.POINTER(LsmLayout),
                                      C.POINTER(LsmTerm), C.c_int, dp, C.c_double]
+        L.orc_extend_along_normals.restype = None
+        L.orc_extend_along_normals.argtypes = [C.POINTER(LsmGrid), BcArray, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.orc_measure.restype = C.c_double
         L.orc_measure.argtypes = [C.c_int, C.POINTER(LsmGrid), BcArray, dp]
         L.orc_set_threads.argtypes = [C.c_int]
@@ -310,6 +312,13 @@ def eikonal_sign(grid, v):
     s0 = np.empty_like(v, order="F")
     lib().orc_eikonal_sign(C.byref(grid.c), _dp(v), _dp(s0))
     return s0
+
+
+def extend_along_normals(grid, bc, F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_band=1.5, min_norm=1.0e-14):
+    """extend_along_normals!(F, ϕ; ...) in place on F — src/velocityextension.jl:20-67."""
+    fz = None if frozen is None else np.asfortranarray(np.asarray(frozen, dtype=np.float64))
+    lib().orc_extend_along_normals(C.byref(grid.c), bc, _dp(F), _dp(phi), _dp(fz), nb_iters, cfl, interface_band, min_norm)
+    return F
 
 
 def volume(grid, v):

@@ -1,0 +1,127 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle needs
+minutes per step at 512³, so here the checks are analytic identities of the scheme itself):
+
+  * a linear field is differentiated exactly by every scheme: one RK3 step of advection with a
+    constant velocity gives ϕ - Δt u·∇ϕ to rounding, Eikonal/NormalMotion see |∇ϕ| exactly,
+    curvature sees κ = 0;
+  * an exact signed-distance plane is a fixed point of the Eikonal term;
+  * an exactly constant field is a fixed point of every term (ε floor of the WENO weights,
+    zero-gradient guards) — no NaN;
+  * the CFL Δt of the vortex-deformation field equals the value reduced on the host from the
+    separable tables at the arg-max node set (bitwise);
+  * slab composition: updating 512³ in three plane ranges equals one full launch (bitwise).
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsm():
+    import lsm_amd
+    return lsm_amd
+
+
+def _interior_err(out, want, pad=4):
+    sl = tuple(slice(pad, -pad) for _ in range(out.ndim))
+    return np.abs(out[sl] - want[sl]).max()
+
+
+def test_512_cubed_linear_field_advection_is_exact(lsm):
+    n = 512
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    a = (0.7, -0.4, 0.25)
+    u = (0.3, 0.9, -0.6)
+    ic = lsm.LazyMeshField(lambda x: a[0] * x[0] + a[1] * x[1] + a[2] * x[2] - 0.2, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(u, lsm.WENO5()),), ic=ic, bc=lsm.LinearExtrapolationBC(), integrator=lsm.RK3())
+    dt = 0.5 * eq.compute_cfl(0.0)
+    h = grid.meshsize(0)
+    assert dt == 0.5 * (1 / (abs(u[0]) / h + abs(u[1]) / h + abs(u[2]) / h))   # src/levelsetterms.jl:90-96
+    eq._advance(0.0, dt)
+    out = eq.current_state().values()
+    want = ic.local_values(None) - dt * (u[0] * a[0] + u[1] * a[1] + u[2] * a[2])
+    assert np.abs(out - want).max() <= 1e-13      # linear extrapolation keeps the field linear in the ghosts too
+    del out, want
+
+
+def test_512_cubed_sdf_plane_is_eikonal_fixed_point_and_constant_field_is_inert(lsm):
+    n = 512
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    nx = (2 / 3, -1 / 3, 2 / 3)     # unit normal
+    ic = lsm.LazyMeshField(lambda x: nx[0] * (x[0] - 0.5) + nx[1] * (x[1] - 0.5) + nx[2] * (x[2] - 0.5), grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.EikonalReinitializationTerm(),), ic=ic, bc=lsm.LinearExtrapolationBC(), integrator=lsm.RK3())
+    dt = 0.5 * eq.compute_cfl(0.0)
+    assert dt == 0.5 * grid.meshsize(0)            # src/levelsetterms.jl:250
+    eq._advance(0.0, dt)
+    out = eq.current_state().values()
+    assert np.abs(out - ic.local_values(None)).max() <= 1e-14
+    del out
+    flat = lsm.LazyMeshField(lambda x: 0.25 + 0.0 * x[0], grid)
+    eq2 = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()), lsm.EikonalReinitializationTerm(),
+                                      lsm.NormalMotionTerm(0.3), lsm.CurvatureTerm(-0.1)), ic=flat, bc=lsm.NeumannBC(),
+                               integrator=lsm.RK3())
+    eq2._advance(0.0, 1.0e-3)
+    lo, hi = eq2.current_state().extrema()
+    # |∇ϕ| = 0: advection, curvature contribute 0; Eikonal S·(0-1) = -ϕ/|ϕ| and NormalMotion 0 -> uniform shift, no NaN
+    assert lo == hi and not math.isnan(lo)
+
+
+def test_512_cubed_vortex_cfl_matches_host_reduction(lsm):
+    n = 512
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    vel = lsm.vortex_deformation(grid)
+    ic = lsm.LazyMeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(vel, lsm.WENO5()),), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    t = 0.37
+    got = eq.compute_cfl(t)
+    g = math.cos(math.pi * t / 3.0)
+    h = grid.meshsize(0)
+    # host: the same ((T1*T2)*T3)*g products, |u|/h sums and max, plane by plane (numpy is IEEE: identical bits)
+    best = 0.0
+    T = vel.tables
+    for k in range(n):
+        s = 0.0
+        for c in range(3):
+            p = (T[c][0][:, None] * T[c][1][None, :]) * T[c][2][k]
+            s = (np.abs(p * g) / h) if c == 0 else s + np.abs(p * g) / h
+        best = max(best, float(s.max()))
+    assert got == 1 / best
+
+
+def test_512_cubed_plane_ranges_compose(lsm):
+    n = 512
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    ic = lsm.LazyMeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+                              ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    from lsm_amd.api import _terms_c
+    b = eq.backend
+    b.fill_ghosts(eq.state.buf)
+    full, part = b.alloc(), b.alloc()
+    arr = _terms_c(eq.terms)
+    b.stage(arr, 2, eq.state.buf, None, full, None, 0, 1e-3, 0.0, 0.1)
+    for m0, m1 in ((0, 4), (n - 4, n), (4, n - 4)):
+        b.stage_planes(arr, 2, eq.state.buf, None, part, None, 0, 1e-3, 0.0, 0.1, m0, m1)
+    import torch
+    assert torch.equal(full, part)
+
+
+def test_2048_squared_zalesak_rotation_step_is_symmetric_under_point_reflection(lsm):
+    """Config 2 size.  Rigid rotation about the origin commutes with the point reflection x -> -x;
+    on a grid symmetric about the origin one RK3 step of a point-symmetric field stays point-symmetric
+    (the scheme's upwind stencils mirror exactly): bitwise in STRICT mode."""
+    n = 2048
+    grid = lsm.CartesianGrid((-1.5, -1.5), (1.5, 1.5), (n, n))
+    f = lambda x: np.minimum(np.hypot(x[0] + 0.75, x[1]) - 0.5, np.hypot(x[0] - 0.75, x[1]) - 0.5)
+    ic = lsm.MeshField(f, grid)
+    assert np.abs(ic.vals - ic.vals[::-1, ::-1]).max() <= 1e-14    # node coordinates mirror to an ulp
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()),), ic=ic, bc=lsm.NeumannBC(),
+                              integrator=lsm.RK3())
+    for _ in range(3):
+        eq._advance(0.0, 0.5 * eq.compute_cfl(0.0))
+    out = eq.current_state().values()
+    assert np.abs(out - out[::-1, ::-1]).max() <= 1e-12
+    assert np.abs(out - ic.vals).max() > 1e-4                       # it did move
