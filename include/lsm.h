@@ -208,6 +208,36 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
                              void* work2, void* work3, int nb_iters, double cfl, double interface_band,
                              double min_norm);
 
+/* ---- NarrowBandMeshField (src/meshfield.jl:314-588) on the device.
+ *      The band is a byte mask (1 = active node) over the same padded index space as the values
+ *      (allocate LsmLayout.total bytes; ghost entries stay 0).  Values stay in the dense padded array.
+ *      PeriodicBC is rejected, as in the reference (:339-340).
+ *
+ *      lsm_band_update      update_band! (:555-588): cut cells of the band (or of the whole grid when
+ *                           from_dense != 0) seed their corners, nlayers L1 dilations grow the new band,
+ *                           newly active nodes get the affine extrapolant from the OLD band; mask is
+ *                           replaced.  scratch_a/b: two more mask-sized buffers.
+ *      lsm_band_halo_mask   nodes within Chebyshev distance radius (<= 3) of the band
+ *      lsm_band_fill        _extrapolate_to_ghost (:481-511) materialised on halo & !band nodes, so that
+ *                           stencils read plain entries; follow with lsm_fill_ghosts for out-of-grid layers
+ *      lsm_band_tiles       per-tile activity flags for lsm_stage_band (lsm_band_tile_count gives the size)
+ *      lsm_stage_band       lsm_stage restricted to band nodes (tiles without band nodes are skipped)
+ *      lsm_compute_cfl_band compute_cfl over active_nodeindices
+ *      lsm_band_count       number of active nodes;  lsm_band_missed: a value was requested farther than
+ *                           the search radius (6) from the band since the last call (the reference throws) */
+int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b);
+int lsm_band_halo_mask(LsmHandle* h, const void* mask, int radius, void* halo_mask, void* scratch);
+int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* halo_mask);
+int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles);
+int lsm_band_tiles(LsmHandle* h, const void* mask, int mc, void* tiles);
+int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count);
+int lsm_band_missed(LsmHandle* h, int* missed);
+int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out,
+                   void* out2, int base_mode, double cdt, double cdt2, double t_stage, const void* mask,
+                   const void* tiles, int mc, void* stream);
+int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask,
+                         double t, double* dt_out);
+
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
 int lsm_profile_enable(LsmHandle* h, int on);
 int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total);   /* synchronises; resets */

@@ -9,7 +9,8 @@ from . import _lib
 from ._lib import LsmError, build
 from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm, EikonalReinitializationTerm,
                   ExtrapolationBC, ForwardEuler, LazyMeshField, LevelSetEquation, LevelSetTerm, LinearExtrapolationBC, MeshField,
-                  NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField, SeparableCoefficient,
+                  NarrowBandMeshField, NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField,
+                  ROCNarrowBandMeshField, SeparableCoefficient,
                   SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_,
                   perimeter, volume,
                   vortex_deformation)
@@ -17,7 +18,8 @@ from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm
 __all__ = [
     "AdvectionTerm", "BoundaryCondition", "CartesianGrid", "CurvatureTerm", "EikonalReinitializationTerm",
     "ExtrapolationBC", "ForwardEuler", "LazyMeshField", "LevelSetEquation", "LevelSetTerm", "LinearExtrapolationBC", "MeshField",
-    "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3", "RigidRotation", "ROCMeshField",
+    "NarrowBandMeshField", "ROCNarrowBandMeshField", "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3",
+    "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
     "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "LsmError", "build",
 ]

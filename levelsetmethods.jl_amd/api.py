@@ -306,6 +306,114 @@ class ROCMeshField:
         return f"ROCMeshField on {self.mesh!r}\n  values: min = {lo:.4g},  max = {hi:.4g}"
 
 
+class NarrowBandMeshField:
+    """NarrowBandMeshField(ϕ::MeshField; nlayers = 3) / NarrowBandMeshField(f, grid; bc, nlayers)
+    (src/meshfield.jl:411-440): host-side description of a field restricted to the topological band
+    of `nlayers` nodes around the cut cells.  Passing it as `ic` makes the equation evolve the band only."""
+
+    def __init__(self, phi_or_f, grid=None, bc=None, nlayers=3):
+        base = phi_or_f if isinstance(phi_or_f, MeshField) else MeshField(phi_or_f, grid, bc=bc)
+        if base.bcs is not None and any(b.kind == L.BC_PERIODIC for pair in base.bcs for b in pair):
+            raise ValueError("PeriodicBC is not supported on a NarrowBandMeshField")   # src/meshfield.jl:339-340
+        self.base, self.mesh, self.bcs, self.nlayers = base, base.mesh, base.bcs, int(nlayers)
+        self.vals = base.vals
+
+    def has_boundary_conditions(self):
+        return self.bcs is not None
+
+
+class ROCNarrowBandMeshField(ROCMeshField):
+    """Device narrow band: dense padded values + a byte mask of active nodes (+ the halo mask and
+    tile flags derived from it).  Non-band entries of the value array are scratch: before every
+    stage they are refilled, within 3 nodes of the band, with the reference's affine extrapolant."""
+    MC = 8          # planes per march chunk in band mode (tile = 32 x 8 x MC in 3-D)
+    HALO = 3
+
+    def __init__(self, backend, mesh, bcs, nlayers, buf=None):
+        super().__init__(backend, mesh, bcs, buf)
+        self.nlayers = int(nlayers)
+        self.mask = backend.alloc_mask()
+        self.halo = backend.alloc_mask()
+        self.tiles = None
+
+    def rebuild(self, from_dense=False):
+        """update_band! (src/meshfield.jl:555-588) + the derived halo mask and tile flags."""
+        b = self.backend
+        b.band_update(self.buf, self.mask, from_dense, self.nlayers)
+        b.band_halo_mask(self.mask, self.HALO, self.halo)
+        self.tiles = b.band_tiles(self.mask, self.MC)
+        self.ghosts_dirty = True
+
+    def prepare(self, buf):
+        """Make `buf` readable by stencils: band halo (extrapolation) then out-of-grid ghosts (BCs)."""
+        self.backend.band_fill(buf, self.mask, self.halo)
+        self.backend.fill_ghosts(buf, 7)
+
+    def active_mask(self):
+        return self.backend.mask_to_host(self.mask)
+
+    def active_count(self):
+        return self.backend.band_count(self.mask)
+
+    def active_nodeindices(self):
+        return [tuple(int(i) for i in I) for I in np.argwhere(self.active_mask())]
+
+    def values(self):
+        """Host copy: stored values on the band, NaN elsewhere."""
+        v = self.backend.download(self.buf)
+        v[~self.active_mask()] = np.nan
+        return v
+
+    def copy(self):
+        c = ROCNarrowBandMeshField(self.backend, self.mesh, self.bcs, self.nlayers, self.backend.clone(self.buf))
+        c.mask.copy_(self.mask)
+        c.halo.copy_(self.halo)
+        c.tiles = None if self.tiles is None else self.tiles.clone()
+        return c
+
+    def __getitem__(self, I):
+        """ϕ[I] (src/meshfield.jl:441-445,475-511): stored value on the band, affine extrapolant from the
+        nearest band node elsewhere in the grid, boundary conditions outside the grid.  Slow scalar path."""
+        I = tuple(I) if not isinstance(I, int) else (I,)
+        n = self.mesh.n
+        if all(0 <= I[d] < n[d] for d in range(len(n))):
+            off = self._offset(I)
+            if not bool(self.mask[off].item()):
+                t = self.backend.alloc_mask()
+                t[off] = 1
+                self.backend.band_fill(self.buf, self.mask, t)
+                if self.backend.band_missed():
+                    raise ValueError(f"index {I} is more than 6 nodes from the band")
+            return float(self.buf[off].item())
+        if self.bcs is None:
+            raise ValueError(f"index {I} lies outside the grid, but the field has no boundary conditions to resolve it.")
+        return self._bc_resolve(I, len(n))
+
+    def _bc_resolve(self, I, dim):   # _getindexbc (src/meshfield.jl:248-260) over this field's own getindex
+        if dim == 0:
+            return self[I]
+        d = dim - 1
+        n = self.mesh.n[d]
+        if 0 <= I[d] < n:
+            return self._bc_resolve(I, dim - 1)
+        left = I[d] < 0
+        bc = self.bcs[d][0 if left else 1]
+        k = -I[d] if left else I[d] - (n - 1)
+        b, sgn = (0, 1) if left else (n - 1, -1)
+        acc = 0.0
+        if bc.kind == L.BC_EXTRAPOLATION:
+            P = bc.degree
+            for j in range(P + 1):
+                w = 1.0
+                for m in range(P + 1):
+                    if m != j:
+                        w *= (-k - m) / (j - m)
+                acc += w * self._bc_resolve(I[:d] + (b + sgn * j,) + I[d + 1:], dim - 1)
+        else:
+            acc += 1.0 * self._bc_resolve(I[:d] + (b + sgn * k,) + I[d + 1:], dim - 1)
+        return acc
+
+
 # ----------------------------------------------------------------------------- derivatives.jl schemes
 
 class SpatialScheme:
@@ -589,8 +697,18 @@ class LevelSetEquation:
             factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device)
         self.backend = factory(grid._c(), _bc_c(bcs, N, slab_faces), self.slab)
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
-        self.state = ROCMeshField(self.backend, grid, bcs)
-        if isinstance(ic, ROCMeshField):
+        self.band = isinstance(ic, NarrowBandMeshField)
+        if self.band:
+            if comm is not None:
+                raise ValueError("a NarrowBandMeshField cannot be slab-decomposed yet (single device only)")
+            self.state = ROCNarrowBandMeshField(self.backend, grid, bcs, ic.nlayers)
+            self.backend.upload(self.state.buf, ic.vals)
+            self.state.rebuild(from_dense=True)   # NarrowBandMeshField(ϕ; nlayers): seed every node, then update_band!
+        else:
+            self.state = ROCMeshField(self.backend, grid, bcs)
+        if self.band:
+            pass
+        elif isinstance(ic, ROCMeshField):
             self.backend.copy_(self.state.buf, ic.buf)
         elif isinstance(ic, LazyMeshField):
             self.backend.upload(self.state.buf, ic.local_values(self.slab))
@@ -638,7 +756,10 @@ class LevelSetEquation:
     def compute_cfl(self, t=None):
         t = self.t if t is None else t
         arr = _terms_c(self.terms)
-        dt = self.backend.compute_cfl_local(arr, len(self.terms), self.state.buf, t)
+        if self.band:   # minimum over active_nodeindices (src/levelsetterms.jl:31-38)
+            dt = self.backend.compute_cfl_band(arr, len(self.terms), self.state.buf, self.state.mask, t)
+        else:
+            dt = self.backend.compute_cfl_local(arr, len(self.terms), self.state.buf, t)
         if self.comm is not None and self.world > 1:
             dt = self._allreduce_min(dt)
         if not dt > 0:
@@ -664,6 +785,8 @@ class LevelSetEquation:
         n = len(self.terms)
         phi = self.state.buf
         name = self.integrator.name
+        if self.band:
+            return self._advance_band(tc, dt, b1, b2)
         if self.comm is None:
             hook = None
             if self._needs_hook():
@@ -707,6 +830,44 @@ class LevelSetEquation:
             self._stage_slab(T(), n, b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
             self._update_terms(fld(b2), tc + 0.5 * dt)
             self._stage_slab(T(), n, b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
+
+    def _advance_band(self, tc, dt, b1, b2):
+        """_advance! on a NarrowBandMeshField: the same stages, looping over active nodes only
+        (src/timestepping.jl:128-202 with active_nodeindices = the band).  Every stage input is made
+        readable first: band halo by affine extrapolation, then the boundary-condition ghosts."""
+        b, st = self.backend, self.state
+        n = len(self.terms)
+        phi = st.buf
+        name = self.integrator.name
+        T = lambda: _terms_c(self.terms)
+        sb = lambda psi, phin, out, out2, mode, c1, c2, t: b.stage_band(T(), n, psi, phin, out, out2, mode, c1, c2, t,
+                                                                      st.mask, st.tiles, st.MC)
+        fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)
+        st.prepare(phi)
+        self._update_terms(st, tc)
+        if name == "fe":
+            b.copy_(b1, phi)                     # copy!(dst, ϕ): non-band entries keep ϕ's (scratch) values
+            sb(phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            b.copy_(phi, b1)
+        elif name == "rk2":
+            sb(phi, None, b1, b2, L.BASE_PSI, dt, 0.5 * dt, tc)
+            st.prepare(b1)
+            self._update_terms(fld(b1), tc + dt)
+            sb(b1, b2, phi, None, L.BASE_OTHER, 0.5 * dt, 0.0, tc + dt)
+        else:
+            sb(phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            st.prepare(b1)
+            self._update_terms(fld(b1), tc + dt)
+            sb(b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
+            st.prepare(b2)
+            self._update_terms(fld(b2), tc + 0.5 * dt)
+            sb(b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
+        st.ghosts_dirty = True
+
+    def update_band(self):
+        """update_band!(ϕ) after an accepted step (src/timestepping.jl:115): no-op on a dense field."""
+        if self.band:
+            self.state.rebuild(from_dense=False)
 
     def _stage_slab(self, arr, n, psi, phin, out, out2, mode, cdt, cdt2, t):
         """One stage of a slab followed by its ghost resolution.  With overlap, the G+1 planes next to
@@ -801,6 +962,7 @@ def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
         ls._advance(tc, step)
         tc += step
         ls.t = tc
+        ls.update_band()   # re-tube before the posthook (no-op on a full grid) — src/timestepping.jl:115
         if posthook is not None:
             posthook(ls)
     ls.t = tf

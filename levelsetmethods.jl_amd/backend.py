@@ -136,6 +136,59 @@ class HipBackend:
                                                           nb_iters, cfl, interface_band, min_norm), "lsm_extend_along_normals")
         self.sync()   # the work buffers are released on return
 
+    # ---- narrow band (byte masks over the padded index space)
+    def alloc_mask(self):
+        return self.torch.zeros(int(self.lay.total), dtype=self.torch.uint8, device=self.device)
+
+    def band_update(self, vals, mask, from_dense, nlayers):
+        a, b = self.alloc_mask(), self.alloc_mask()
+        L.check(self.h, self.lib.lsm_band_update(self.h, self.ptr(vals), self.ptr(mask), 1 if from_dense else 0, int(nlayers),
+                                                 self.ptr(a), self.ptr(b)), "lsm_band_update")
+        self.sync()
+
+    def band_halo_mask(self, mask, radius, halo):
+        s = self.alloc_mask()
+        L.check(self.h, self.lib.lsm_band_halo_mask(self.h, self.ptr(mask), int(radius), self.ptr(halo), self.ptr(s)), "lsm_band_halo_mask")
+        self.sync()
+
+    def band_fill(self, vals, mask, halo):
+        L.check(self.h, self.lib.lsm_band_fill(self.h, self.ptr(vals), self.ptr(mask), self.ptr(halo)), "lsm_band_fill")
+
+    def band_tiles(self, mask, mc):
+        n = C.c_int64()
+        L.check(self.h, self.lib.lsm_band_tile_count(self.h, int(mc), C.byref(n)), "lsm_band_tile_count")
+        tiles = self.torch.zeros(int(n.value), dtype=self.torch.uint8, device=self.device)
+        L.check(self.h, self.lib.lsm_band_tiles(self.h, self.ptr(mask), int(mc), self.ptr(tiles)), "lsm_band_tiles")
+        return tiles
+
+    def band_count(self, mask):
+        n = C.c_int64()
+        L.check(self.h, self.lib.lsm_band_count(self.h, self.ptr(mask), C.byref(n)), "lsm_band_count")
+        return int(n.value)
+
+    def band_missed(self):
+        m = C.c_int()
+        L.check(self.h, self.lib.lsm_band_missed(self.h, C.byref(m)), "lsm_band_missed")
+        return bool(m.value)
+
+    def stage_band(self, terms_c, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, mask, tiles, mc):
+        L.check(self.h, self.lib.lsm_stage_band(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out), self.ptr(out2),
+                                                base_mode, cdt, cdt2, t, self.ptr(mask), self.ptr(tiles), int(mc), None), "lsm_stage_band")
+
+    def compute_cfl_band(self, terms_c, nterms, phi, mask, t):
+        dt = C.c_double(0.0)
+        L.check(self.h, self.lib.lsm_compute_cfl_band(self.h, terms_c, nterms, self.ptr(phi), self.ptr(mask), t, C.byref(dt)),
+                "lsm_compute_cfl_band")
+        return dt.value
+
+    def mask_to_host(self, mask):
+        """Boolean (local) interior of a mask, Fortran order."""
+        g = [int(self.lay.g[d]) for d in range(self.ndim)]
+        shape = tuple(int(self.lay.n[d]) + 2 * g[d] for d in range(self.ndim))
+        a = mask.cpu().numpy().reshape(shape, order="F")
+        sl = tuple(slice(g[d], g[d] + int(self.lay.n[d])) for d in range(self.ndim))
+        return a[sl].astype(bool)
+
     def volume_local(self, t):
         out = C.c_double()
         L.check(self.h, self.lib.lsm_volume(self.h, self.ptr(t), C.byref(out)), "lsm_volume")

@@ -2,6 +2,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <array>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +42,13 @@ struct LsmHandle {
     hipStream_t stream;
     bool own_stream;
     double* d_w;         // device copy of w
+    signed char* d_ring; // narrow band: distance-sorted offset ring
+    int nring;
+    int* d_miss;
+    unsigned long long* d_count;
+    const unsigned char* band_mask;    // set for the duration of a *_band call
+    const unsigned char* band_tiles;
+    int band_mc;
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
     double* d_result;    // 2 doubles
@@ -118,6 +127,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->cfl_cache_on = true;
+    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr;
+    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
     if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
@@ -191,6 +202,7 @@ void lsm_destroy(LsmHandle* h) {
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_flag);
     (void)hipFree(h->d_w);
+    if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
     (void)hipFree(h->d_result);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -301,6 +313,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     }
     a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
     a.dxmin = h->dxmin;
+    a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
 }
 
 static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
@@ -457,6 +470,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             fill_coeff(tm.coeff, t, a.coeff);
             a.partial = h->d_partial;
             a.nanflag = h->d_flag;
+            a.mask = h->band_mask;
             int nb = cfl_blocks(N, h->nloc);
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
@@ -621,6 +635,171 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
     }
     if (cur != F) LSM_HIP(h, hipMemcpyAsync(F, cur, sizeof(double) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));
     return LSM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrow band (NarrowBandMeshField, src/meshfield.jl:314-588) — see lsm_band.hip
+// ------------------------------------------------------------------------------------------------
+static const int BAND_SEARCH_RADIUS = 6;   // src/meshfield.jl:513
+
+static BandArgs band_args(const LsmHandle* h) {
+    BandArgs a;
+    a.ndim = h->grid.ndim;
+    for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
+    a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+    return a;
+}
+
+// _ring_offsets (src/meshfield.jl:515-520): all offsets of the (2R+1)^N box in column-major order,
+// stably sorted by squared length
+static int ensure_ring(LsmHandle* h) {
+    if (h->d_ring) return LSM_OK;
+    const int N = h->grid.ndim, R = BAND_SEARCH_RADIUS;
+    std::vector<std::array<signed char, 3>> off;
+    for (int z = (N > 2 ? -R : 0); z <= (N > 2 ? R : 0); ++z)
+        for (int y = (N > 1 ? -R : 0); y <= (N > 1 ? R : 0); ++y)
+            for (int x = -R; x <= R; ++x) off.push_back({(signed char)x, (signed char)y, (signed char)z});
+    std::stable_sort(off.begin(), off.end(), [](const std::array<signed char, 3>& p, const std::array<signed char, 3>& q) {
+        return p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    });
+    h->nring = (int)off.size();
+    LSM_HIP(h, hipMalloc((void**)&h->d_ring, off.size() * 3));
+    LSM_HIP(h, hipMemcpy(h->d_ring, off.data(), off.size() * 3, hipMemcpyHostToDevice));
+    LSM_HIP(h, hipMalloc((void**)&h->d_miss, sizeof(int)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_count, sizeof(unsigned long long)));
+    LSM_HIP(h, hipMemset(h->d_miss, 0, sizeof(int)));
+    return LSM_OK;
+}
+
+// update_band! (src/meshfield.jl:555-588).  mask: in = old band (ignored when from_dense), out = new
+// band.  Newly active nodes receive the affine extrapolant from the OLD band.  scratch_a/b: mask-sized.
+int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b) {
+    if (!h || !vals || !mask || !scratch_a || !scratch_b) return h ? fail(h, LSM_ERR_INVALID, "lsm_band_update: null argument") : LSM_ERR_INVALID;
+    if (nlayers < 0) return fail(h, LSM_ERR_INVALID, "lsm_band_update: nlayers must be >= 0");
+    const int N = h->grid.ndim;
+    for (int d = 0; d < N; ++d)
+        for (int sd = 0; sd < 2; ++sd)
+            if (h->bc[d][sd].kind == LSM_BC_PERIODIC)   // src/meshfield.jl:339-340
+                return fail(h, LSM_ERR_INVALID, "PeriodicBC is not supported on a NarrowBandMeshField");
+    LSM_TRY(ensure_ring(h));
+    const BandArgs a = band_args(h);
+    const size_t bytes = (size_t)h->lay.total;
+    unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
+    LSM_HIP(h, hipMemsetAsync(A, 0, bytes, h->stream));
+    LSM_HIP(h, hipMemsetAsync(B, 0, bytes, h->stream));
+    launch_band_cut(a, (const double*)vals, from_dense ? nullptr : (const unsigned char*)mask, A, h->stream);
+    for (int l = 0; l < nlayers; ++l) {
+        launch_band_dilate(a, A, B, h->stream);
+        unsigned char* t = A; A = B; B = t;
+    }
+    if (!from_dense)
+        launch_band_extrapolate(a, A, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals, (double*)vals, h->d_miss,
+                                h->stream);
+    LSM_HIP(h, hipMemcpyAsync(mask, A, bytes, hipMemcpyDeviceToDevice, h->stream));
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+// halo_mask := nodes within Chebyshev distance `radius` (<= 3) of the band (once per band update)
+int lsm_band_halo_mask(LsmHandle* h, const void* mask, int radius, void* halo_mask, void* scratch) {
+    if (!h || !mask || !halo_mask || !scratch) return LSM_ERR_INVALID;
+    if (radius < 0 || radius > LSM_GHOST) return fail(h, LSM_ERR_INVALID, "lsm_band_halo_mask: radius must be in 0..3");
+    const BandArgs a = band_args(h);
+    const int N = h->grid.ndim;
+    const size_t bytes = (size_t)h->lay.total;
+    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, bytes, h->stream));
+    LSM_HIP(h, hipMemsetAsync(scratch, 0, bytes, h->stream));
+    const unsigned char* in = (const unsigned char*)mask;
+    unsigned char* bufs[2] = {(unsigned char*)halo_mask, (unsigned char*)scratch};
+    int w = N % 2 == 1 ? 0 : 1;   // so that the last pass lands in halo_mask
+    for (int d = 0; d < N; ++d) {
+        launch_band_box_dilate(a, d, radius, in, bufs[w], h->stream);
+        in = bufs[w];
+        w ^= 1;
+    }
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+// ϕ[I] for the non-band nodes of the halo: _extrapolate_to_ghost materialised (src/meshfield.jl:481-511).
+// Call lsm_fill_ghosts afterwards for the out-of-grid layers.
+int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* halo_mask) {
+    if (!h || !vals || !mask || !halo_mask) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    launch_band_extrapolate(band_args(h), (const unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring,
+                            (const double*)vals, (double*)vals, h->d_miss, h->stream);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
+    if (!h || !ntiles || mc < 1) return LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    int tx, ty;
+    stage_tile_shape(N, &tx, &ty);
+    const int64_t nbx = (h->nloc[0] + tx - 1) / tx, nby = N == 3 ? (h->nloc[1] + ty - 1) / ty : 1;
+    const int64_t nbm = N >= 2 ? (h->nloc[N - 1] + mc - 1) / mc : 1;
+    *ntiles = nbx * nby * nbm;
+    return LSM_OK;
+}
+
+int lsm_band_tiles(LsmHandle* h, const void* mask, int mc, void* tiles) {
+    if (!h || !mask || !tiles || mc < 1) return LSM_ERR_INVALID;
+    const int N = h->grid.ndim;
+    int tx, ty;
+    stage_tile_shape(N, &tx, &ty);
+    const unsigned nbx = (h->nloc[0] + tx - 1) / tx, nby = N == 3 ? (h->nloc[1] + ty - 1) / ty : 1;
+    const unsigned nbm = N >= 2 ? (h->nloc[N - 1] + mc - 1) / mc : 1;
+    launch_band_tiles(band_args(h), tx, ty, mc, nbx, nby, nbm, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count) {
+    if (!h || !mask || !count) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    LSM_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(unsigned long long), h->stream));
+    launch_band_count(band_args(h), (const unsigned char*)mask, h->d_count, h->stream);
+    unsigned long long c = 0;
+    LSM_HIP(h, hipMemcpyAsync(&c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    *count = (int64_t)c;
+    return LSM_OK;
+}
+
+// a node asked for a value farther than the search radius from the band since the last call
+// (the reference throws ArgumentError, src/meshfield.jl:499-500)
+int lsm_band_missed(LsmHandle* h, int* missed) {
+    if (!h || !missed) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
+    return LSM_OK;
+}
+
+// one stage on the band: tiles without band nodes are skipped, only band nodes are stored
+int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+                   int base_mode, double cdt, double cdt2, double t_stage, const void* mask, const void* tiles, int mc,
+                   void* stream) {
+    if (!h || !mask) return LSM_ERR_INVALID;
+    h->band_mask = (const unsigned char*)mask;
+    h->band_tiles = (const unsigned char*)tiles;
+    h->band_mc = tiles ? mc : 0;
+    const int r = stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, 0, h->nloc[h->grid.ndim - 1], stream);
+    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
+    return r;
+}
+
+int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask, double t, double* dt_out) {
+    if (!h || !mask) return LSM_ERR_INVALID;
+    h->band_mask = (const unsigned char*)mask;
+    const bool keep = h->cfl_cache_on;
+    h->cfl_cache_on = false;            // the minimum runs over the current band only
+    const int r = lsm_compute_cfl(h, terms, nterms, phi, t, dt_out);
+    h->cfl_cache_on = keep;
+    h->band_mask = nullptr;
+    return r;
 }
 
 int lsm_cfl_cache(LsmHandle* h, int enable) {

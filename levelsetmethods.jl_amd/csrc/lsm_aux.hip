@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, con
         }
 #pragma unroll 2
         for (int m = mb; m < me; ++m) {
+            if (a.mask && !a.mask[cbase + (NDIM == 1 ? 0 : m * slast)]) continue;   // narrow band: active nodes only
             double u[3] = {0, 0, 0};
             if constexpr (CKIND == LSM_COEFF_CONST) {
 #pragma unroll

@@ -49,6 +49,9 @@ struct StageArgs {
     const double* s0;  // Eikonal frozen sign (NULL = current-sign mode)
     unsigned nb[3];    // tiles along x, y (3-D only) and march chunks — set by the launcher
     int mb, me;        // range [mb, me) of the march (last) dimension to update
+    int mc;            // planes per march chunk (0 = the tile's compile-time default)
+    const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
+    const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
 };
 
 struct GhostArgs {
@@ -84,7 +87,25 @@ struct CflArgs {
     CoeffArgs coeff;
     double* partial;     // one value per block
     int* nanflag;        // set to 1 if any node produced NaN
+    const unsigned char* mask;   // narrow band: only band nodes count (NULL = all nodes)
 };
+
+// narrow-band kernels (lsm_band.hip)
+struct BandArgs {
+    int ndim;
+    int n[3];
+    long long s1, s2, origin;
+};
+void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
+void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_box_dilate(const BandArgs& a, int dim, int r, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, const unsigned char* src_mask, const signed char* ring,
+                             int nring, const double* src, double* dst, int* miss, hipStream_t s);
+void launch_band_tiles(const BandArgs& a, int tx, int ty, int mc, unsigned nbx, unsigned nby, unsigned nbm, const unsigned char* mask,
+                       unsigned char* tiles, hipStream_t s);
+void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s);
+// tile geometry of the stage kernel for a given dimension and march chunk (stage_tu.hip)
+void stage_tile_shape(int ndim, int* tx, int* ty);
 
 // compile-time description of one instantiated fused kernel
 struct Combo {

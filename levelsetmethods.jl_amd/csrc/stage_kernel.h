@@ -354,6 +354,8 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- stage combination — src/timestepping.jl:129-136,147-163,172-200
     if (!active) return;
+    // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
+    if (a.mask && !*(reinterpret_cast<const unsigned char*>(a.mask) + io.plane_off + (io.ocol >> 3))) return;
     double base;
     if (a.base_mode == LSM_BASE_PSI) base = c;
     else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * ldg(a.phin + io.plane_off, io.ocol) + 0.25 * c;
@@ -412,6 +414,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     const unsigned per_xcd = (ntiles + 7u) / 8u;
     const unsigned tile_id = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
     if (tile_id >= ntiles) return;   // whole workgroup leaves before any barrier
+    if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
     const unsigned tbx = tile_id % a.nb[0];
     const unsigned tby = (tile_id / a.nb[0]) % a.nb[1];
     const unsigned tbm = tile_id / (a.nb[0] * a.nb[1]);
@@ -434,8 +437,9 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
     const unsigned ocol = 8u * ((unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
-    const int m0 = MARCH ? a.mb + (int)tbm * MC : 0;
-    const int m1 = MARCH ? (m0 + MC < a.me ? m0 + MC : a.me) : 1;
+    const int mc = a.mc > 0 ? a.mc : MC;
+    const int m0 = MARCH ? a.mb + (int)tbm * mc : 0;
+    const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
     auto plane = [&](int p) { return a.psi + (corner + (long long)clampM(p) * sm); };
@@ -567,7 +571,8 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     StageArgs b = a;
     b.nb[0] = (a.n[0] + T::TX - 1) / T::TX;
     b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
-    b.nb[2] = NDIM >= 2 ? (a.me - a.mb + T::MC - 1) / T::MC : 1;
+    const int mc = a.mc > 0 ? a.mc : T::MC;
+    b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
     if (NDIM >= 2 && a.me <= a.mb) return;
     const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);

@@ -25,4 +25,13 @@ int LSM_CAT(launch_stage_fast_, LSM_TU_NDIM, d)(const Combo& c, const StageArgs&
 #endif
     return LSM_NS::launch_ndim<LSM_TU_NDIM>(c, a, s);
 }
+
+#if !LSM_STRICT && LSM_TU_NDIM == 3
+// tile footprint of the stage kernel per dimension (the narrow-band tile flags must match it)
+void stage_tile_shape(int ndim, int* tx, int* ty) {
+    if (ndim == 1) { *tx = LSM_NS::TileCfg<1>::TX; *ty = 1; }
+    else if (ndim == 2) { *tx = LSM_NS::TileCfg<2>::TX; *ty = 1; }
+    else { *tx = LSM_NS::TileCfg<3>::TX; *ty = LSM_NS::TileCfg<3>::TY; }
+}
+#endif
 }  // namespace lsm
