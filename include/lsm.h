@@ -213,25 +213,41 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
  *      (allocate LsmLayout.total bytes; ghost entries stay 0).  Values stay in the dense padded array.
  *      PeriodicBC is rejected, as in the reference (:339-340).
  *
- *      lsm_band_update      update_band! (:555-588): cut cells of the band (or of the whole grid when
- *                           from_dense != 0) seed their corners, nlayers L1 dilations grow the new band,
- *                           newly active nodes get the affine extrapolant from the OLD band; mask is
- *                           replaced.  scratch_a/b: two more mask-sized buffers.
- *      lsm_band_halo_mask   nodes within Chebyshev distance radius (<= 3) of the band
- *      lsm_band_fill        _extrapolate_to_ghost (:481-511) materialised on halo & !band nodes, so that
- *                           stencils read plain entries; follow with lsm_fill_ghosts for out-of-grid layers
- *      lsm_band_tiles       per-tile activity flags for lsm_stage_band (lsm_band_tile_count gives the size)
+ *      lsm_band_update      update_band! (:555-588) and everything derived from the new band in one call:
+ *                           cut cells of the band (or of the whole grid when from_dense != 0) seed their
+ *                           corners, nlayers L1 dilations grow the new band, newly active nodes get the
+ *                           affine extrapolant from the OLD band; mask is replaced; tiles := per-tile
+ *                           activity flags (size: lsm_band_tile_count; tile = the stage kernel's brick
+ *                           with mc planes; on entry the OLD band's flags unless from_dense); then
+ *                           lsm_band_halo on the new band.  scratch_a/b: mask-sized.
+ *      lsm_band_halo        halo_mask := the in-grid nodes a stencil centred on a band node reads — up to
+ *                           3 nodes along each axis, the 3^N box, and the in-grid nodes out-of-grid
+ *                           positions resolve to through _getindexbc (:248-260);  halo_list := one 16-byte
+ *                           entry per non-band halo node naming its nearest band node
+ *                           (_nearest_band_node, :513-530 — a function of the mask alone, so it is found
+ *                           once per band).  halo_count: device uint32, receives the number of entries
+ *                           wanted; if it exceeds halo_cap the list is truncated — repeat with a larger one.
+ *      lsm_band_fill_list   _extrapolate_to_ghost (:481-511) materialised on the halo from halo_list, so that
+ *                           stencils read plain entries; follow with lsm_fill_ghosts for the out-of-grid
+ *                           layers.  Called on every stage input.
+ *      lsm_band_fill        the same by a fresh search for targets & !band nodes; tiles = NULL visits the whole
+ *                           grid (scalar getindex path).
  *      lsm_stage_band       lsm_stage restricted to band nodes (tiles without band nodes are skipped)
  *      lsm_compute_cfl_band compute_cfl over active_nodeindices
  *      lsm_band_count       number of active nodes;  lsm_band_missed: a value was requested farther than
- *                           the search radius (6) from the band since the last call (the reference throws) */
-int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b);
-int lsm_band_halo_mask(LsmHandle* h, const void* mask, int radius, void* halo_mask, void* scratch);
-int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* halo_mask);
+ *                           the search radius (6) from the band since the last call (the reference throws);
+ *      lsm_band_status      lsm_band_missed and *halo_count in one synchronisation */
 int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles);
-int lsm_band_tiles(LsmHandle* h, const void* mask, int mc, void* tiles);
+int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b,
+                    void* halo_mask, void* tiles, int mc, void* halo_list, int64_t halo_cap, void* halo_count);
+int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc,
+                  void* halo_list, int64_t halo_cap, void* halo_count);
+int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,
+                       const void* halo_count);
+int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* targets, const void* tiles, int mc);
 int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count);
 int lsm_band_missed(LsmHandle* h, int* missed);
+int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* missed);
 int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out,
                    void* out2, int base_mode, double cdt, double cdt2, double t_stage, const void* mask,
                    const void* tiles, int mc, void* stream);

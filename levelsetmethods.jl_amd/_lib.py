@@ -85,11 +85,13 @@ _SIGS = [
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("lsm_extend_along_normals", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_double, C.c_double, C.c_double]),
-    ("lsm_band_update", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    ("lsm_band_halo_mask", C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    ("lsm_band_fill", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_band_tile_count", C.c_int, [_H, C.c_int, C.POINTER(C.c_int64)]),
-    ("lsm_band_tiles", C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
+    ("lsm_band_update", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    ("lsm_band_halo", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("lsm_band_fill_list", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("lsm_band_status", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("lsm_band_fill", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("lsm_band_count", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int64)]),
     ("lsm_band_missed", C.c_int, [_H, C.POINTER(C.c_int)]),
     ("lsm_stage_band", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -334,19 +334,34 @@ class ROCNarrowBandMeshField(ROCMeshField):
         self.nlayers = int(nlayers)
         self.mask = backend.alloc_mask()
         self.halo = backend.alloc_mask()
-        self.tiles = None
+        self.tiles = backend.alloc_tiles(self.MC)
+        self._scratch = (backend.alloc_mask(), backend.alloc_mask())   # reused by every rebuild
+        self._hlist = self._hcount = None
 
     def rebuild(self, from_dense=False):
-        """update_band! (src/meshfield.jl:555-588) + the derived halo mask and tile flags."""
+        """update_band! (src/meshfield.jl:555-588) + what is derived from the new band: tile flags, the
+        halo mask and the (halo node -> nearest band node) list every stage input is filled from."""
         b = self.backend
-        b.band_update(self.buf, self.mask, from_dense, self.nlayers)
-        b.band_halo_mask(self.mask, self.HALO, self.halo)
-        self.tiles = b.band_tiles(self.mask, self.MC)
+        if self._hlist is None:
+            self._hlist, self._hcount = b.alloc_halo_list(1 << 16)
+        b.band_update(self.buf, self.mask, from_dense, self.nlayers, self._scratch[0], self._scratch[1], self.halo,
+                      self.tiles, self.MC, self._hlist, self._hcount)
+        self._check_halo()
         self.ghosts_dirty = True
+
+    def _check_halo(self):
+        b = self.backend
+        want, missed = b.band_status(self._hcount)
+        if want > self._hlist.numel() // 2:          # list too short: grow it and search again
+            self._hlist, self._hcount = b.alloc_halo_list(2 * want)
+            b.band_halo(self.buf, self.mask, self.halo, self.tiles, self.MC, self._hlist, self._hcount)
+            want, missed = b.band_status(self._hcount)
+        if missed:                                   # src/meshfield.jl:499-500
+            raise ValueError("a stencil of the band reads a node more than 6 nodes away from every band node")
 
     def prepare(self, buf):
         """Make `buf` readable by stencils: band halo (extrapolation) then out-of-grid ghosts (BCs)."""
-        self.backend.band_fill(buf, self.mask, self.halo)
+        self.backend.band_fill_list(buf, self.mask, self._hlist, self._hcount)
         self.backend.fill_ghosts(buf, 7)
 
     def active_mask(self):
@@ -368,7 +383,9 @@ class ROCNarrowBandMeshField(ROCMeshField):
         c = ROCNarrowBandMeshField(self.backend, self.mesh, self.bcs, self.nlayers, self.backend.clone(self.buf))
         c.mask.copy_(self.mask)
         c.halo.copy_(self.halo)
-        c.tiles = None if self.tiles is None else self.tiles.clone()
+        c.tiles.copy_(self.tiles)
+        if self._hlist is not None:
+            c._hlist, c._hcount = self._hlist.clone(), self._hcount.clone()
         return c
 
     def __getitem__(self, I):
@@ -381,7 +398,7 @@ class ROCNarrowBandMeshField(ROCMeshField):
             if not bool(self.mask[off].item()):
                 t = self.backend.alloc_mask()
                 t[off] = 1
-                self.backend.band_fill(self.buf, self.mask, t)
+                self.backend.band_fill(self.buf, self.mask, t, None, self.MC)   # whole grid: the node may be far from the band
                 if self.backend.band_missed():
                     raise ValueError(f"index {I} is more than 6 nodes from the band")
             return float(self.buf[off].item())

@@ -140,26 +140,40 @@ class HipBackend:
     def alloc_mask(self):
         return self.torch.zeros(int(self.lay.total), dtype=self.torch.uint8, device=self.device)
 
-    def band_update(self, vals, mask, from_dense, nlayers):
-        a, b = self.alloc_mask(), self.alloc_mask()
-        L.check(self.h, self.lib.lsm_band_update(self.h, self.ptr(vals), self.ptr(mask), 1 if from_dense else 0, int(nlayers),
-                                                 self.ptr(a), self.ptr(b)), "lsm_band_update")
-        self.sync()
-
-    def band_halo_mask(self, mask, radius, halo):
-        s = self.alloc_mask()
-        L.check(self.h, self.lib.lsm_band_halo_mask(self.h, self.ptr(mask), int(radius), self.ptr(halo), self.ptr(s)), "lsm_band_halo_mask")
-        self.sync()
-
-    def band_fill(self, vals, mask, halo):
-        L.check(self.h, self.lib.lsm_band_fill(self.h, self.ptr(vals), self.ptr(mask), self.ptr(halo)), "lsm_band_fill")
-
-    def band_tiles(self, mask, mc):
+    def band_tile_count(self, mc):
         n = C.c_int64()
         L.check(self.h, self.lib.lsm_band_tile_count(self.h, int(mc), C.byref(n)), "lsm_band_tile_count")
-        tiles = self.torch.zeros(int(n.value), dtype=self.torch.uint8, device=self.device)
-        L.check(self.h, self.lib.lsm_band_tiles(self.h, self.ptr(mask), int(mc), self.ptr(tiles)), "lsm_band_tiles")
-        return tiles
+        return int(n.value)
+
+    def alloc_tiles(self, mc):
+        return self.torch.zeros(self.band_tile_count(mc), dtype=self.torch.uint8, device=self.device)
+
+    def alloc_halo_list(self, cap):
+        """(entries, counter): 16-byte (node, nearest band node) records and the device uint32 count."""
+        return (self.torch.empty(2 * int(cap), dtype=self.torch.int64, device=self.device),
+                self.torch.zeros(1, dtype=self.torch.int32, device=self.device))
+
+    def band_update(self, vals, mask, from_dense, nlayers, scratch_a, scratch_b, halo, tiles, mc, hlist, hcount):
+        L.check(self.h, self.lib.lsm_band_update(self.h, self.ptr(vals), self.ptr(mask), 1 if from_dense else 0, int(nlayers),
+                                                 self.ptr(scratch_a), self.ptr(scratch_b), self.ptr(halo), self.ptr(tiles), int(mc),
+                                                 self.ptr(hlist), hlist.numel() // 2, self.ptr(hcount)), "lsm_band_update")
+
+    def band_halo(self, vals, mask, halo, tiles, mc, hlist, hcount):
+        L.check(self.h, self.lib.lsm_band_halo(self.h, self.ptr(vals), self.ptr(mask), self.ptr(halo), self.ptr(tiles), int(mc),
+                                               self.ptr(hlist), hlist.numel() // 2, self.ptr(hcount)), "lsm_band_halo")
+
+    def band_fill_list(self, vals, mask, hlist, hcount):
+        L.check(self.h, self.lib.lsm_band_fill_list(self.h, self.ptr(vals), self.ptr(mask), self.ptr(hlist), hlist.numel() // 2,
+                                                    self.ptr(hcount)), "lsm_band_fill_list")
+
+    def band_status(self, hcount):
+        n, m = C.c_int64(), C.c_int()
+        L.check(self.h, self.lib.lsm_band_status(self.h, self.ptr(hcount), C.byref(n), C.byref(m)), "lsm_band_status")
+        return int(n.value), bool(m.value)
+
+    def band_fill(self, vals, mask, targets, tiles, mc):
+        L.check(self.h, self.lib.lsm_band_fill(self.h, self.ptr(vals), self.ptr(mask), self.ptr(targets), self.ptr(tiles), int(mc)),
+                "lsm_band_fill")
 
     def band_count(self, mask):
         n = C.c_int64()

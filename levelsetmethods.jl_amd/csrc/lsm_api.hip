@@ -46,6 +46,8 @@ struct LsmHandle {
     int nring;
     int* d_miss;
     unsigned long long* d_count;
+    unsigned char* d_work;             // per-tile work flags (narrow band)
+    int64_t work_cap;
     const unsigned char* band_mask;    // set for the duration of a *_band call
     const unsigned char* band_tiles;
     int band_mc;
@@ -127,7 +129,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->cfl_cache_on = true;
-    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr;
+    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
@@ -203,6 +205,7 @@ void lsm_destroy(LsmHandle* h) {
     (void)hipFree(h->d_flag);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
+    if (h->d_work) (void)hipFree(h->d_work);
     (void)hipFree(h->d_result);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -642,11 +645,17 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
 // ------------------------------------------------------------------------------------------------
 static const int BAND_SEARCH_RADIUS = 6;   // src/meshfield.jl:513
 
-static BandArgs band_args(const LsmHandle* h) {
+static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work) {
     BandArgs a;
     a.ndim = h->grid.ndim;
     for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
     a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+    stage_tile_shape(a.ndim, &a.tx, &a.ty);
+    a.tm = mc;
+    a.nbx = (h->nloc[0] + a.tx - 1) / a.tx;
+    a.nby = a.ndim == 3 ? (h->nloc[1] + a.ty - 1) / a.ty : 1;
+    a.nbm = a.ndim >= 2 ? (h->nloc[a.ndim - 1] + mc - 1) / mc : 1;
+    a.work = work;
     return a;
 }
 
@@ -671,18 +680,53 @@ static int ensure_ring(LsmHandle* h) {
     return LSM_OK;
 }
 
-// update_band! (src/meshfield.jl:555-588).  mask: in = old band (ignored when from_dense), out = new
-// band.  Newly active nodes receive the affine extrapolant from the OLD band.  scratch_a/b: mask-sized.
-int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b) {
-    if (!h || !vals || !mask || !scratch_a || !scratch_b) return h ? fail(h, LSM_ERR_INVALID, "lsm_band_update: null argument") : LSM_ERR_INVALID;
-    if (nlayers < 0) return fail(h, LSM_ERR_INVALID, "lsm_band_update: nlayers must be >= 0");
+// handle-owned scratch for the per-tile work flags
+static int ensure_work(LsmHandle* h, int64_t ntiles) {
+    if (h->work_cap >= ntiles) return LSM_OK;
+    if (h->d_work) (void)hipFree(h->d_work);
+    LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
+    h->work_cap = ntiles;
+    return LSM_OK;
+}
+
+int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
+    if (!h || !ntiles || mc < 1) return LSM_ERR_INVALID;
+    const BandArgs a = band_args(h, mc, nullptr);
+    *ntiles = (int64_t)a.nbx * a.nby * a.nbm;
+    return LSM_OK;
+}
+
+// update_band! (src/meshfield.jl:555-588) and everything derived from the new band, in one call:
+//   mask      in: old band (ignored when from_dense), out: new band
+//   tiles     in: active tiles of the old band (ignored when from_dense), out: active tiles of the new band
+//   halo_mask out: nodes within Chebyshev distance 3 of the new band
+// Newly active nodes receive the affine extrapolant from the OLD band.  scratch_a/b: mask-sized buffers.
+int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
+                  int64_t halo_cap, void* halo_count);
+int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b,
+                    void* halo_mask, void* tiles, int mc, void* halo_list, int64_t halo_cap, void* halo_count) {
+    if (!h || !vals || !mask || !scratch_a || !scratch_b || !halo_mask || !tiles)
+        return h ? fail(h, LSM_ERR_INVALID, "lsm_band_update: null argument") : LSM_ERR_INVALID;
+    if (nlayers < 0 || mc < 1) return fail(h, LSM_ERR_INVALID, "lsm_band_update: nlayers must be >= 0 and mc >= 1");
     const int N = h->grid.ndim;
     for (int d = 0; d < N; ++d)
         for (int sd = 0; sd < 2; ++sd)
             if (h->bc[d][sd].kind == LSM_BC_PERIODIC)   // src/meshfield.jl:339-340
                 return fail(h, LSM_ERR_INVALID, "PeriodicBC is not supported on a NarrowBandMeshField");
     LSM_TRY(ensure_ring(h));
-    const BandArgs a = band_args(h);
+    BandArgs a = band_args(h, mc, nullptr);
+    const int64_t ntiles = (int64_t)a.nbx * a.nby * a.nbm;
+    LSM_TRY(ensure_work(h, ntiles));
+    // The new band grows out of cut cells of the OLD band, so it lies within nlayers nodes of it and its halo
+    // within nlayers + 3: all inside the old band's tiles and their neighbours as long as a tile is at least
+    // that thick (8 nodes in its thinnest direction); wider bands fall back to visiting every tile.
+    int tmin = a.tx;
+    if (N == 3) tmin = a.ty < tmin ? a.ty : tmin;
+    if (N >= 2) tmin = a.tm < tmin ? a.tm : tmin;
+    if (!from_dense && nlayers + LSM_GHOST <= tmin) {
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        a.work = h->d_work;
+    }
     const size_t bytes = (size_t)h->lay.total;
     unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
     LSM_HIP(h, hipMemsetAsync(A, 0, bytes, h->stream));
@@ -694,63 +738,68 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     }
     if (!from_dense)
         launch_band_extrapolate(a, A, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals, (double*)vals, h->d_miss,
-                                h->stream);
-    LSM_HIP(h, hipMemcpyAsync(mask, A, bytes, hipMemcpyDeviceToDevice, h->stream));
+                                nullptr, nullptr, 0, h->stream);
+    if (from_dense) LSM_HIP(h, hipMemcpyAsync(mask, A, bytes, hipMemcpyDeviceToDevice, h->stream));
+    else launch_band_copy(a, A, (unsigned char*)mask, h->stream);   // the old band lies inside the work tiles
+    // tiles of the new band; everything below lies in them or their neighbours (a BC source is at most 7 < 8 nodes
+    // from the band node whose stencil resolves to it)
+    launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
     LSM_HIP(h, hipGetLastError());
-    return LSM_OK;
+    return lsm_band_halo(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count);
 }
 
-// halo_mask := nodes within Chebyshev distance `radius` (<= 3) of the band (once per band update)
-int lsm_band_halo_mask(LsmHandle* h, const void* mask, int radius, void* halo_mask, void* scratch) {
-    if (!h || !mask || !halo_mask || !scratch) return LSM_ERR_INVALID;
-    if (radius < 0 || radius > LSM_GHOST) return fail(h, LSM_ERR_INVALID, "lsm_band_halo_mask: radius must be in 0..3");
-    const BandArgs a = band_args(h);
+// halo_mask := the in-grid nodes stencils centred on band nodes read, directly (axis lines of length LSM_GHOST and
+// the 3^N box) or through the boundary conditions; halo_list := for each of them outside the band, its nearest band
+// node (a function of the mask alone: found once per band, applied to every stage input by lsm_band_fill_list).
+// *halo_count may exceed halo_cap: the list is then truncated and the call must be repeated with a larger one.
+int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
+                  int64_t halo_cap, void* halo_count) {
+    if (!h || !vals || !mask || !halo_mask || !tiles || mc < 1) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    BandArgs a = band_args(h, mc, nullptr);
+    LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
+    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+    a.work = h->d_work;
     const int N = h->grid.ndim;
-    const size_t bytes = (size_t)h->lay.total;
-    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, bytes, h->stream));
-    LSM_HIP(h, hipMemsetAsync(scratch, 0, bytes, h->stream));
-    const unsigned char* in = (const unsigned char*)mask;
-    unsigned char* bufs[2] = {(unsigned char*)halo_mask, (unsigned char*)scratch};
-    int w = N % 2 == 1 ? 0 : 1;   // so that the last pass lands in halo_mask
-    for (int d = 0; d < N; ++d) {
-        launch_band_box_dilate(a, d, radius, in, bufs[w], h->stream);
-        in = bufs[w];
-        w ^= 1;
+    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
+    launch_band_cross(a, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
+    BandBcArgs bc;
+    for (int d = 0; d < 3; ++d)
+        for (int sd = 0; sd < 2; ++sd) { bc.kind[d][sd] = d < N ? h->bc[d][sd].kind : LSM_BC_NONE; bc.degree[d][sd] = d < N ? h->bc[d][sd].degree : 0; }
+    for (int d = N - 1; d >= 0; --d)
+        launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
+    if (halo_list && halo_count) {
+        LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
+        launch_band_extrapolate(a, (const unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals,
+                                nullptr, h->d_miss, (BandEntry*)halo_list, (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
     }
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
 
-// ϕ[I] for the non-band nodes of the halo: _extrapolate_to_ghost materialised (src/meshfield.jl:481-511).
-// Call lsm_fill_ghosts afterwards for the out-of-grid layers.
-int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* halo_mask) {
-    if (!h || !vals || !mask || !halo_mask) return LSM_ERR_INVALID;
+// ϕ[I] for the non-band nodes flagged in `targets`: _extrapolate_to_ghost materialised
+// (src/meshfield.jl:481-511) by a fresh nearest-node search over the whole grid (scalar getindex path).
+int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* targets, const void* tiles, int mc) {
+    if (!h || !vals || !mask || !targets || mc < 1) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
-    launch_band_extrapolate(band_args(h), (const unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring,
-                            (const double*)vals, (double*)vals, h->d_miss, h->stream);
+    BandArgs a = band_args(h, mc, nullptr);
+    if (tiles) {
+        LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        a.work = h->d_work;
+    }
+    launch_band_extrapolate(a, (const unsigned char*)targets, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals,
+                            (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
 
-int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
-    if (!h || !ntiles || mc < 1) return LSM_ERR_INVALID;
-    const int N = h->grid.ndim;
-    int tx, ty;
-    stage_tile_shape(N, &tx, &ty);
-    const int64_t nbx = (h->nloc[0] + tx - 1) / tx, nby = N == 3 ? (h->nloc[1] + ty - 1) / ty : 1;
-    const int64_t nbm = N >= 2 ? (h->nloc[N - 1] + mc - 1) / mc : 1;
-    *ntiles = nbx * nby * nbm;
-    return LSM_OK;
-}
-
-int lsm_band_tiles(LsmHandle* h, const void* mask, int mc, void* tiles) {
-    if (!h || !mask || !tiles || mc < 1) return LSM_ERR_INVALID;
-    const int N = h->grid.ndim;
-    int tx, ty;
-    stage_tile_shape(N, &tx, &ty);
-    const unsigned nbx = (h->nloc[0] + tx - 1) / tx, nby = N == 3 ? (h->nloc[1] + ty - 1) / ty : 1;
-    const unsigned nbm = N >= 2 ? (h->nloc[N - 1] + mc - 1) / mc : 1;
-    launch_band_tiles(band_args(h), tx, ty, mc, nbx, nby, nbm, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
+// The same for the halo of the band, from the (node, nearest band node) list lsm_band_update prepared:
+// a gather per stage input.  Call lsm_fill_ghosts afterwards for the out-of-grid layers.
+int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap, const void* halo_count) {
+    if (!h || !vals || !mask || !halo_list || !halo_count) return LSM_ERR_INVALID;
+    launch_band_apply(band_args(h, 8, nullptr), (const BandEntry*)halo_list, (const unsigned*)halo_count, (unsigned)halo_cap,
+                      (const unsigned char*)mask, (const double*)vals, (double*)vals, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
@@ -759,7 +808,7 @@ int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count) {
     if (!h || !mask || !count) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
     LSM_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(unsigned long long), h->stream));
-    launch_band_count(band_args(h), (const unsigned char*)mask, h->d_count, h->stream);
+    launch_band_count(band_args(h, 8, nullptr), (const unsigned char*)mask, h->d_count, h->stream);
     unsigned long long c = 0;
     LSM_HIP(h, hipMemcpyAsync(&c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
@@ -775,6 +824,19 @@ int lsm_band_missed(LsmHandle* h, int* missed) {
     LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
+    return LSM_OK;
+}
+
+// lsm_band_missed + the number of entries the last lsm_band_halo wanted to write, in one synchronisation
+int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* missed) {
+    if (!h || !halo_count || !count || !missed) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    unsigned c = 0;
+    LSM_HIP(h, hipMemcpyAsync(&c, halo_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    if (*missed) LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
+    *count = (int64_t)c;
     return LSM_OK;
 }
 

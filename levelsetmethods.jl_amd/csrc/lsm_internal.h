@@ -95,14 +95,30 @@ struct BandArgs {
     int ndim;
     int n[3];
     long long s1, s2, origin;
+    int tx, ty, tm;              // tile footprint (x, y [3-D only], last dimension): the stage kernel's bricks
+    unsigned nbx, nby, nbm;      // tiles per direction
+    const unsigned char* work;   // per-tile flags: tiles to visit (NULL = all)
 };
+void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_box_dilate(const BandArgs& a, int dim, int r, const unsigned char* in, unsigned char* out, hipStream_t s);
+struct BandEntry {          // a halo node and its nearest band node (16 bytes)
+    long long q;            // padded index of the node
+    int rel;                // padded index of the nearest band node minus q
+    signed char d[4];       // I - P per dimension
+};
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, const unsigned char* src_mask, const signed char* ring,
-                             int nring, const double* src, double* dst, int* miss, hipStream_t s);
-void launch_band_tiles(const BandArgs& a, int tx, int ty, int mc, unsigned nbx, unsigned nby, unsigned nbm, const unsigned char* mask,
-                       unsigned char* tiles, hipStream_t s);
+                             int nring, const double* src, double* dst, int* miss, BandEntry* list, unsigned* list_count,
+                             unsigned list_cap, hipStream_t s);
+void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
+                       const unsigned char* src_mask, const double* src, double* dst, hipStream_t s);
+struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
+void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
+                         hipStream_t s);
+void launch_band_cross(const BandArgs& a, int r, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned char* tiles, hipStream_t s);
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s);
 // tile geometry of the stage kernel for a given dimension and march chunk (stage_tu.hip)
 void stage_tile_shape(int ndim, int* tx, int* ty);

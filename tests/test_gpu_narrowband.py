@@ -197,3 +197,87 @@ def test_integrate_full_rotation_and_curvature_match_full_grid(lsm):
     frac = nb3.current_state().active_count() / 40 ** 3
     assert 0.02 < frac < 0.5
     assert _nb_full_error(nb3.current_state(), full3.current_state().values(), 3, min(g3.meshsize())) < 0.01
+
+
+@pytest.mark.parametrize("shape,bcspec", [
+    ((30, 26), [("extrapolation", 5), ("symmetry", ("extrapolation", 2))]),
+    ((26, 30), [("symmetry", "neumann"), ("extrapolation", 4)]),
+    ((14, 12, 16), [("extrapolation", 3), ("symmetry", "linear"), ("extrapolation", 2)]),
+])
+def test_band_stage_reads_reference_values_at_the_grid_boundary(shape, bcspec):
+    """A band that runs into the grid boundary: every position a band node's stencil reads — in the grid
+    (stored or extrapolated from the nearest band node) or outside it (resolved by _getindexbc over those
+    values, src/meshfield.jl:248-260,475-511) — must hold the reference's value, and a stage over the band
+    must equal the reference stage evaluated on those values.  Through the C ABI, strict mode."""
+    import itertools
+    import _hip as hip
+    from _nb_ref import NBRef
+    from lsm_amd import _lib as L
+    from oracle import oracle as orc
+    nd = len(shape)
+    c = hip.Case(shape, bcspec, mode="strict")
+    ax = [np.linspace(-1.0, 1.0, n) for n in shape]
+    X = np.meshgrid(*ax, indexing="ij")
+    ctr = (-0.85, -0.7, 0.75)
+    phi = np.asfortranarray(np.sqrt(sum((X[d] - ctr[d]) ** 2 for d in range(nd))) - 0.62)
+    ref = NBRef(phi, 3)
+    band = ref.mask()
+    assert band[0].any() and band[:, 0].any()          # the band touches the low faces
+
+    be = c.be
+    vals = c.to_dev(c.pad(phi, fill=False))
+    mask, halo, sa, sb = (be.alloc_mask() for _ in range(4))
+    MC = 8
+    tiles = be.alloc_tiles(MC)
+    hlist, hcount = be.alloc_halo_list(64)             # deliberately too short: exercises the regrow path
+    be.band_update(vals, mask, True, 3, sa, sb, halo, tiles, MC, hlist, hcount)
+    want_n, missed = be.band_status(hcount)
+    assert want_n > 64 and not missed
+    hlist, hcount = be.alloc_halo_list(want_n)
+    be.band_halo(vals, mask, halo, tiles, MC, hlist, hcount)
+    assert be.band_status(hcount) == (want_n, False)
+    assert np.array_equal(be.mask_to_host(mask), band)
+
+    # the reference's view of the field: stored values on the band, the affine extrapolant elsewhere
+    D = np.zeros(shape, order="F")
+    known = np.zeros(shape, dtype=bool)
+    for I in np.ndindex(*shape):
+        try:
+            D[I] = ref.get(I)
+            known[I] = True
+        except ValueError:
+            pass
+    psi = c.pad(D)                                     # + _getindexbc ghosts (oracle, bitwise-checked elsewhere)
+    kpad = c.pad(known.astype(np.float64)) != 0        # crude: which padded entries derive from known nodes only
+
+    be.band_fill_list(vals, mask, hlist, hcount)
+    be.fill_ghosts(vals, 7)
+    got = c.to_host(vals)
+    G = 3
+    offs = set()
+    for d in range(nd):
+        for k in range(-3, 4):
+            offs.add(tuple(k if e == d else 0 for e in range(nd)))
+    offs |= set(itertools.product((-1, 0, 1), repeat=nd))
+    nread = 0
+    for I in np.argwhere(band):
+        for o in offs:
+            J = tuple(int(I[d]) + o[d] + G for d in range(nd))
+            assert got[J] == psi[J], (tuple(I), o, got[J], psi[J])
+            nread += 1
+    assert nread > 1000
+
+    specs = [("adv", ("const", (0.7, -0.4, 0.3)[:nd]), "weno5"), ("nm", ("const", (0.5,))), ("curv", ("const", (-0.05,)))]
+    for sub in ([specs[0]], [specs[1]], specs[1:], [specs[0], specs[2]]):
+        ot, arr = c.terms(sub)
+        cdt = 2.0e-3
+        want = np.full_like(psi, np.nan)
+        orc.stage_padded(c.grid, c.bc, c.olay, ot, psi, None, want, None, L.BASE_PSI, cdt, 0.0, 0.1)
+        out = c.to_dev(np.zeros_like(psi))
+        be.stage_band(arr, len(sub), vals, None, out, None, L.BASE_PSI, cdt, 0.0, 0.1, mask, tiles, MC)
+        g, w = c.interior(c.to_host(out)), c.interior(want)
+        if any(s[0] == "curv" for s in sub):
+            assert np.abs(g[band] - w[band]).max() <= 1e-13 * np.abs(w[band]).max()
+        else:
+            assert np.array_equal(g[band], w[band])
+        assert np.all(g[~band] == 0.0)                 # only band nodes are stored
