@@ -230,13 +230,18 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
  *      lsm_band_fill_list   _extrapolate_to_ghost (:481-511) materialised on the halo from halo_list, so that
  *                           stencils read plain entries; follow with lsm_fill_ghosts for the out-of-grid
  *                           layers.  Called on every stage input.
+ *      lsm_band_prepare     lsm_band_fill_list + lsm_fill_ghosts in one call (the ghost fill is skipped while the
+ *                           band stays a tile away from every face of the grid).
  *      lsm_band_fill        the same by a fresh search for targets & !band nodes; tiles = NULL visits the whole
  *                           grid (scalar getindex path).
  *      lsm_stage_band       lsm_stage restricted to band nodes (tiles without band nodes are skipped)
- *      lsm_compute_cfl_band compute_cfl over active_nodeindices
+ *      lsm_compute_cfl_band compute_cfl over active_nodeindices (tiles/mc: optional tile flags, to step over empty tiles)
  *      lsm_band_count       number of active nodes;  lsm_band_missed: a value was requested farther than
  *                           the search radius (6) from the band since the last call (the reference throws);
- *      lsm_band_status      lsm_band_missed and *halo_count in one synchronisation */
+ *      lsm_band_status      lsm_band_missed and *halo_count in one synchronisation.  It also brings the lengths
+ *                           of the compact tile lists lsm_band_update built on the device to the host: from
+ *                           then on band kernels launch one block per listed tile instead of one per tile
+ *                           (without the call everything still works, over all tiles). */
 int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles);
 int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b,
                     void* halo_mask, void* tiles, int mc, void* halo_list, int64_t halo_cap, void* halo_count);
@@ -244,6 +249,8 @@ int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_m
                   void* halo_list, int64_t halo_cap, void* halo_count);
 int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,
                        const void* halo_count);
+int lsm_band_prepare(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,
+                     const void* halo_count, const void* tiles, int mc);
 int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* targets, const void* tiles, int mc);
 int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count);
 int lsm_band_missed(LsmHandle* h, int* missed);
@@ -252,7 +259,7 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
                    void* out2, int base_mode, double cdt, double cdt2, double t_stage, const void* mask,
                    const void* tiles, int mc, void* stream);
 int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask,
-                         double t, double* dt_out);
+                         const void* tiles, int mc, double t, double* dt_out);
 
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
 int lsm_profile_enable(LsmHandle* h, int on);

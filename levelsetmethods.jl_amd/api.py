@@ -361,8 +361,7 @@ class ROCNarrowBandMeshField(ROCMeshField):
 
     def prepare(self, buf):
         """Make `buf` readable by stencils: band halo (extrapolation) then out-of-grid ghosts (BCs)."""
-        self.backend.band_fill_list(buf, self.mask, self._hlist, self._hcount)
-        self.backend.fill_ghosts(buf, 7)
+        self.backend.band_prepare(buf, self.mask, self._hlist, self._hcount, self.tiles, self.MC)
 
     def active_mask(self):
         return self.backend.mask_to_host(self.mask)
@@ -774,7 +773,7 @@ class LevelSetEquation:
         t = self.t if t is None else t
         arr = _terms_c(self.terms)
         if self.band:   # minimum over active_nodeindices (src/levelsetterms.jl:31-38)
-            dt = self.backend.compute_cfl_band(arr, len(self.terms), self.state.buf, self.state.mask, t)
+            dt = self.backend.compute_cfl_band(arr, len(self.terms), self.state.buf, self.state.mask, t, self.state.tiles, self.state.MC)
         else:
             dt = self.backend.compute_cfl_local(arr, len(self.terms), self.state.buf, t)
         if self.comm is not None and self.world > 1:

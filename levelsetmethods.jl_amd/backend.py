@@ -166,6 +166,10 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_band_fill_list(self.h, self.ptr(vals), self.ptr(mask), self.ptr(hlist), hlist.numel() // 2,
                                                     self.ptr(hcount)), "lsm_band_fill_list")
 
+    def band_prepare(self, vals, mask, hlist, hcount, tiles, mc):
+        L.check(self.h, self.lib.lsm_band_prepare(self.h, self.ptr(vals), self.ptr(mask), self.ptr(hlist), hlist.numel() // 2,
+                                                  self.ptr(hcount), self.ptr(tiles), int(mc)), "lsm_band_prepare")
+
     def band_status(self, hcount):
         n, m = C.c_int64(), C.c_int()
         L.check(self.h, self.lib.lsm_band_status(self.h, self.ptr(hcount), C.byref(n), C.byref(m)), "lsm_band_status")
@@ -189,10 +193,10 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_stage_band(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out), self.ptr(out2),
                                                 base_mode, cdt, cdt2, t, self.ptr(mask), self.ptr(tiles), int(mc), None), "lsm_stage_band")
 
-    def compute_cfl_band(self, terms_c, nterms, phi, mask, t):
+    def compute_cfl_band(self, terms_c, nterms, phi, mask, t, tiles=None, mc=0):
         dt = C.c_double(0.0)
-        L.check(self.h, self.lib.lsm_compute_cfl_band(self.h, terms_c, nterms, self.ptr(phi), self.ptr(mask), t, C.byref(dt)),
-                "lsm_compute_cfl_band")
+        L.check(self.h, self.lib.lsm_compute_cfl_band(self.h, terms_c, nterms, self.ptr(phi), self.ptr(mask), self.ptr(tiles), int(mc),
+                                                      t, C.byref(dt)), "lsm_compute_cfl_band")
         return dt.value
 
     def mask_to_host(self, mask):

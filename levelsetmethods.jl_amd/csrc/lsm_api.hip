@@ -44,6 +44,7 @@ struct LsmHandle {
     double* d_w;         // device copy of w
     signed char* d_ring; // narrow band: distance-sorted offset ring
     int nring;
+    int nring_lds;       // ring entries before the first with a component beyond the LDS apron (3)
     int* d_miss;
     unsigned long long* d_count;
     unsigned char* d_work;             // per-tile work flags (narrow band)
@@ -51,6 +52,18 @@ struct LsmHandle {
     const unsigned char* band_mask;    // set for the duration of a *_band call
     const unsigned char* band_tiles;
     int band_mc;
+    const int* band_list;              // compact active-tile list for a stage (NULL = flags only)
+    unsigned band_nlist;
+    // compact tile lists of the band last updated (built on the device by lsm_band_update, lengths read back by
+    // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
+    int* d_act_list;
+    int* d_work_list;
+    unsigned* d_lcounts;
+    const void* lists_tiles;           // the tile-flag buffer the lists describe
+    int lists_mc;
+    bool lists_host_valid;
+    unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
+    bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
     double* d_result;    // 2 doubles
@@ -63,6 +76,8 @@ struct LsmHandle {
     size_t ev_used;
 };
 
+struct LsmHandle;
+static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work);
 static const int MAXB = 4096;
 static std::string g_create_err;
 
@@ -130,7 +145,10 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->prof = false; h->ev_used = 0;
     h->cfl_cache_on = true;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
-    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
+    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
+    h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
+    h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
+    h->no_lists = getenv("LSM_BAND_NO_LISTS") != nullptr;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
     if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
@@ -205,7 +223,7 @@ void lsm_destroy(LsmHandle* h) {
     (void)hipFree(h->d_flag);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
-    if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); }
     (void)hipFree(h->d_result);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -317,6 +335,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
     a.dxmin = h->dxmin;
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
+    a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
 }
 
 static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
@@ -474,6 +493,11 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             a.partial = h->d_partial;
             a.nanflag = h->d_flag;
             a.mask = h->band_mask;
+            if (h->band_mask && h->band_tiles && N > 1) {
+                const BandArgs ba = band_args(h, h->band_mc, nullptr);
+                a.tile_active = h->band_tiles;
+                a.tx = ba.tx; a.ty = ba.ty; a.tm = ba.tm; a.nbx = ba.nbx; a.nby = ba.nby;
+            }
             int nb = cfl_blocks(N, h->nloc);
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
@@ -656,6 +680,7 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.nby = a.ndim == 3 ? (h->nloc[1] + a.ty - 1) / a.ty : 1;
     a.nbm = a.ndim >= 2 ? (h->nloc[a.ndim - 1] + mc - 1) / mc : 1;
     a.work = work;
+    a.list = nullptr; a.nlist = 0;
     return a;
 }
 
@@ -672,6 +697,9 @@ static int ensure_ring(LsmHandle* h) {
         return p[0] * p[0] + p[1] * p[1] + p[2] * p[2] < q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
     });
     h->nring = (int)off.size();
+    h->nring_lds = h->nring;
+    for (int r = h->nring - 1; r >= 0; --r)
+        if (std::abs((int)off[r][0]) > 3 || std::abs((int)off[r][1]) > 3 || std::abs((int)off[r][2]) > 3) h->nring_lds = r;
     LSM_HIP(h, hipMalloc((void**)&h->d_ring, off.size() * 3));
     LSM_HIP(h, hipMemcpy(h->d_ring, off.data(), off.size() * 3, hipMemcpyHostToDevice));
     LSM_HIP(h, hipMalloc((void**)&h->d_miss, sizeof(int)));
@@ -683,10 +711,19 @@ static int ensure_ring(LsmHandle* h) {
 // handle-owned scratch for the per-tile work flags
 static int ensure_work(LsmHandle* h, int64_t ntiles) {
     if (h->work_cap >= ntiles) return LSM_OK;
-    if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); }
     LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
+    LSM_HIP(h, hipMalloc((void**)&h->d_act_list, (size_t)ntiles * sizeof(int)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_work_list, (size_t)ntiles * sizeof(int)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_lcounts, 3 * sizeof(unsigned)));
     h->work_cap = ntiles;
+    h->lists_tiles = nullptr; h->lists_host_valid = false;
     return LSM_OK;
+}
+
+// are the compact tile lists (and their lengths on the host) those of this tile-flag buffer?
+static bool have_lists(const LsmHandle* h, const void* tiles, int mc) {
+    return !h->no_lists && h->lists_host_valid && h->lists_tiles == tiles && h->lists_mc == mc;
 }
 
 int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
@@ -701,8 +738,40 @@ int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
 //   tiles     in: active tiles of the old band (ignored when from_dense), out: active tiles of the new band
 //   halo_mask out: nodes within Chebyshev distance 3 of the new band
 // Newly active nodes receive the affine extrapolant from the OLD band.  scratch_a/b: mask-sized buffers.
-int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
-                  int64_t halo_cap, void* halo_count);
+// `visit`: the tiles to cover (from lsm_band_update); NULL = the band's own work tiles
+// `interior`: 1 = no stencil of the band reaches outside the grid (known by the caller), 0 = unknown / it may, -1 = ask the lists
+static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
+                          int64_t halo_cap, void* halo_count, const BandArgs* visit, int interior_hint) {
+    if (!h || !vals || !mask || !halo_mask || !tiles || mc < 1) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    BandArgs a = band_args(h, mc, nullptr);
+    LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
+    if (visit) {
+        a = *visit;
+    } else if (have_lists(h, tiles, mc)) {
+        a.list = h->d_work_list; a.nlist = h->nwork;
+    } else {
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        a.work = h->d_work;
+    }
+    const int N = h->grid.ndim;
+    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
+    BandBcArgs bc;
+    for (int d = 0; d < 3; ++d)
+        for (int sd = 0; sd < 2; ++sd) { bc.kind[d][sd] = d < N ? h->bc[d][sd].kind : LSM_BC_NONE; bc.degree[d][sd] = d < N ? h->bc[d][sd].degree : 0; }
+    // no work tile of the band these lists describe touches a face of the grid: no stencil reaches outside it
+    const bool interior = interior_hint < 0 ? (have_lists(h, tiles, mc) && h->nface == 0) : interior_hint != 0;
+    if (!interior)
+        for (int d = N - 1; d >= 0; --d)
+            launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
+    if (halo_count) LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
+    launch_band_extrapolate(a, nullptr, (unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
+                            (const double*)vals, nullptr, h->d_miss, halo_count ? (BandEntry*)halo_list : nullptr,
+                            (unsigned*)halo_count, halo_list && halo_count ? (unsigned)halo_cap : 0u, h->stream);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
 int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nlayers, void* scratch_a, void* scratch_b,
                     void* halo_mask, void* tiles, int mc, void* halo_list, int64_t halo_cap, void* halo_count) {
     if (!h || !vals || !mask || !scratch_a || !scratch_b || !halo_mask || !tiles)
@@ -717,35 +786,57 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     BandArgs a = band_args(h, mc, nullptr);
     const int64_t ntiles = (int64_t)a.nbx * a.nby * a.nbm;
     LSM_TRY(ensure_work(h, ntiles));
-    // The new band grows out of cut cells of the OLD band, so it lies within nlayers nodes of it and its halo
-    // within nlayers + 3: all inside the old band's tiles and their neighbours as long as a tile is at least
-    // that thick (8 nodes in its thinnest direction); wider bands fall back to visiting every tile.
-    int tmin = a.tx;
+    // The new band grows out of cut cells of the OLD band, so it lies within nlayers nodes of it, its halo within
+    // nlayers + 3 and the boundary-condition sources of its stencils within nlayers + P: all inside the old band's
+    // tiles and their neighbours ("work tiles") as long as a tile is at least that thick (8 nodes in its thinnest
+    // direction); wider bands fall back to visiting every tile.
+    int tmin = a.tx, reach = LSM_GHOST;
     if (N == 3) tmin = a.ty < tmin ? a.ty : tmin;
     if (N >= 2) tmin = a.tm < tmin ? a.tm : tmin;
-    if (!from_dense && nlayers + LSM_GHOST <= tmin) {
+    for (int d = 0; d < N; ++d)
+        for (int sd = 0; sd < 2; ++sd)
+            if (h->bc[d][sd].kind == LSM_BC_EXTRAPOLATION && h->bc[d][sd].degree > reach) reach = h->bc[d][sd].degree;
+    const bool local = !from_dense && nlayers + reach <= tmin;
+    const bool listed = local && have_lists(h, tiles, mc);   // the work tiles as a compact list: one block per work tile
+    if (listed) {
+        a.list = h->d_work_list; a.nlist = h->nwork;
+    } else if (local) {
         launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
         a.work = h->d_work;
     }
     const size_t bytes = (size_t)h->lay.total;
     unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
-    LSM_HIP(h, hipMemsetAsync(A, 0, bytes, h->stream));
-    LSM_HIP(h, hipMemsetAsync(B, 0, bytes, h->stream));
-    launch_band_cut(a, (const double*)vals, from_dense ? nullptr : (const unsigned char*)mask, A, h->stream);
-    for (int l = 0; l < nlayers; ++l) {
-        launch_band_dilate(a, A, B, h->stream);
-        unsigned char* t = A; A = B; B = t;
+    const unsigned char* old_mask = from_dense ? nullptr : (const unsigned char*)mask;
+    const bool fused = band_grow_fits(a, nlayers);
+    if (fused) {
+        // cut cells, seeds, dilations and the tile flags in one LDS-resident kernel; A is written on every visited tile
+        launch_band_grow(a, (const double*)vals, old_mask, nlayers, A, (unsigned char*)tiles, h->stream);
+    } else {
+        LSM_HIP(h, hipMemsetAsync(A, 0, bytes, h->stream));
+        LSM_HIP(h, hipMemsetAsync(B, 0, bytes, h->stream));
+        launch_band_cut(a, (const double*)vals, old_mask, A, h->stream);
+        for (int l = 0; l < nlayers; ++l) {
+            launch_band_dilate(a, A, B, h->stream);
+            unsigned char* t = A; A = B; B = t;
+        }
     }
     if (!from_dense)
-        launch_band_extrapolate(a, A, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals, (double*)vals, h->d_miss,
-                                nullptr, nullptr, 0, h->stream);
-    if (from_dense) LSM_HIP(h, hipMemcpyAsync(mask, A, bytes, hipMemcpyDeviceToDevice, h->stream));
-    else launch_band_copy(a, A, (unsigned char*)mask, h->stream);   // the old band lies inside the work tiles
-    // tiles of the new band; everything below lies in them or their neighbours (a BC source is at most 7 < 8 nodes
-    // from the band node whose stencil resolves to it)
-    launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
+        launch_band_extrapolate(a, A, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds, (const double*)vals,
+                                (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
+    launch_band_copy(a, A, (unsigned char*)mask, h->stream);   // the old band lies inside the visited tiles
+    if (!fused) launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
     LSM_HIP(h, hipGetLastError());
-    return lsm_band_halo(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count);
+    // halo of the new band: over the same (old) work tiles when they are listed, else over the new band's
+    const int interior = listed && h->nface == 0 ? 1 : 0;   // the new band lies in the old work tiles: none on a face
+    h->lists_host_valid = false;                             // from here on the lists describe the previous band
+    LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior));
+    // compact lists of the new band's tiles for the launches that follow lsm_band_status
+    BandArgs full = band_args(h, mc, nullptr);
+    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->stream);
+    launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+    h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
 }
 
 // halo_mask := the in-grid nodes stencils centred on band nodes read, directly (axis lines of length LSM_GHOST and
@@ -754,27 +845,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
 // *halo_count may exceed halo_cap: the list is then truncated and the call must be repeated with a larger one.
 int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
                   int64_t halo_cap, void* halo_count) {
-    if (!h || !vals || !mask || !halo_mask || !tiles || mc < 1) return LSM_ERR_INVALID;
-    LSM_TRY(ensure_ring(h));
-    BandArgs a = band_args(h, mc, nullptr);
-    LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
-    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
-    a.work = h->d_work;
-    const int N = h->grid.ndim;
-    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
-    launch_band_cross(a, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
-    BandBcArgs bc;
-    for (int d = 0; d < 3; ++d)
-        for (int sd = 0; sd < 2; ++sd) { bc.kind[d][sd] = d < N ? h->bc[d][sd].kind : LSM_BC_NONE; bc.degree[d][sd] = d < N ? h->bc[d][sd].degree : 0; }
-    for (int d = N - 1; d >= 0; --d)
-        launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
-    if (halo_list && halo_count) {
-        LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
-        launch_band_extrapolate(a, (const unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals,
-                                nullptr, h->d_miss, (BandEntry*)halo_list, (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
-    }
-    LSM_HIP(h, hipGetLastError());
-    return LSM_OK;
+    return band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, nullptr, -1);
 }
 
 // ϕ[I] for the non-band nodes flagged in `targets`: _extrapolate_to_ghost materialised
@@ -783,13 +854,15 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
     if (!h || !vals || !mask || !targets || mc < 1) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
     BandArgs a = band_args(h, mc, nullptr);
-    if (tiles) {
+    if (tiles && have_lists(h, tiles, mc)) {
+        a.list = h->d_work_list; a.nlist = h->nwork;
+    } else if (tiles) {
         LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
         launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
         a.work = h->d_work;
     }
-    launch_band_extrapolate(a, (const unsigned char*)targets, (const unsigned char*)mask, h->d_ring, h->nring, (const double*)vals,
-                            (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
+    launch_band_extrapolate(a, (const unsigned char*)targets, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
+                            (const double*)vals, (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
@@ -802,6 +875,16 @@ int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* h
                       (const unsigned char*)mask, (const double*)vals, (double*)vals, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
+}
+
+// lsm_band_fill_list followed by lsm_fill_ghosts — what a stage input needs; the ghost fill is skipped while no
+// work tile of the band touches a face of the grid (then no band stencil reads a ghost)
+int lsm_band_prepare(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap, const void* halo_count,
+                     const void* tiles, int mc) {
+    const int r = lsm_band_fill_list(h, vals, mask, halo_list, halo_cap, halo_count);
+    if (r != LSM_OK) return r;
+    if (tiles && have_lists(h, tiles, mc) && h->nface == 0) return LSM_OK;
+    return lsm_fill_ghosts(h, vals, 7, nullptr);
 }
 
 int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count) {
@@ -834,7 +917,10 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
     unsigned c = 0;
     LSM_HIP(h, hipMemcpyAsync(&c, halo_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    unsigned lc[3] = {0, 0, 0};
+    if (h->lists_tiles) LSM_HIP(h, hipMemcpyAsync(lc, h->d_lcounts, sizeof(lc), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->lists_tiles) { h->nact = lc[0]; h->nwork = lc[1]; h->nface = lc[2]; h->lists_host_valid = true; }
     if (*missed) LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
     *count = (int64_t)c;
     return LSM_OK;
@@ -848,19 +934,23 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
     h->band_mask = (const unsigned char*)mask;
     h->band_tiles = (const unsigned char*)tiles;
     h->band_mc = tiles ? mc : 0;
+    if (tiles && have_lists(h, tiles, mc)) { h->band_list = h->d_act_list; h->band_nlist = h->nact; }
     const int r = stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, 0, h->nloc[h->grid.ndim - 1], stream);
-    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
+    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
     return r;
 }
 
-int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask, double t, double* dt_out) {
-    if (!h || !mask) return LSM_ERR_INVALID;
+int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask, const void* tiles, int mc,
+                         double t, double* dt_out) {
+    if (!h || !mask || (tiles && mc < 1)) return LSM_ERR_INVALID;
     h->band_mask = (const unsigned char*)mask;
+    h->band_tiles = (const unsigned char*)tiles;
+    h->band_mc = tiles ? mc : 0;
     const bool keep = h->cfl_cache_on;
     h->cfl_cache_on = false;            // the minimum runs over the current band only
     const int r = lsm_compute_cfl(h, terms, nterms, phi, t, dt_out);
     h->cfl_cache_on = keep;
-    h->band_mask = nullptr;
+    h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
     return r;
 }
 

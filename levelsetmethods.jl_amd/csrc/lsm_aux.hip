@@ -239,8 +239,13 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, con
             pre[1] = c.v[0] * (x1 - c.v[1]);
             if (NDIM == 3) pre[0] = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
         }
-#pragma unroll 2
+        // narrow band: the column crosses tiles of tm planes; tiles without band nodes are stepped over
+        const unsigned tcol = a.tile_active ? (unsigned)(i0 / a.tx) + a.nbx * (NDIM == 3 ? (unsigned)(i1 / a.ty) : 0u) : 0u;
         for (int m = mb; m < me; ++m) {
+            if (a.tile_active && NDIM > 1 && !a.tile_active[tcol + a.nbx * a.nby * (unsigned)(m / a.tm)]) {
+                m = (m / a.tm + 1) * a.tm - 1;
+                continue;
+            }
             if (a.mask && !a.mask[cbase + (NDIM == 1 ? 0 : m * slast)]) continue;   // narrow band: active nodes only
             double u[3] = {0, 0, 0};
             if constexpr (CKIND == LSM_COEFF_CONST) {

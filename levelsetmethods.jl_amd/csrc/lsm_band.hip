@@ -19,15 +19,18 @@
 //  * work tiles: a step moves the interface by less than a cell, so the new band, its halo and every
 //    node the rebuild reads lie in the old band's tiles or their 26 neighbours; `work` flags those.
 // Built with -ffp-contract=off.
+#include <cstdlib>
 #include "lsm_internal.h"
 
-#define LSM_BAND_LDS 20480   // bytes of LDS for a tile's mask + search apron ((32+12)·(8+12)·(8+12) = 17600 in 3-D)
+#define LSM_BAND_LDS 40960   // bytes of LDS for a tile + apron of byte flags
 
 namespace lsm {
 
+// this block's tile: taken from the compact tile list when there is one (grid = list length)
+#define LSM_TILE_ID(a) ((a).list ? (unsigned)(a).list[blockIdx.x] : (unsigned)blockIdx.x)
 // iterate the nodes of this block's tile; returns false if the tile is skipped
 #define LSM_TILE_PROLOGUE(a)                                                                         \
-    const unsigned tile = blockIdx.x;                                                                \
+    const unsigned tile = LSM_TILE_ID(a);                                                            \
     if ((a).work && !(a).work[tile]) return;                                                         \
     const int bx_ = tile % (a).nbx, by_ = (tile / (a).nbx) % (a).nby, bm_ = tile / ((a).nbx * (a).nby); \
     const int x0_ = bx_ * (a).tx, y0_ = (a).ndim == 3 ? by_ * (a).ty : 0, m0_ = bm_ * (a).tm;        \
@@ -39,6 +42,139 @@ namespace lsm {
         if (const int X = x0_ + e_ % ex_, Y = y0_ + (e_ / ex_) % ey_, M = m0_ + e_ / (ex_ * ey_);     \
             X < nx_ && Y < ny_ && M < nm_)                                                           \
             if (const long long Q = (a).origin + X + Y * sy_ + M * sm_; true)
+
+// LDS box = this block's tile plus an apron of `ap` nodes per side, one byte per node, index
+// lx + bx·(ly + by·lm) in tile-local coordinates (apron included); positions outside the grid read as 0.
+struct Box { int ap, bx, by, bm, nel; float rbx, rby; };
+__device__ __forceinline__ Box make_box(const BandArgs& a, int ex, int ey, int em, int ap) {
+    Box b;
+    b.ap = ap; b.bx = ex + 2 * ap; b.by = a.ndim == 3 ? ey + 2 * ap : 1; b.bm = a.ndim >= 2 ? em + 2 * ap : 1;
+    b.nel = b.bx * b.by * b.bm;
+    b.rbx = 1.0f / (float)b.bx; b.rby = 1.0f / (float)b.by;
+    return b;
+}
+// e -> (lx, ly, lm) without integer division (e < 2^16: a float quotient is off by at most one)
+__device__ __forceinline__ void box_coords(const Box& b, int e, int& lx, int& ly, int& lm) {
+    int t = (int)((float)e * b.rbx), r = e - t * b.bx;
+    if (r >= b.bx) { ++t; r -= b.bx; } else if (r < 0) { --t; r += b.bx; }
+    int u = (int)((float)t * b.rby), r2 = t - u * b.by;
+    if (r2 >= b.by) { ++u; r2 -= b.by; } else if (r2 < 0) { --u; r2 += b.by; }
+    lx = r; ly = r2; lm = u;
+}
+// Staging is latency-bound (a byte per lane per load), so every thread issues K independent loads before
+// it stores anything: first(q) for all K, then second(q, first) for all K (which may load again).
+template <int K, typename F1, typename F2>
+__device__ __forceinline__ void stage_box(const BandArgs& a, const Box& b, int x0, int y0, int m0, int nx, int ny, int nm,
+                                          long long sy, long long sm, unsigned char* lds, F1 first, F2 second) {
+    const int apy = a.ndim == 3 ? b.ap : 0, apm = a.ndim >= 2 ? b.ap : 0;
+    for (int e0 = threadIdx.x; e0 < b.nel; e0 += blockDim.x * K) {
+        long long q[K];
+        bool ok[K];
+        unsigned char u[K], v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = e0 + k * blockDim.x;
+            int lx, ly, lm;
+            box_coords(b, e < b.nel ? e : 0, lx, ly, lm);
+            const int gx = x0 - b.ap + lx, gy = y0 - apy + ly, gm = m0 - apm + lm;
+            ok[k] = e < b.nel && gx >= 0 && gx < nx && gy >= 0 && gy < ny && gm >= 0 && gm < nm;
+            q[k] = ok[k] ? a.origin + gx + gy * sy + gm * sm : a.origin;   // always a valid address: loads need no branch
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) u[k] = first(q[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) u[k] = ok[k] ? u[k] : (unsigned char)0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = second(q[k], u[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (e0 + k * blockDim.x < b.nel) lds[e0 + k * blockDim.x] = v[k];
+    }
+}
+
+// update_band! (src/meshfield.jl:555-588) for one tile, entirely in LDS: node flags (in the old band,
+// value <= 0, value >= 0) on the tile + apron nl+1 -> cut cells -> seeds (corners of cut cells) -> nl
+// von-Neumann dilations -> new band on the tile, and the tile's activity flag.
+__global__ void __launch_bounds__(256) band_grow_kernel(BandArgs a, const double* v, const unsigned char* old_mask, int nl,
+                                                        unsigned char* new_mask, unsigned char* tiles) {
+    if (a.work && !a.work[LSM_TILE_ID(a)]) {
+        if (threadIdx.x == 0) tiles[LSM_TILE_ID(a)] = 0;
+        return;
+    }
+    LSM_TILE_PROLOGUE(a)
+    extern __shared__ unsigned char f[];
+    const Box b = make_box(a, ex_, ey_, em_, nl + 1);
+    const int nel = b.nel;
+    stage_box<8>(a, b, x0_, y0_, m0_, nx_, ny_, nm_, sy_, sm_, f,
+                 [&](long long q) -> unsigned char { return old_mask ? old_mask[q] : (unsigned char)1; },
+                 [&](long long q, unsigned char inband) -> unsigned char {
+                     const double x = v[inband ? q : a.origin];      // unconditional load from a valid address
+                     return inband ? (unsigned char)(1 | (x <= 0.0 ? 2 : 0) | (x >= 0.0 ? 4 : 0)) : (unsigned char)0;
+                 });
+    __syncthreads();
+    const int sby = b.bx, sbm = b.bx * b.by;
+    const int cy = a.ndim == 3 ? 1 : 0, cm = a.ndim >= 2 ? 1 : 0;   // cell extent per tile direction
+    // cut cells: lower corner l, all corners in the old band, values straddling 0 (bit 3)
+    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+        int lx, ly, lm;
+        box_coords(b, e, lx, ly, lm);
+        if (lx + 1 >= b.bx || ly + cy >= b.by || lm + cm >= b.bm) continue;
+        unsigned all = 1, any = 0;
+        for (int dm = 0; dm <= cm; ++dm)
+            for (int dy = 0; dy <= cy; ++dy)
+                for (int dx = 0; dx <= 1; ++dx) {
+                    const unsigned c = f[e + dx + dy * sby + dm * sbm];
+                    all &= c; any |= c;
+                }
+        if ((all & 1) && (any & 2) && (any & 4)) f[e] |= 8;
+    }
+    __syncthreads();
+    // seeds: every corner of a cut cell (bit 4)
+    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+        int lx, ly, lm;
+        box_coords(b, e, lx, ly, lm);
+        unsigned sd = 0;
+        for (int dm = 0; dm <= cm; ++dm)
+            for (int dy = 0; dy <= cy; ++dy)
+                for (int dx = 0; dx <= 1; ++dx) {
+                    if (lx - dx < 0 || ly - dy < 0 || lm - dm < 0) continue;
+                    sd |= f[e - dx - dy * sby - dm * sbm] & 8;
+                }
+        if (sd) f[e] |= 16;
+    }
+    __syncthreads();
+    // nl dilation steps, ping-pong between bits 4 and 5
+    unsigned cur = 16, nxt = 32;
+    for (int it = 0; it < nl; ++it) {
+        for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+            int lx, ly, lm;
+            box_coords(b, e, lx, ly, lm);
+            unsigned r = f[e];
+            if (lx > 0) r |= f[e - 1];
+            if (lx + 1 < b.bx) r |= f[e + 1];
+            if (cy) {
+                if (ly > 0) r |= f[e - sby];
+                if (ly + 1 < b.by) r |= f[e + sby];
+            }
+            if (cm) {
+                if (lm > 0) r |= f[e - sbm];
+                if (lm + 1 < b.bm) r |= f[e + sbm];
+            }
+            f[e] = (unsigned char)((f[e] & ~nxt) | ((r & cur) ? nxt : 0));
+        }
+        __syncthreads();
+        const unsigned t = cur; cur = nxt; nxt = t;
+    }
+    int any = 0;
+    LSM_TILE_FOR(a, x, y, m, q) {
+        const int lx = x - x0_ + b.ap, ly = a.ndim == 3 ? y - y0_ + b.ap : 0, lm = a.ndim >= 2 ? m - m0_ + b.ap : 0;
+        const unsigned char on = (f[lx + b.bx * (ly + b.by * lm)] & cur) ? 1 : 0;
+        new_mask[q] = on;
+        any |= on;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
+}
 
 __global__ void __launch_bounds__(256) band_cut_kernel(BandArgs a, const double* v, const unsigned char* old_mask,
                                                        unsigned char* seed) {
@@ -73,102 +209,440 @@ __global__ void __launch_bounds__(256) band_dilate_kernel(BandArgs a, const unsi
     }
 }
 
-// Chebyshev dilation of radius r (<= LSM_GHOST) along ONE axis; N passes give the box dilation
-__global__ void __launch_bounds__(256) band_box_dilate_kernel(BandArgs a, int dim, int r, const unsigned char* in, unsigned char* out) {
-    LSM_TILE_PROLOGUE(a)
-    const long long sd = dim == 0 ? 1 : (dim == 1 ? a.s1 : a.s2);
-    LSM_TILE_FOR(a, x, y, m, q) {
-        unsigned char o = 0;
-        for (int k = -r; k <= r; ++k) o |= in[q + k * sd];
-        out[q] = o ? 1 : 0;
-    }
-}
-
 __global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsigned char* in, unsigned char* out) {
     LSM_TILE_PROLOGUE(a)
     LSM_TILE_FOR(a, x, y, m, q) out[q] = in[q];
 }
 
-// _extrapolate_to_ghost (src/meshfield.jl:494-511) for every node with target[q] && !src_mask[q]
-// With `list` the (node, nearest band node) pairs are appended for band_apply_kernel: the nearest node
-// depends on the mask only, so the search runs once per band update and every stage input is then
-// filled by a plain gather.
-__global__ void __launch_bounds__(256) band_extrapolate_kernel(BandArgs a, const unsigned char* target, const unsigned char* src_mask,
-                                                               const signed char* ring, int nring, const double* src, double* dst,
-                                                               int* miss, BandEntry* list, unsigned* list_count, unsigned list_cap) {
+// _nearest_band_node continued in global memory: ring entries [r0, nring) in order, bounds-checked
+__device__ __forceinline__ bool ring_scan_global(const BandArgs& a, const unsigned char* src_mask, const signed char* ring, int r0,
+                                                 int nring, const int I[3], int P[3]) {
+    for (int r = r0; r < nring; ++r) {
+        const int p0 = I[0] + ring[3 * r], p1 = I[1] + ring[3 * r + 1], p2 = I[2] + ring[3 * r + 2];
+        if (p0 < 0 || p0 >= a.n[0] || p1 < 0 || p1 >= a.n[1] || p2 < 0 || p2 >= a.n[2]) continue;
+        if (src_mask[a.origin + p0 + p1 * a.s1 + p2 * a.s2]) { P[0] = p0; P[1] = p1; P[2] = p2; return true; }
+    }
+    return false;
+}
+
+// what follows the search for node I (padded index q) with nearest band node P: record the pair and / or
+// write the affine extrapolant (_extrapolate_to_ghost, src/meshfield.jl:494-511)
+__device__ __forceinline__ void finish_node(const BandArgs& a, long long q, const int I[3], const int P[3], bool found,
+                                            const unsigned char* src_mask, const double* src, double* dst, int* miss, BandEntry* list,
+                                            unsigned* list_count, unsigned list_cap) {
+    if (!found) { atomicOr(miss, 1); return; }   // the reference throws: farther than the search radius
+    const long long qp = a.origin + P[0] + P[1] * a.s1 + P[2] * a.s2;
+    if (list) {
+        // one atomic per wave: the lanes that reach this point together take consecutive slots
+        const unsigned long long bal = __ballot(1);
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(list_count, (unsigned)__popcll(bal));
+        const unsigned k = __shfl(base, leader, 64) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (k < list_cap) {
+            BandEntry e;
+            e.q = q; e.rel = (int)(qp - q);
+            e.d[0] = (signed char)(I[0] - P[0]); e.d[1] = (signed char)(I[1] - P[1]); e.d[2] = (signed char)(I[2] - P[2]); e.d[3] = 0;
+            list[k] = e;
+        }
+    }
+    if (!dst) return;
+    const double phiP = src[qp];
+    double val = phiP;
+    for (int d = 0; d < a.ndim; ++d) {
+        const int delta = I[d] - P[d];
+        if (delta == 0) continue;
+        const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+        double slope = 0.0;                                   // _axis_slope: + neighbour first, then -
+        if (P[d] + 1 < a.n[d] && src_mask[qp + sd]) slope = src[qp + sd] - phiP;
+        else if (P[d] - 1 >= 0 && src_mask[qp - sd]) slope = phiP - src[qp - sd];
+        val += (double)delta * slope;
+    }
+    // never let extrapolation invent a sign change far from the band
+    const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
+    dst[q] = (phiP == 0.0 || sv == sp) ? val : phiP;
+}
+
+// _extrapolate_to_ghost (src/meshfield.jl:494-511).
+//  * target != NULL: for every node with target[q] && !src_mask[q], value written to dst.
+//  * halo   != NULL (band-halo mode): the targets are the nodes a stencil centred on a band node reads — up
+//    to LSM_GHOST nodes along each axis and the 3^N box, found here from the LDS copy of the mask — plus the
+//    nodes already marked in halo[] (boundary-condition sources, band_halo_bc_kernel); halo[] becomes the
+//    full halo mask (band included) and the (node, nearest band node) pairs are appended to `list` for
+//    band_apply_kernel: the nearest node depends on the mask only, so the search runs once per band update
+//    and every stage input is then filled by a plain gather.
+// The ring search probes mask bytes in order of distance; the tile's mask with an apron of RL nodes is staged
+// in LDS (out-of-grid entries read as 0), which serves the first nring_lds ring entries (those with all
+// components <= RL); the rare longer searches continue in global memory.
+constexpr int RL = 3;
+__global__ void __launch_bounds__(256) band_extrapolate_kernel(BandArgs a, const unsigned char* target, unsigned char* halo,
+                                                               const unsigned char* src_mask, const signed char* ring, int nring,
+                                                               int nring_lds, const double* src, double* dst, int* miss,
+                                                               BandEntry* list, unsigned* list_count, unsigned list_cap) {
     LSM_TILE_PROLOGUE(a)
-    {   // nothing to do in most tiles: skip them before staging anything
+    if (target) {   // nothing to do in most tiles: skip them before staging anything
         int any = 0;
         LSM_TILE_FOR(a, x, y, m, q) any |= (target[q] && !src_mask[q]) ? 1 : 0;
         if (!__syncthreads_or(any)) return;
     }
-    // The ring search probes up to (2R+1)^N mask bytes per node; stage the tile's mask with an apron of R
-    // nodes in LDS once (out-of-grid entries read as 0) so that every probe is an LDS byte read.
-    constexpr int R = 6;
-    __shared__ unsigned char lmask[LSM_BAND_LDS];
-    const int ax = ex_ + 2 * R, ay = a.ndim == 3 ? ey_ + 2 * R : 1, am = a.ndim >= 2 ? em_ + 2 * R : 1;
-    const bool staged = ax * ay * am <= LSM_BAND_LDS;
+    extern __shared__ unsigned char lmask[];
+    const Box b = make_box(a, ex_, ey_, em_, RL);
+    const bool staged = b.nel <= LSM_BAND_LDS;     // the launcher sized the dynamic LDS accordingly
     if (staged) {
-        for (int e = threadIdx.x; e < ax * ay * am; e += blockDim.x) {
-            const int lx = e % ax, ly = (e / ax) % ay, lm = e / (ax * ay);
-            const int gx = x0_ - R + lx, gy = a.ndim == 3 ? y0_ - R + ly : 0, gm = a.ndim >= 2 ? m0_ - R + lm : 0;
-            unsigned char v = 0;
-            if (gx >= 0 && gx < nx_ && gy >= 0 && gy < ny_ && gm >= 0 && gm < nm_) v = src_mask[a.origin + gx + gy * sy_ + gm * sm_];
-            lmask[e] = v;
-        }
+        stage_box<8>(a, b, x0_, y0_, m0_, nx_, ny_, nm_, sy_, sm_, lmask, [&](long long q) -> unsigned char { return src_mask[q]; },
+                     [&](long long, unsigned char u) -> unsigned char { return u; });
         __syncthreads();
     }
+    const int cy = a.ndim == 3 ? 1 : 0, cm = a.ndim >= 2 ? 1 : 0;
+    const int sby = cy ? b.bx : 0, sbm = cm ? b.bx * b.by : 0;      // LDS strides of the tile directions
     LSM_TILE_FOR(a, x, y, m, q) {
-        if (!target[q] || src_mask[q]) continue;
+        const int lx = x - x0_ + RL, ly = cy ? y - y0_ + RL : 0, lm = cm ? m - m0_ + RL : 0;
+        const int c = lx + b.bx * (ly + b.by * lm);
+        if (halo) {
+            unsigned char t;
+            if (staged) {
+                if (lmask[c]) { halo[q] = 1; continue; }
+                t = halo[q];
+                if (!t) {
+                    for (int k = -LSM_GHOST; k <= LSM_GHOST; ++k) t |= lmask[c + k] | lmask[c + k * sby] | lmask[c + k * sbm];
+                    for (int dm = -cm; dm <= cm; ++dm)
+                        for (int dy = -cy; dy <= cy; ++dy) {
+                            const int cc = c + dy * sby + dm * sbm;
+                            t |= lmask[cc - 1] | lmask[cc] | lmask[cc + 1];
+                        }
+                }
+            } else {
+                // mask at tile-direction offset (dx, dy, dm) from this node
+                auto at = [&](int dx, int dy, int dm) -> unsigned char {
+                    const int X = x + dx, Y = y + dy, M = m + dm;
+                    if (X < 0 || X >= nx_ || Y < 0 || Y >= ny_ || M < 0 || M >= nm_) return 0;
+                    return src_mask[a.origin + X + Y * sy_ + M * sm_];
+                };
+                if (at(0, 0, 0)) { halo[q] = 1; continue; }
+                t = halo[q];
+                if (!t) {
+                    for (int k = -LSM_GHOST; k <= LSM_GHOST; ++k) {
+                        t |= at(k, 0, 0);
+                        if (cy) t |= at(0, k, 0);
+                        if (cm) t |= at(0, 0, k);
+                    }
+                    for (int dm = -cm; dm <= cm; ++dm)
+                        for (int dy = -cy; dy <= cy; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx) t |= at(dx, dy, dm);
+                }
+            }
+            if (!t) continue;
+            halo[q] = 1;
+        } else if (!target[q] || src_mask[q]) {
+            continue;
+        }
         int I[3] = {x, 0, 0};
         if (a.ndim == 2) I[1] = m;
         if (a.ndim == 3) { I[1] = y; I[2] = m; }
-        // _nearest_band_node: first hit along the distance-sorted offset ring
+        // _nearest_band_node: first hit along the distance-sorted offset ring (offsets in field dimensions)
         int P[3] = {0, 0, 0};
         bool found = false;
+        int r = 0;
         if (staged) {
-            // tile-local coordinates of I inside the staged block (ring offsets are in field dimensions)
-            const int lx = x - x0_ + R, ly = a.ndim == 3 ? y - y0_ + R : 0, lm = a.ndim >= 2 ? m - m0_ + R : 0;
-            for (int r = 0; r < nring; ++r) {
+            for (; r < nring_lds; ++r) {
                 const int o0 = ring[3 * r], o1 = ring[3 * r + 1], o2 = ring[3 * r + 2];
                 const int oy = a.ndim == 3 ? o1 : 0, om = a.ndim == 3 ? o2 : (a.ndim == 2 ? o1 : 0);
-                if (lmask[(lx + o0) + ax * ((ly + oy) + ay * (lm + om))]) {
+                if (lmask[c + o0 + oy * sby + om * sbm]) {
                     P[0] = I[0] + o0; P[1] = I[1] + o1; P[2] = I[2] + o2; found = true; break;
                 }
             }
-        } else {
-            for (int r = 0; r < nring; ++r) {
-                const int p0 = I[0] + ring[3 * r], p1 = I[1] + ring[3 * r + 1], p2 = I[2] + ring[3 * r + 2];
-                if (p0 < 0 || p0 >= a.n[0] || p1 < 0 || p1 >= a.n[1] || p2 < 0 || p2 >= a.n[2]) continue;
-                if (src_mask[a.origin + p0 + p1 * a.s1 + p2 * a.s2]) { P[0] = p0; P[1] = p1; P[2] = p2; found = true; break; }
+        }
+        if (!found) found = ring_scan_global(a, src_mask, ring, r, nring, I, P);
+        finish_node(a, q, I, P, found, src_mask, src, dst, miss, list, list_count, list_cap);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-D fast path (32×8×mc tiles): the same two kernels with the masks held as 64-bit row words (bit lx of
+// row (ly, lm) = node lx of that x-line of the tile + apron, built with wave ballots), so that cut
+// cells, dilations, the halo test and the nearest-node search handle a whole x-line per operation.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+
+// stage one flag word per x-line of the box: wave per row, lanes along x, K rows in flight per wave.
+// flags(q, ok, row, f): f[k] = flag bits of this lane's node of row[k] (bit wd goes to out[wd][row]).
+template <int K, int NW, typename F>
+__device__ __forceinline__ void stage_rows(const BandArgs& a, int ap, int bx, int by, int bm, int x0, int y0, int m0, u64* const (&out)[NW],
+                                           F flags) {
+    const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the row arithmetic below is scalar
+    const int nrows = by * bm;
+    const int gx = x0 - ap + lane;
+    const bool xok = (lane < bx) & ((unsigned)gx < (unsigned)a.n[0]);
+    const long long qx = a.origin + (xok ? gx : 0);
+    for (int row0 = wv * K; row0 < nrows; row0 += nwv * K) {
+        long long q[K];
+        bool ok[K];
+        int rows[K];
+        unsigned f[K];
+        int lm = row0 / by, ly = row0 - lm * by;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // branch-free: out-of-range rows and nodes load from a valid address and are masked afterwards
+            const int gy = y0 - ap + ly, gm = m0 - ap + lm;
+            const bool rok = (row0 + k < nrows) & ((unsigned)gy < (unsigned)a.n[1]) & ((unsigned)gm < (unsigned)a.n[2]);
+            ok[k] = xok & rok;
+            q[k] = qx + (rok ? gy * a.s1 + gm * a.s2 : 0ll);
+            rows[k] = row0 + k < nrows ? row0 + k : 0;
+            ++ly;
+            const bool wrap = ly >= by;
+            ly = wrap ? 0 : ly;
+            lm += wrap ? 1 : 0;
+        }
+        flags(q, ok, rows, f);                 // K independent loads per lane
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) {
+                const u64 bal = __ballot((f[k] >> wd) & 1u);
+                if (lane == 0 && row0 + k < nrows) out[wd][row0 + k] = bal;
+            }
+    }
+}
+
+// update_band! for one 32×8×mc tile (see band_grow_kernel)
+__global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const double* v, const unsigned char* old_mask, int nl,
+                                                         unsigned char* new_mask, unsigned char* tiles) {
+    const unsigned tile = LSM_TILE_ID(a);
+    if (a.work && !a.work[tile]) {
+        if (threadIdx.x == 0) tiles[tile] = 0;
+        return;
+    }
+    const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
+    const int ap = nl + 1, bx = a.tx + 2 * ap, by = a.ty + 2 * ap, bm = a.tm + 2 * ap, nrows = by * bm;
+    extern __shared__ u64 w3[];
+    u64 *B = w3, *LE = w3 + nrows, *GE = w3 + 2 * nrows, *S0 = w3 + 3 * nrows, *S1 = w3 + 4 * nrows;
+    // pass 1: the old band's row words; tiles whose box holds no band node have no cut cell -> empty
+    u64* const out1[1] = {B};
+    stage_rows<16, 1>(a, ap, bx, by, bm, x0, y0, m0, out1, [&](const long long (&q)[16], const bool (&ok)[16], const int (&)[16], unsigned (&f)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = old_mask ? (unsigned)old_mask[q[k]] : 1u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = ok[k] ? f[k] : 0u;
+    });
+    __syncthreads();
+    // tile is 32 × 8 × tm; the block's 256-thread groups take planes pg, pg + npg, ...
+    const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
+    const int x = x0 + tx_, y = y0 + ty_;
+    {
+        int anyb = 0;
+        for (int t = threadIdx.x; t < nrows; t += blockDim.x) anyb |= B[t] ? 1 : 0;
+        if (!__syncthreads_or(anyb)) {
+            if (x < a.n[0] && y < a.n[1])
+                for (int i = pg; i < a.tm && m0 + i < a.n[2]; i += npg) new_mask[a.origin + x + y * a.s1 + (m0 + i) * a.s2] = 0;
+            if (threadIdx.x == 0) tiles[tile] = 0;
+            return;
+        }
+    }
+    // pass 2: values of the band nodes -> (<= 0) and (>= 0) row words
+    u64* const out2[2] = {LE, GE};
+    stage_rows<16, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, [&](const long long (&q)[16], const bool (&)[16], const int (&rows)[16], unsigned (&f)[16]) {
+        const int lane = threadIdx.x & 63;
+        double xv[16];
+        bool on[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            on[k] = (B[rows[k]] >> lane) & 1ull;
+            xv[k] = v[on[k] ? q[k] : a.origin];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = on[k] ? ((xv[k] <= 0.0 ? 1u : 0u) | (xv[k] >= 0.0 ? 2u : 0u)) : 0u;
+    });
+    __syncthreads();
+    const float rby = 1.0f / (float)by;
+    auto rowcoords = [&](int t, int& ly, int& lm) {
+        lm = (int)((float)t * rby); ly = t - lm * by;
+        if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+    };
+    // cut cells: bit lx of row (ly, lm) = the cell with lower corner (lx, ly, lm)
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) {
+        int ly, lm;
+        rowcoords(t, ly, lm);
+        u64 cut = 0;
+        if (ly + 1 < by && lm + 1 < bm) {
+            u64 all = B[t] & B[t + 1] & B[t + by] & B[t + by + 1];
+            u64 le = LE[t] | LE[t + 1] | LE[t + by] | LE[t + by + 1];
+            u64 ge = GE[t] | GE[t + 1] | GE[t + by] | GE[t + by + 1];
+            all &= all >> 1; le |= le >> 1; ge |= ge >> 1;
+            cut = all & le & ge;
+        }
+        S0[t] = cut;
+    }
+    __syncthreads();
+    // seeds: every corner of a cut cell
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) {
+        int ly, lm;
+        rowcoords(t, ly, lm);
+        u64 c = S0[t];
+        if (ly > 0) c |= S0[t - 1];
+        if (lm > 0) c |= S0[t - by];
+        if (ly > 0 && lm > 0) c |= S0[t - by - 1];
+        S1[t] = c | (c << 1);
+    }
+    __syncthreads();
+    // nl von-Neumann dilations (bits shifted past the box only relay paths that exist in the full grid)
+    u64 *cur = S1, *nxt = S0;
+    for (int it = 0; it < nl; ++it) {
+        for (int t = threadIdx.x; t < nrows; t += blockDim.x) {
+            int ly, lm;
+            rowcoords(t, ly, lm);
+            const u64 c = cur[t];
+            u64 r = c | (c << 1) | (c >> 1);
+            if (ly > 0) r |= cur[t - 1];
+            if (ly + 1 < by) r |= cur[t + 1];
+            if (lm > 0) r |= cur[t - by];
+            if (lm + 1 < bm) r |= cur[t + by];
+            nxt[t] = r;
+        }
+        __syncthreads();
+        u64* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    int any = 0;
+    if (x < a.n[0] && y < a.n[1]) {
+        for (int i = pg; i < a.tm && m0 + i < a.n[2]; i += npg) {
+            const unsigned char on = (unsigned char)((cur[(ty_ + ap) + by * (i + ap)] >> (tx_ + ap)) & 1ull);
+            new_mask[a.origin + x + y * a.s1 + (m0 + i) * a.s2] = on;
+            any |= on;
+        }
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
+}
+
+// band_extrapolate_kernel for 32×8×mc tiles; the block's 256-thread groups share the planes, J per thread and round
+template <int J>
+__global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const unsigned char* target, unsigned char* halo,
+                                                           const unsigned char* src_mask, const signed char* ring, int nring,
+                                                           int nring_lds, const double* src, double* dst, int* miss,
+                                                           BandEntry* list, unsigned* list_count, unsigned list_cap) {
+    const unsigned tile = LSM_TILE_ID(a);
+    if (a.work && !a.work[tile]) return;
+    const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
+    const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
+    const int x = x0 + tx_, y = y0 + ty_;
+    const bool inxy = x < a.n[0] && y < a.n[1];
+    const long long qxy = a.origin + x + y * a.s1;
+    if (target) {   // nothing to do in most tiles: skip them before staging anything
+        int any = 0;
+        if (inxy)
+            for (int i = pg; i < a.tm && m0 + i < a.n[2]; i += npg) {
+                const long long q = qxy + (m0 + i) * a.s2;
+                any |= (target[q] && !src_mask[q]) ? 1 : 0;
+            }
+        if (!__syncthreads_or(any)) return;
+    }
+    const int bx = a.tx + 2 * RL, by = a.ty + 2 * RL, bm = a.tm + 2 * RL, nrows = by * bm;
+    extern __shared__ u64 w3[];
+    u64 *B = w3, *T = w3 + nrows;            // T: halo words of the tile rows (ty × tm)
+    u64* const outs[1] = {B};
+    stage_rows<16, 1>(a, RL, bx, by, bm, x0, y0, m0, outs, [&](const long long (&q)[16], const bool (&ok)[16], const int (&)[16], unsigned (&f)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = src_mask[q[k]];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = ok[k] ? f[k] : 0u;
+    });
+    __syncthreads();
+    if (halo) {
+        // what stencils centred on band nodes read: LSM_GHOST nodes along each axis and the 3^3 box
+        for (int t = threadIdx.x; t < a.ty * a.tm; t += blockDim.x) {
+            const int ly = t % a.ty + RL, lm = t / a.ty + RL, r = ly + by * lm;
+            u64 c = B[r];
+            u64 h = c | (c << 1) | (c >> 1) | (c << 2) | (c >> 2) | (c << 3) | (c >> 3);
+            for (int k = 1; k <= LSM_GHOST; ++k) h |= B[r + k] | B[r - k] | B[r + k * by] | B[r - k * by];
+            for (int dm = -1; dm <= 1; ++dm)
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const u64 d = B[r + dy + dm * by];
+                    h |= d | (d << 1) | (d >> 1);
+                }
+            T[t] = h;
+        }
+        __syncthreads();
+    }
+    // The (node, nearest band node) pairs of the tile are appended with ONE global atomic per block and
+    // J·npg planes: lanes take tile-local slots through an LDS counter first.
+    __shared__ unsigned s_cnt, s_base;
+    const int lx = tx_ + RL, ly = ty_ + RL, lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < a.tm; i0 += J * npg) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        unsigned rec[J], slot[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int i = i0 + j * npg + pg, m = m0 + i, lm = i + RL, r = ly + by * lm;
+            const long long q = qxy + m * a.s2;
+            rec[j] = 0; slot[j] = 0;
+            bool want = inxy && i < a.tm && m < a.n[2];
+            if (want) {
+                const bool inband = (B[r] >> lx) & 1ull;
+                if (halo) {
+                    if (inband) { halo[q] = 1; want = false; }
+                    else if (!(halo[q] | (unsigned char)((T[ty_ + a.ty * i] >> lx) & 1ull))) want = false;
+                    else halo[q] = 1;
+                } else if (!target[q] || inband) {
+                    want = false;
+                }
+            }
+            if (want) {
+                const int I[3] = {x, y, m};
+                int P[3] = {0, 0, 0};
+                // _nearest_band_node inside the (2·RL+1)^3 cube: the first ring hit is the set bit with the smallest
+                // (|off|², o_z, o_y, o_x) — the ring is the column-major offset list stably sorted by |off|².
+                // Per x-line: the nearest set bit to lx, the lower x winning ties.
+                unsigned best = 0xffffffffu;
+                for (int dm = -RL; dm <= RL; ++dm)
+                    for (int dy = -RL; dy <= RL; ++dy) {
+                        const unsigned pat = (unsigned)(B[r + dy + dm * by] >> (lx - RL)) & 0x7fu;   // bit j <-> o_x = j - RL
+                        if (!pat) continue;
+                        const unsigned lo = pat & 0xfu, hi = pat >> 4;                                // o_x <= 0 | o_x >= 1
+                        const int kl = lo ? RL - (31 - __clz((int)lo)) : 99;                         // distance of the nearest o_x <= 0
+                        const int kr = hi ? __ffs((int)hi) : 99;                                      // distance of the nearest o_x >= 1
+                        const int ox = kl <= kr ? -kl : kr;
+                        const unsigned key = ((unsigned)(ox * ox + dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7 + (ox + RL));
+                        best = key < best ? key : best;
+                    }
+                bool found = false;
+                if (best < (16u << 9)) {       // closer than any offset with a component beyond RL: final
+                    const int code = best & 511;
+                    P[0] = x + code % 7 - RL; P[1] = y + (code / 7) % 7 - RL; P[2] = m + code / 49 - RL;
+                    found = true;
+                } else {
+                    found = ring_scan_global(a, src_mask, ring, nring_lds, nring, I, P);
+                }
+                finish_node(a, q, I, P, found, src_mask, src, dst, miss, nullptr, nullptr, 0);
+                if (found) rec[j] = 0x8000u | (unsigned)(I[0] - P[0] + 8) | ((unsigned)(I[1] - P[1] + 8) << 4) | ((unsigned)(I[2] - P[2] + 8) << 8);
+            }
+            if (list) {
+                const u64 bal = __ballot(rec[j] != 0);
+                if (bal) {
+                    const int leader = __ffsll((long long)bal) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                    slot[j] = __shfl(base, leader, 64) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                }
             }
         }
-        if (!found) { atomicOr(miss, 1); continue; }   // the reference throws: farther than the search radius
-        const long long qp = a.origin + P[0] + P[1] * a.s1 + P[2] * a.s2;
         if (list) {
-            const unsigned k = atomicAdd(list_count, 1u);
-            if (k < list_cap) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(list_count, s_cnt) : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (!rec[j]) continue;
+                const unsigned k = s_base + slot[j];
+                if (k >= list_cap) continue;
+                const int d0 = (int)(rec[j] & 15u) - 8, d1 = (int)((rec[j] >> 4) & 15u) - 8, d2 = (int)((rec[j] >> 8) & 15u) - 8;
                 BandEntry e;
-                e.q = q; e.rel = (int)(qp - q);
-                e.d[0] = (signed char)(I[0] - P[0]); e.d[1] = (signed char)(I[1] - P[1]); e.d[2] = (signed char)(I[2] - P[2]); e.d[3] = 0;
+                e.q = qxy + (long long)(m0 + i0 + j * npg + pg) * a.s2;
+                e.rel = -(int)(d0 + d1 * a.s1 + d2 * a.s2);
+                e.d[0] = (signed char)d0; e.d[1] = (signed char)d1; e.d[2] = (signed char)d2; e.d[3] = 0;
                 list[k] = e;
             }
         }
-        if (!dst) continue;
-        const double phiP = src[qp];
-        double val = phiP;
-        for (int d = 0; d < a.ndim; ++d) {
-            const int delta = I[d] - P[d];
-            if (delta == 0) continue;
-            const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-            double slope = 0.0;                                   // _axis_slope: + neighbour first, then -
-            if (P[d] + 1 < a.n[d] && src_mask[qp + sd]) slope = src[qp + sd] - phiP;
-            else if (P[d] - 1 >= 0 && src_mask[qp - sd]) slope = phiP - src[qp - sd];
-            val += (double)delta * slope;
-        }
-        // never let extrapolation invent a sign change far from the band
-        const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
-        dst[q] = (phiP == 0.0 || sv == sp) ? val : phiP;
     }
 }
 
@@ -193,28 +667,6 @@ __global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandE
         }
         const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
         dst[e.q] = (phiP == 0.0 || sv == sp) ? val : phiP;
-    }
-}
-
-// halo of the band = what stencils centred on band nodes can read: up to r nodes along each axis
-// (WENO5 / ENO2 lines) and the 3^N box (curvature's edge diagonals).  In-grid part here; the in-grid
-// nodes that out-of-grid stencil positions resolve to are added by band_halo_bc_kernel.
-__global__ void __launch_bounds__(256) band_cross_kernel(BandArgs a, int r, const unsigned char* in, unsigned char* out) {
-    LSM_TILE_PROLOGUE(a)
-    LSM_TILE_FOR(a, x, y, m, q) {
-        unsigned char o = 0;
-        for (int k = -r; k <= r; ++k) {
-            o |= in[q + k];
-            if (a.ndim > 1) o |= in[q + k * a.s1];
-            if (a.ndim > 2) o |= in[q + k * a.s2];
-        }
-        for (int k2 = -1; k2 <= 1; ++k2)
-            for (int k1 = -1; k1 <= 1; ++k1)
-                for (int k0 = -1; k0 <= 1; ++k0) {
-                    if ((a.ndim < 2 && k1) || (a.ndim < 3 && k2)) continue;
-                    o |= in[q + k0 + k1 * a.s1 + k2 * a.s2];
-                }
-        out[q] = o ? 1 : 0;
     }
 }
 
@@ -269,8 +721,8 @@ __global__ void __launch_bounds__(256) band_halo_bc_kernel(BandArgs a, BandBcArg
 
 // tile activity: tile is active iff it contains a band node (skipped tiles are written 0)
 __global__ void __launch_bounds__(256) band_tiles_kernel(BandArgs a, const unsigned char* mask, unsigned char* tiles) {
-    if (a.work && !a.work[blockIdx.x]) {
-        if (threadIdx.x == 0) tiles[blockIdx.x] = 0;
+    if (a.work && !a.work[LSM_TILE_ID(a)]) {
+        if (threadIdx.x == 0) tiles[LSM_TILE_ID(a)] = 0;
         return;
     }
     LSM_TILE_PROLOGUE(a)
@@ -297,6 +749,57 @@ __global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsign
     work[t] = r ? 1 : 0;
 }
 
+// compact, ordered lists of the active tiles and of the work tiles (active or next to one), so that the
+// next launches cover those tiles only; counts[0..1] = list lengths, counts[2] = number of work tiles on a
+// face of the grid (0: no band node can sit within a tile of the boundary before the next update, so no
+// stencil reaches outside the grid).  One block: chunked exclusive scan, flags read 8 at a time.
+__global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsigned char* active, const unsigned char* work,
+                                                          int* act_list, int* work_list, unsigned* counts) {
+    __shared__ unsigned sa[1024], sw[1024], sb[1024];
+    const unsigned ntiles = a.nbx * a.nby * a.nbm;
+    const unsigned per = ((ntiles + blockDim.x - 1) / blockDim.x + 7u) & ~7u;      // multiple of 8: chunks stay word-aligned
+    const unsigned t0 = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    const bool words = (((unsigned long long)active | (unsigned long long)work) & 7ull) == 0;
+    auto flags8 = [&](const unsigned char* p, unsigned t) -> unsigned long long {   // flags of tiles t .. t+7 (t % 8 == 0)
+        if (words && t + 8 <= ntiles) return *(const unsigned long long*)(p + t);
+        unsigned long long r = 0;
+        for (unsigned k = 0; k < 8 && t + k < ntiles; ++k) r |= (unsigned long long)p[t + k] << (8 * k);
+        return r;
+    };
+    unsigned na = 0, nw = 0, nbd = 0;
+    for (unsigned t = t0; t < t1; t += 8) {
+        const unsigned long long fa = flags8(active, t), fw = flags8(work, t);
+        for (unsigned k = 0; k < 8; ++k) {
+            na += ((fa >> (8 * k)) & 0xff) ? 1 : 0;
+            if ((fw >> (8 * k)) & 0xff) {
+                ++nw;
+                const unsigned tt = t + k, bx = tt % a.nbx, by = (tt / a.nbx) % a.nby, bm = tt / (a.nbx * a.nby);
+                const bool face = bx == 0 || bx == a.nbx - 1 || (a.ndim == 3 && (by == 0 || by == a.nby - 1)) ||
+                                  (a.ndim >= 2 && (bm == 0 || bm == a.nbm - 1));
+                nbd += face ? 1 : 0;
+            }
+        }
+    }
+    sa[threadIdx.x] = na; sw[threadIdx.x] = nw; sb[threadIdx.x] = nbd;
+    __syncthreads();
+    for (unsigned off = 1; off < blockDim.x; off <<= 1) {      // inclusive Hillis-Steele scan
+        const bool on = threadIdx.x >= off;
+        const unsigned va = on ? sa[threadIdx.x - off] : 0, vw = on ? sw[threadIdx.x - off] : 0, vb = on ? sb[threadIdx.x - off] : 0;
+        __syncthreads();
+        sa[threadIdx.x] += va; sw[threadIdx.x] += vw; sb[threadIdx.x] += vb;
+        __syncthreads();
+    }
+    unsigned ia = sa[threadIdx.x] - na, iw = sw[threadIdx.x] - nw;
+    for (unsigned t = t0; t < t1; t += 8) {
+        const unsigned long long fa = flags8(active, t), fw = flags8(work, t);
+        for (unsigned k = 0; k < 8; ++k) {
+            if ((fa >> (8 * k)) & 0xff) act_list[ia++] = (int)(t + k);
+            if ((fw >> (8 * k)) & 0xff) work_list[iw++] = (int)(t + k);
+        }
+    }
+    if (threadIdx.x == blockDim.x - 1) { counts[0] = sa[threadIdx.x]; counts[1] = sw[threadIdx.x]; counts[2] = sb[threadIdx.x]; }
+}
+
 __global__ void __launch_bounds__(256) band_count_kernel(BandArgs a, const unsigned char* mask, unsigned long long* count) {
     LSM_TILE_PROLOGUE(a)
     unsigned long long c = 0;
@@ -305,33 +808,60 @@ __global__ void __launch_bounds__(256) band_count_kernel(BandArgs a, const unsig
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
-static dim3 tile_grid(const BandArgs& a) { return dim3(a.nbx * a.nby * a.nbm); }
+static dim3 tile_grid(const BandArgs& a) { return dim3(a.list ? a.nlist : a.nbx * a.nby * a.nbm); }
+// the row-word kernels need 32×8 tiles whose x-lines (with apron) fit a 64-bit word, and `words` words per row in LDS
+static bool fast3(const BandArgs& a, int ap, int words) {
+    return a.ndim == 3 && a.tx == 32 && a.ty == 8 && a.tx + 2 * ap <= 64 &&
+           (long long)words * 8 * (a.ty + 2 * ap) * (a.tm + 2 * ap) + 8 * a.ty * a.tm <= 65536 && !getenv("LSM_BAND_BYTES");
+}
+static bool no_tiles(const BandArgs& a) { return a.list && a.nlist == 0; }
+static long long box_bytes(const BandArgs& a, long long ap) {
+    return (a.tx + 2 * ap) * (a.ndim == 3 ? a.ty + 2 * ap : 1) * (a.ndim >= 2 ? a.tm + 2 * ap : 1);
+}
 void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s) {
+    if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_cut_kernel, tile_grid(a), dim3(256), 0, s, a, v, old_mask, seed);
 }
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s) {
+    if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_dilate_kernel, tile_grid(a), dim3(256), 0, s, a, in, out);
 }
-void launch_band_box_dilate(const BandArgs& a, int dim, int r, const unsigned char* in, unsigned char* out, hipStream_t s) {
-    hipLaunchKernelGGL(band_box_dilate_kernel, tile_grid(a), dim3(256), 0, s, a, dim, r, in, out);
+void launch_band_grow(const BandArgs& a, const double* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
+                      unsigned char* tiles, hipStream_t s) {
+    if (fast3(a, nl + 1, 5)) {
+        const size_t lds = (size_t)5 * 8 * (a.ty + 2 * (nl + 1)) * (a.tm + 2 * (nl + 1));
+        if (no_tiles(a)) return;
+        hipLaunchKernelGGL(band_grow3_kernel, tile_grid(a), dim3(256), lds, s, a, v, old_mask, nl, new_mask, tiles);
+        return;
+    }
+    if (no_tiles(a)) return;
+    hipLaunchKernelGGL(band_grow_kernel, tile_grid(a), dim3(256), (size_t)box_bytes(a, nl + 1), s, a, v, old_mask, nl, new_mask, tiles);
 }
+bool band_grow_fits(const BandArgs& a, int nl) { return fast3(a, nl + 1, 5) || box_bytes(a, nl + 1) <= LSM_BAND_LDS; }
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s) {
+    if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_copy_kernel, tile_grid(a), dim3(256), 0, s, a, in, out);
 }
-void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, const unsigned char* src_mask, const signed char* ring,
-                             int nring, const double* src, double* dst, int* miss, BandEntry* list, unsigned* list_count,
-                             unsigned list_cap, hipStream_t s) {
-    hipLaunchKernelGGL(band_extrapolate_kernel, tile_grid(a), dim3(256), 0, s, a, target, src_mask, ring, nring, src, dst, miss, list,
-                       list_count, list_cap);
+void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
+                             const signed char* ring, int nring, int nring_lds, const double* src, double* dst, int* miss,
+                             BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s) {
+    if (fast3(a, RL, 1)) {
+        const size_t lds = (size_t)8 * ((a.ty + 2 * RL) * (a.tm + 2 * RL) + a.ty * a.tm);
+        if (no_tiles(a)) return;
+        hipLaunchKernelGGL(band_search3_kernel<8>, tile_grid(a), dim3(256), lds, s, a, target, halo, src_mask, ring, nring, nring_lds, src,
+                           dst, miss, list, list_count, list_cap);
+        return;
+    }
+    const long long bytes = box_bytes(a, RL);
+    if (no_tiles(a)) return;
+    hipLaunchKernelGGL(band_extrapolate_kernel, tile_grid(a), dim3(256), (size_t)(bytes <= LSM_BAND_LDS ? bytes : 0), s, a, target, halo,
+                       src_mask, ring, nring, nring_lds, src, dst, miss, list, list_count, list_cap);
 }
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
                        const unsigned char* src_mask, const double* src, double* dst, hipStream_t s) {
     unsigned blocks = (list_cap + 255) / 256;
     blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(band_apply_kernel, dim3(blocks), dim3(256), 0, s, a, list, list_count, list_cap, src_mask, src, dst);
-}
-void launch_band_cross(const BandArgs& a, int r, const unsigned char* in, unsigned char* out, hipStream_t s) {
-    hipLaunchKernelGGL(band_cross_kernel, tile_grid(a), dim3(256), 0, s, a, r, in, out);
 }
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s) {
@@ -343,13 +873,19 @@ void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, 
     hipLaunchKernelGGL(band_halo_bc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, bc, d, r, band, halo);
 }
 void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned char* tiles, hipStream_t s) {
+    if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_tiles_kernel, tile_grid(a), dim3(256), 0, s, a, mask, tiles);
 }
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
     hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work);
 }
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list,
+                       unsigned* counts, hipStream_t s) {
+    hipLaunchKernelGGL(band_lists_kernel, dim3(1), dim3(1024), 0, s, a, active, work, act_list, work_list, counts);
+}
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s) {
+    if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_count_kernel, tile_grid(a), dim3(256), 0, s, a, mask, count);
 }
 

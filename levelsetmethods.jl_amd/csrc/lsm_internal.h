@@ -52,6 +52,8 @@ struct StageArgs {
     int mc;            // planes per march chunk (0 = the tile's compile-time default)
     const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
+    const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
+    unsigned ntile_list;
 };
 
 struct GhostArgs {
@@ -88,6 +90,9 @@ struct CflArgs {
     double* partial;     // one value per block
     int* nanflag;        // set to 1 if any node produced NaN
     const unsigned char* mask;   // narrow band: only band nodes count (NULL = all nodes)
+    const unsigned char* tile_active;   // narrow band: per-tile activity flags of tx × ty × tm bricks (NULL = none)
+    int tx, ty, tm;
+    unsigned nbx, nby;
 };
 
 // narrow-band kernels (lsm_band.hip)
@@ -98,26 +103,31 @@ struct BandArgs {
     int tx, ty, tm;              // tile footprint (x, y [3-D only], last dimension): the stage kernel's bricks
     unsigned nbx, nby, nbm;      // tiles per direction
     const unsigned char* work;   // per-tile flags: tiles to visit (NULL = all)
+    const int* list;             // compact list of the tiles to visit (NULL = every tile gets a block)
+    unsigned nlist;
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
-void launch_band_box_dilate(const BandArgs& a, int dim, int r, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_grow(const BandArgs& a, const double* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
+                      unsigned char* tiles, hipStream_t s);
+bool band_grow_fits(const BandArgs& a, int nl);
 struct BandEntry {          // a halo node and its nearest band node (16 bytes)
     long long q;            // padded index of the node
     int rel;                // padded index of the nearest band node minus q
     signed char d[4];       // I - P per dimension
 };
-void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, const unsigned char* src_mask, const signed char* ring,
-                             int nring, const double* src, double* dst, int* miss, BandEntry* list, unsigned* list_count,
-                             unsigned list_cap, hipStream_t s);
+void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
+                             const signed char* ring, int nring, int nring_lds, const double* src, double* dst, int* miss,
+                             BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
                        const unsigned char* src_mask, const double* src, double* dst, hipStream_t s);
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s);
-void launch_band_cross(const BandArgs& a, int r, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list,
+                       unsigned* counts, hipStream_t s);
 void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned char* tiles, hipStream_t s);
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s);
 // tile geometry of the stage kernel for a given dimension and march chunk (stage_tu.hip)

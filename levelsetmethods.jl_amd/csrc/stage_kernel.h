@@ -410,11 +410,13 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
     // own L2.  Remap so that every XCD walks a CONTIGUOUS range of tiles (x fastest, then y, then
     // march chunk): tiles sharing halo columns/rows then share an L2 (speed only, never correctness).
-    const unsigned ntiles = a.nb[0] * a.nb[1] * a.nb[2];
+    // Narrow band with a compact (ordered) tile list: the same dealing over the list instead of all tiles.
+    const unsigned ntiles = a.tile_list ? a.ntile_list : a.nb[0] * a.nb[1] * a.nb[2];
     const unsigned per_xcd = (ntiles + 7u) / 8u;
-    const unsigned tile_id = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    unsigned tile_id = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
     if (tile_id >= ntiles) return;   // whole workgroup leaves before any barrier
-    if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
+    if (a.tile_list) tile_id = (unsigned)a.tile_list[tile_id];
+    else if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
     const unsigned tbx = tile_id % a.nb[0];
     const unsigned tby = (tile_id / a.nb[0]) % a.nb[1];
     const unsigned tbm = tile_id / (a.nb[0] * a.nb[1]);
@@ -574,7 +576,8 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     const int mc = a.mc > 0 ? a.mc : T::MC;
     b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
     if (NDIM >= 2 && a.me <= a.mb) return;
-    const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
+    const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
+    if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
     hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, b);
 }
