@@ -207,6 +207,82 @@ function Base.extrema(ϕ::ROCMeshField)
     return lo[], hi[]
 end
 
+# ---- next rows (SURVEY.md §8f) ------------------------------------------------------------------
+
+# volume / perimeter (src/levelsetops.jl:139-149,171-183)
+function LSM.volume(ϕ::ROCMeshField)
+    out = Ref{Float64}()
+    _check(ϕ.handle, ccall((:lsm_volume, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ϕ.handle, pointer(ϕ.buf), out), "lsm_volume")
+    return out[]
+end
+function LSM.perimeter(ϕ::ROCMeshField)
+    out = Ref{Float64}()
+    _check(ϕ.handle, ccall((:lsm_perimeter, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ϕ.handle, pointer(ϕ.buf), out), "lsm_perimeter")
+    return out[]
+end
+
+# extend_along_normals!(F, ϕ; ...) (src/velocityextension.jl:20-116); frozen = nothing -> band rule
+function LSM.extend_along_normals!(F::ROCMeshField, ϕ::ROCMeshField; nb_iters = 50, cfl = 0.45, frozen = nothing,
+                                   interface_band = 1.5, min_norm = 1.0e-14)
+    N = length(ϕ.mesh.n)
+    work = [similar(ϕ.buf) for _ in 1:(N + 1)]
+    w = [i <= length(work) ? pointer(work[i]) : C_NULL for i in 1:4]
+    _check(ϕ.handle, ccall((:lsm_extend_along_normals, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Float64),
+        ϕ.handle, pointer(F.buf), pointer(ϕ.buf), frozen === nothing ? C_NULL : pointer(frozen.buf), w[1], w[2], w[3], w[4],
+        nb_iters, cfl, interface_band, min_norm), "lsm_extend_along_normals")
+    _check(ϕ.handle, ccall((:lsm_sync, libhiplsm), Cint, (Ptr{Cvoid},), ϕ.handle), "lsm_sync")   # work buffers die here
+    return F
+end
+
+# NarrowBandMeshField on the device (src/meshfield.jl:314-588): dense padded values + byte masks.
+const BAND_MC = 8
+mutable struct ROCNarrowBandMeshField{N,T,B} <: LSM.AbstractMeshField{N,T,Float64}
+    buf::ROCVector{Float64}; mesh::CartesianGrid{N,T}; bcs::B; handle::Ptr{Cvoid}; layout::LsmLayout
+    nlayers::Int
+    mask::ROCVector{UInt8}; halo::ROCVector{UInt8}; tiles::ROCVector{UInt8}
+    scratch::NTuple{2,ROCVector{UInt8}}
+    hlist::ROCVector{Int64}; hcount::ROCVector{UInt32}     # (halo node -> nearest band node) entries, 2 Int64 each
+end
+
+# update_band!(ϕ) (src/timestepping.jl:115)
+function LSM.update_band!(ϕ::ROCNarrowBandMeshField; from_dense = false)
+    while true
+        _check(ϕ.handle, ccall((:lsm_band_update, libhiplsm), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+            ϕ.handle, pointer(ϕ.buf), pointer(ϕ.mask), from_dense, ϕ.nlayers, pointer(ϕ.scratch[1]), pointer(ϕ.scratch[2]),
+            pointer(ϕ.halo), pointer(ϕ.tiles), BAND_MC, pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount)), "lsm_band_update")
+        want, missed = Ref{Int64}(), Ref{Cint}()
+        _check(ϕ.handle, ccall((:lsm_band_status, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}, Ref{Cint}),
+            ϕ.handle, pointer(ϕ.hcount), want, missed), "lsm_band_status")
+        missed[] != 0 && throw(ArgumentError("index is more than $(LSM._BAND_SEARCH_RADIUS) nodes from the band"))   # src/meshfield.jl:499-500
+        want[] <= length(ϕ.hlist) ÷ 2 && return ϕ
+        ϕ.hlist = ROCVector{Int64}(undef, 4 * want[])       # list too short: grow it, derive the halo again
+        from_dense = false
+    end
+end
+
+# one stage input made readable by stencils, then the band-restricted stage (what _advance! loops over)
+function _band_stage!(ϕ::ROCNarrowBandMeshField, ts, psi, phin, out, out2, mode, cdt, cdt2, t)
+    _check(ϕ.handle, ccall((:lsm_band_prepare, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+        ϕ.handle, psi, pointer(ϕ.mask), pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount), pointer(ϕ.tiles), BAND_MC), "lsm_band_prepare")
+    _check(ϕ.handle, ccall((:lsm_stage_band, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}),
+        ϕ.handle, ts, length(ts), psi, phin, out, out2, mode, cdt, cdt2, t, pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, C_NULL), "lsm_stage_band")
+end
+
+function LSM.compute_cfl(terms, ϕ::ROCNarrowBandMeshField, t)
+    ts = [_term(term) for term in terms]
+    dt = Ref{Float64}(0.0)
+    _check(ϕ.handle, ccall((:lsm_compute_cfl_band, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ref{Float64}),
+        ϕ.handle, ts, length(ts), pointer(ϕ.buf), pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, t, dt), "lsm_compute_cfl_band")
+    Δt = dt[]
+    Δt > 0 || throw(ArgumentError("invalid time-step based on CFL condition: Δt = $Δt (check for NaN/Inf in velocity or speed)"))
+    return Δt
+end
+
 # usage (drop-in):
 #   ϕ  = MeshField(x -> norm(x) - 0.5, grid; bc = NeumannBC())
 #   eq = LevelSetEquation(; terms = (AdvectionTerm(RigidRotation(1.0, (0.0, 0.0))),), ic = ROCMeshField(ϕ), integrator = RK3())
