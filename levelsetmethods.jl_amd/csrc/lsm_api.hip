@@ -71,6 +71,9 @@ struct LsmHandle {
     std::string err;
     bool cfl_cache_on;
     std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients
+    struct CflCand { LsmTerm key; long long* d_cand; unsigned count; };
+    std::vector<CflCand> cfl_cand;                       // SEPARABLE × g(t): the arg-max candidates are time-independent
+    unsigned* d_cand_count;
     bool prof;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used;
@@ -144,6 +147,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->cfl_cache_on = true;
+    h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
     h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
@@ -219,6 +223,8 @@ void lsm_destroy(LsmHandle* h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
+    for (auto& e : h->cfl_cand) (void)hipFree(e.d_cand);
+    if (h->d_cand_count) (void)hipFree(h->d_cand_count);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_flag);
     (void)hipFree(h->d_w);
@@ -503,7 +509,47 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
             static const bool single_env = getenv("LSM_CFL_SINGLE_PASS") != nullptr;   // A/B switch
             const bool two_pass = !single_env && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
-            if (two_pass) {
+            // u(x)·g(t): the nodes that can attain the maximum are the same for every t (recorded once, with g = 1)
+            static const bool nocand_env = getenv("LSM_CFL_NO_CANDIDATES") != nullptr;   // A/B switch
+            const bool sep_time = two_pass && !nocand_env && h->cfl_cache_on && !h->band_mask && tm.coeff.kind == LSM_COEFF_SEPARABLE &&
+                                  tm.coeff.time_kind != LSM_TIME_ONE && fabs(a.coeff.tfac) > 1e-200;
+            const LsmHandle::CflCand* cand = nullptr;
+            if (sep_time) {
+                for (auto& e : h->cfl_cand)
+                    if (memcmp(&e.key, &tm, sizeof(LsmTerm)) == 0) { cand = &e; break; }
+                if (!cand) {
+                    const unsigned cap = 8192;
+                    if (!h->d_cand_count) LSM_HIP(h, hipMalloc((void**)&h->d_cand_count, sizeof(unsigned)));
+                    long long* buf = nullptr;
+                    LSM_HIP(h, hipMalloc((void**)&buf, cap * sizeof(long long)));
+                    CflArgs b = a;
+                    b.coeff.tfac = 1.0;
+                    b.cand = buf; b.cand_count = h->d_cand_count; b.cand_cap = cap;
+                    LSM_HIP(h, hipMemsetAsync(h->d_cand_count, 0, sizeof(unsigned), h->stream));
+                    launch_cfl(N, b, nb, 0, nullptr, h->stream);
+                    launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 0, h->stream);
+                    launch_cfl(N, b, nb, 2, h->d_result + 1, h->stream);
+                    unsigned cnt = 0;
+                    int flag = 0;
+                    LSM_HIP(h, hipMemcpyAsync(&cnt, h->d_cand_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+                    LSM_HIP(h, hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+                    LSM_HIP(h, hipStreamSynchronize(h->stream));
+                    LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+                    if (!flag && cnt >= 1 && cnt <= cap) {     // NaN tables or a flat maximum: keep sweeping the grid
+                        if (h->cfl_cand.size() > 16) { for (auto& e : h->cfl_cand) (void)hipFree(e.d_cand); h->cfl_cand.clear(); }
+                        h->cfl_cand.push_back({tm, buf, cnt});
+                        cand = &h->cfl_cand.back();
+                    } else {
+                        (void)hipFree(buf);
+                    }
+                }
+            }
+            if (cand) {
+                CflArgs b = a;
+                b.cand = cand->d_cand;
+                launch_cfl_candidates(N, b, cand->count, h->stream);
+                nb = 1;
+            } else if (two_pass) {
                 launch_cfl(N, a, nb, 0, nullptr, h->stream);
                 launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 0, h->stream);
                 launch_cfl(N, a, nb, 1, h->d_result + 1, h->stream);
@@ -958,6 +1004,8 @@ int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;
     h->cfl_cache.clear();
+    for (auto& e : h->cfl_cand) (void)hipFree(e.d_cand);
+    h->cfl_cand.clear();
     return LSM_OK;
 }
 

@@ -198,7 +198,7 @@ __device__ __forceinline__ double wave_max(double v) {
 template <int NDIM, int TKIND, int CKIND>
 __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, const double* thresh_ptr) {
     constexpr int NCOMP = TKIND == LSM_TERM_ADVECTION ? NDIM : 1;
-    const double thresh = pass == 1 && thresh_ptr ? *thresh_ptr : 0.0;
+    const double thresh = pass >= 1 && thresh_ptr ? *thresh_ptr : 0.0;   // pass 2 = pass 1 + record the candidates
     const double ih0 = 1.0 / a.h[0], ih1 = 1.0 / a.h[1], ih2 = 1.0 / a.h[2];
     // one thread per column of the LAST dimension (x fastest across lanes: coalesced FIELD reads);
     // everything that does not depend on the last index is hoisted out of the march.
@@ -279,7 +279,11 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, con
             } else {
                 sv = __builtin_fabs(u[0]);
             }
-            if (pass == 1 && sv >= thresh) {   // candidate: exact value with the reference's divisions
+            if (pass >= 1 && sv >= thresh) {   // candidate: exact value with the reference's divisions
+                if (pass == 2) {
+                    const unsigned slot = atomicAdd(a.cand_count, 1u);
+                    if (slot < a.cand_cap) a.cand[slot] = (NDIM == 3 ? (long long)i0 + (long long)a.n[0] * i1 : (long long)i0) + ncol * m;
+                }
                 if constexpr (TKIND == LSM_TERM_ADVECTION) {
                     sv = __builtin_fabs(u[0]) / a.h[0];
                     if (NDIM > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(256) cfl_kernel(const CflArgs a, int pass, con
                     if (NDIM > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
                     if (NDIM > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
                 }
-            } else if (pass == 1) {
+            } else if (pass >= 1) {
                 sv = 0.0;   // not a candidate
             }
             if (sv == sv) best = sv > best ? sv : best;
@@ -330,6 +334,67 @@ __global__ void __launch_bounds__(256) cfl_final_kernel(const double* partial, i
             out[0] = *nanflag ? __builtin_nan("") : cfl;
         }
     }
+}
+
+// The candidates of a SEPARABLE coefficient u(x)·g(t) do not depend on t (the computed s is |g|·S(x)
+// up to a few ulp), so they are recorded once (pass 2 above, with g = 1) and later steps evaluate the
+// exact s at those nodes only: one small block instead of two sweeps of the grid.  Same arithmetic as
+// the candidate branch of cfl_kernel.
+template <int NDIM, int TKIND>
+__global__ void __launch_bounds__(256) cfl_cand_kernel(const CflArgs a, unsigned count) {
+    constexpr int NCOMP = TKIND == LSM_TERM_ADVECTION ? NDIM : 1;
+    const CoeffArgs& c = a.coeff;
+    const long long ncol = NDIM == 1 ? a.n[0] : (NDIM == 2 ? a.n[0] : (long long)a.n[0] * a.n[1]);
+    const int toff = (NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + a.goff[NDIM - 1];
+    double best = 0.0;
+    int sawnan = 0;
+    for (unsigned i = threadIdx.x; i < count; i += blockDim.x) {
+        const long long e = a.cand[i];
+        const int m = (int)(e / ncol);
+        const long long col = e - (long long)m * ncol;
+        const int i0 = NDIM == 3 ? (int)(col % a.n[0]) : (int)col, i1 = NDIM == 3 ? (int)(col / a.n[0]) : 0;
+        const int g0 = i0 + a.goff[0], g1 = i1 + a.goff[1];
+        double u[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) {
+            double p = c.sep[k][g0];
+            if (NDIM == 3) p = p * c.sep[k][a.gn[0] + g1];
+            if (NDIM > 1) p = p * c.sep[k][toff + m];
+            u[k] = p * c.tfac;
+        }
+        if (u[0] != u[0] || u[1] != u[1] || u[2] != u[2]) sawnan = 1;
+        double sv;
+        if constexpr (TKIND == LSM_TERM_ADVECTION) {
+            sv = __builtin_fabs(u[0]) / a.h[0];
+            if (NDIM > 1) sv = sv + __builtin_fabs(u[1]) / a.h[1];
+            if (NDIM > 2) sv = sv + __builtin_fabs(u[2]) / a.h[2];
+        } else {
+            sv = __builtin_fabs(u[0]) / a.h[0];
+            if (NDIM > 1) sv = sv + __builtin_fabs(u[0]) / a.h[1];
+            if (NDIM > 2) sv = sv + __builtin_fabs(u[0]) / a.h[2];
+        }
+        if (sv == sv) best = sv > best ? sv : best;
+    }
+    best = wave_max(best);
+    sawnan = __any(sawnan) ? 1 : 0;
+    __shared__ double smax[4];
+    __shared__ int snan[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { smax[wave] = best; snan[wave] = sawnan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = smax[0];
+        int f = snan[0];
+        for (int w = 1; w < 4; ++w) { m = smax[w] > m ? smax[w] : m; f |= snan[w]; }
+        a.partial[0] = m;
+        if (f) atomicOr(a.nanflag, 1);
+    }
+}
+void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream_t s) {
+    const bool adv = a.term_kind == LSM_TERM_ADVECTION;
+    if (ndim == 1) { if (adv) hipLaunchKernelGGL((cfl_cand_kernel<1, LSM_TERM_ADVECTION>), dim3(1), dim3(256), 0, s, a, count); else hipLaunchKernelGGL((cfl_cand_kernel<1, LSM_TERM_NORMAL_MOTION>), dim3(1), dim3(256), 0, s, a, count); }
+    else if (ndim == 2) { if (adv) hipLaunchKernelGGL((cfl_cand_kernel<2, LSM_TERM_ADVECTION>), dim3(1), dim3(256), 0, s, a, count); else hipLaunchKernelGGL((cfl_cand_kernel<2, LSM_TERM_NORMAL_MOTION>), dim3(1), dim3(256), 0, s, a, count); }
+    else { if (adv) hipLaunchKernelGGL((cfl_cand_kernel<3, LSM_TERM_ADVECTION>), dim3(1), dim3(256), 0, s, a, count); else hipLaunchKernelGGL((cfl_cand_kernel<3, LSM_TERM_NORMAL_MOTION>), dim3(1), dim3(256), 0, s, a, count); }
 }
 
 static int cfl_chunks(int ndim, const int n[3]) {

@@ -93,6 +93,9 @@ struct CflArgs {
     const unsigned char* tile_active;   // narrow band: per-tile activity flags of tx × ty × tm bricks (NULL = none)
     int tx, ty, tm;
     unsigned nbx, nby;
+    long long* cand;             // pass 2: candidate nodes (i0 + n0·i1 + ncol·m) are appended here
+    unsigned* cand_count;
+    unsigned cand_cap;
 };
 
 // narrow-band kernels (lsm_band.hip)
@@ -151,6 +154,7 @@ void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s);
 void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s);
 int cfl_blocks(int ndim, const int n[3]);
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s);
+void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
                       int pass, hipStream_t s);
 void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const double* v,

@@ -194,6 +194,37 @@ def test_cfl_bitwise(hip, orc, shape):
     assert math.isnan(c.be.compute_cfl_local(arr, 1, c.to_dev(c.pad(phi)), 0.0))
 
 
+@pytest.mark.parametrize("shape", [(60,), (40, 30), (24, 20, 18)])
+def test_cfl_time_separable_coefficient_bitwise_at_every_time(hip, orc, shape):
+    """u(x)·cos(πt/T): the arg-max candidates are recorded on the first call and only those nodes are
+    evaluated afterwards — Δt must stay bitwise equal to the full reduction at every t (sign change,
+    near-zero and zero factor included), for advection and normal motion, and a NaN table entry or a flat
+    (all-equal) field must fall back to the sweep."""
+    nd = len(shape)
+    c = hip.Case(shape, "neumann", mode="fast")
+    phi = _rand_field(shape, 3)
+    rng = np.random.default_rng(11)
+    tabs = lambda ncomp: [[rng.standard_normal(n) for n in shape] for _ in range(ncomp)]
+    p = c.pad(phi)
+    d = c.to_dev(p)
+    T = 3.0
+    for specs in ([("adv", ("sep", tabs(nd), ("cos", T)), "weno5")], [("nm", ("sep", tabs(1), ("cos", T))), ("eik", None)]):
+        ot, arr = c.terms(specs)
+        for t in (0.0, 0.3, 1.4999999, 1.5, 2.0, 2.9, 3.0, 7.7, 0.3):
+            want = orc.cfl_padded(c.grid, c.bc, c.olay, ot, p, t)
+            got = c.be.compute_cfl_local(arr, len(specs), d, t)
+            assert got == want or (math.isinf(got) and math.isinf(want)), (specs[0][0], t, got, want)
+    flat = [[np.ones(n) for n in shape] for _ in range(nd)]          # every node attains the maximum
+    ot, arr = c.terms([("adv", ("sep", flat, ("cos", T)), "upwind")])
+    for t in (0.1, 2.0):
+        assert c.be.compute_cfl_local(arr, 1, d, t) == orc.cfl_padded(c.grid, c.bc, c.olay, ot, p, t)
+    bad = tabs(nd)
+    bad[0][0][shape[0] // 2] = np.nan
+    ot, arr = c.terms([("adv", ("sep", bad, ("cos", T)), "upwind")])
+    for t in (0.1, 2.0):
+        assert math.isnan(c.be.compute_cfl_local(arr, 1, d, t))
+
+
 INTEG = {"fe": 0, "rk2": 1, "rk3": 2}
 
 
