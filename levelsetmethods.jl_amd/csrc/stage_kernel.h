@@ -138,8 +138,8 @@ struct NodeView {
 LSM_DEV double sel64(int m, double x, double y) {   // m = all-ones ? x : y
     return __hiloint2double((__double2hiint(x) & m) | (__double2hiint(y) & ~m), (__double2loint(x) & m) | (__double2loint(y) & ~m));
 }
-template <int NDIM, int D, int G, int W, class NV>
-LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v) {
+template <int NDIM, int D, int G, int W, bool PQ, class NV>
+LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, double& P, double& Q) {
     const int m = ~(__double2hiint(v) >> 31);   // all ones when the sign bit of u_d is clear
     double q[6];
     if constexpr (D == 0 || (D == 1 && NDIM == 3)) {
@@ -156,7 +156,7 @@ LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v) {
         q[4] = sel64(m, nv.zl[G + 1], nv.zl[G - 1]);
         q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
     }
-    const double w = weno5_undivided(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], 1.0e-99 * a.h2[D]);
+    const double w = weno5_undivided_pq<PQ>(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], 1.0e-99 * a.h2[D], P, Q);
     return (__builtin_fabs(v) * a.inv_h[D]) * w;
 }
 #endif
@@ -189,6 +189,13 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
                          const double pre_curv[3], bool active) {
     const double c = nv.c;
     double Ladv = 0.0, Lnm = 0.0, Lcurv = 0.0, Leik = 0.0;
+    double A[3] = {0, 0, 0}, B[3] = {0, 0, 0};   // second-order ENO pairs (NormalMotion, Eikonal)
+#if LSM_STRICT
+    constexpr bool ENO_FROM_WENO = false;
+#else
+    // FAST: a WENO5 line already holds the differences of its ENO pair (stage_math.h, weno5_undivided_pq)
+    constexpr bool ENO_FROM_WENO = ADV == 2 && (NM || EIK);
+#endif
 
     // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
     if constexpr (ADV != 0) {
@@ -202,7 +209,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 #if LSM_STRICT
                 der = weno_dim<NDIM, D, G, W>(nv, a, v);
 #else
-                return weno_term<NDIM, D, G, W>(nv, a, v);
+                return weno_term<NDIM, D, G, W, ENO_FROM_WENO>(nv, a, v, A[D], B[D]);
 #endif
             } else {
 #if LSM_STRICT
@@ -219,8 +226,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     }
 
     // ---- second-order ENO pairs shared by NormalMotion and Eikonal — src/levelsetterms.jl:161-163,255-257
-    double A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
-    if constexpr (NM || EIK) {
+    if constexpr ((NM || EIK) && !ENO_FROM_WENO) {
         auto pr = [&](auto Dc) {
             constexpr int D = decltype(Dc)::value;
             eno2_pair(nv.template at<D>(-2), nv.template at<D>(-1), c, nv.template at<D>(1), nv.template at<D>(2), a.h[D],

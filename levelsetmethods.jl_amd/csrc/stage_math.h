@@ -120,8 +120,19 @@ LSM_DEV double lsm_sqrt(double x0) {
 //     Σ ω_k dϕ_k = dϕ₂ + (ω₁/3)(A₁-A₂) + (ω₃/6)(A₂-A₃),   A_k = e_k - 2e_{k+1} + e_{k+2},
 // (algebraically identical to src/derivatives.jl:63-80 because Σω = 1), with the three weights from
 // ONE reciprocal: ω_k ∝ c_k Π_{j≠k} (S_j+ε)².  eps_floor = 1e-99·h².
-LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, double e5, double eps_floor) {
+// With PQ, the second-order ENO pair of the same line (eno2_pair below) is returned as well, in the
+// upwind frame of the stencil: P = e3 + ½·minmod(w2, w3), Q = e4 - ½·minmod(w4, w3) — the differences
+// it needs are exactly e3, e4, w2, w3, w4.  In the flipped frame (P, Q) = (-B, -A), which the Godunov
+// sum max(σA,0)² + min(σB,0)² does not see, so a fused WENO5 + NormalMotion/Eikonal node computes its
+// ENO pairs for free.
+LSM_DEV double minmod_fast(double x, double y);
+template <bool PQ>
+LSM_DEV double weno5_undivided_pq(double e1, double e2, double e3, double e4, double e5, double eps_floor, double& P, double& Q) {
     const double w1 = e2 - e1, w2 = e3 - e2, w3 = e4 - e3, w4 = e5 - e4;
+    if constexpr (PQ) {
+        P = __builtin_fma(0.5, minmod_fast(w2, w3), e3);
+        Q = __builtin_fma(-0.5, minmod_fast(w4, w3), e4);
+    }
     const double A1 = w2 - w1, A2 = w3 - w2, A3 = w4 - w3;
     const double B1 = __builtin_fma(2.0, w2, A1);      // e1 - 4e2 + 3e3
     const double B2 = w2 + w3;                         // -(e2 - e4)
@@ -142,6 +153,10 @@ LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, doubl
     const double dphi2 = __builtin_fma(-1.0 / 6, e2, __builtin_fma(5.0 / 6, e3, (1.0 / 3) * e4));
     const double X = __builtin_fma(c1W1, A1 - A2, c3W3 * (A2 - A3));
     return __builtin_fma(rc, X, dphi2);
+}
+LSM_DEV double weno5_undivided(double e1, double e2, double e3, double e4, double e5, double eps_floor) {
+    double P, Q;
+    return weno5_undivided_pq<false>(e1, e2, e3, e4, e5, eps_floor, P, Q);
 }
 
 LSM_DEV double weno5_upwind(const double q[6], double /*hs*/, double inv_hs, double eps_floor) {
