@@ -21,6 +21,12 @@
 namespace lsm {
 namespace LSM_NS {
 
+#if LSM_STRICT
+constexpr bool ADV_SCALED = false;
+#else
+constexpr bool ADV_SCALED = true;    // the advection velocity is carried as u_d/h_d (see coeff_prep)
+#endif
+
 constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
     int g = 0;
     if (ADV == 2) g = 3;
@@ -43,18 +49,22 @@ LSM_DEV void stg(double* base, unsigned boff, double v) {
 // split into the part that is constant along the march axis (hoisted out of the plane loop: table
 // look-ups of the leading dimensions, the in-plane rotation) and the per-plane remainder.
 // Operation order is exactly ((T1*T2)*T3)*g and lc + i*h, as in the oracle.
-template <int NDIM, int NCOMP>
+// SCALED (FAST build, advection velocity only): the values produced are u_d/h_d — the factor 1/h_d and
+// the time factor g(t) are folded into the hoisted part, so the per-node remainder is one multiply.
+template <int NDIM, int NCOMP, bool SCALED = false>
 LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1, double pre[3]) {
     pre[0] = pre[1] = pre[2] = 0.0;
     if (c.kind == LSM_COEFF_CONST) {
 #pragma unroll
-        for (int k = 0; k < NCOMP; ++k) pre[k] = c.v[k];
+        for (int k = 0; k < NCOMP; ++k) pre[k] = SCALED ? c.v[k] * a.inv_h[k] : c.v[k];
     } else if (c.kind == LSM_COEFF_ROTATION) {
         const double x1 = a.lc[0] + (double)gi0 * a.h[0];
         pre[1] = c.v[0] * (x1 - c.v[1]);
+        if (SCALED) pre[1] = pre[1] * a.inv_h[1];
         if (NDIM == 3) {
             const double x2 = a.lc[1] + (double)gi1 * a.h[1];
             pre[0] = -(c.v[0] * (x2 - c.v[2]));
+            if (SCALED) pre[0] = pre[0] * a.inv_h[0];
         }
     } else if (c.kind == LSM_COEFF_SEPARABLE) {
 #pragma unroll
@@ -62,11 +72,11 @@ LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1
             const double* T = c.sep[k];
             double p = T[gi0];
             if (NDIM == 3) p = p * T[a.gn[0] + gi1];
-            pre[k] = p;
+            pre[k] = SCALED ? p * (c.tfac * a.inv_h[k]) : p;
         }
     }
 }
-template <int NDIM, int NCOMP>
+template <int NDIM, int NCOMP, bool SCALED = false>
 LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], int gim, long long plane_off, unsigned ocol,
                         double out[3]) {
     if (c.kind == LSM_COEFF_CONST) {
@@ -76,6 +86,7 @@ LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre
         if (NDIM == 2) {
             const double x2 = a.lc[1] + (double)gim * a.h[1];
             out[0] = -(c.v[0] * (x2 - c.v[2]));
+            if (SCALED) out[0] = out[0] * a.inv_h[0];
         } else {
             out[0] = pre[0];
         }
@@ -86,11 +97,14 @@ LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre
         for (int k = 0; k < NCOMP; ++k) {
             double p = pre[k];
             if (NDIM > 1) p = p * c.sep[k][(NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gim];
-            out[k] = p * c.tfac;
+            out[k] = SCALED ? p : p * c.tfac;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NCOMP; ++k) out[k] = ldg(c.f[k] + plane_off, ocol);
+        for (int k = 0; k < NCOMP; ++k) {
+            out[k] = ldg(c.f[k] + plane_off, ocol);
+            if (SCALED) out[k] = out[k] * a.inv_h[k];
+        }
     }
 }
 
@@ -157,7 +171,7 @@ LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, double& P, 
         q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
     }
     const double w = weno5_undivided_pq<PQ>(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], 1.0e-99 * a.h2[D], P, Q);
-    return (__builtin_fabs(v) * a.inv_h[D]) * w;
+    return __builtin_fabs(v) * w;          // v = u_d/h_d
 }
 #endif
 
@@ -200,7 +214,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
     if constexpr (ADV != 0) {
         double u[3];
-        coeff_eval<NDIM, NDIM>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocol, u);
+        coeff_eval<NDIM, NDIM, ADV_SCALED>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocol, u);   // FAST: u_d/h_d
         auto one = [&](auto Dc) {
             constexpr int D = decltype(Dc)::value;
             const double v = u[D];
@@ -215,7 +229,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 #if LSM_STRICT
                 der = v > 0 ? (c - nv.template at<D>(-1)) / a.h[D] : (nv.template at<D>(1) - c) / a.h[D];
 #else
-                der = (v > 0 ? (c - nv.template at<D>(-1)) : (nv.template at<D>(1) - c)) * a.inv_h[D];
+                der = v > 0 ? (c - nv.template at<D>(-1)) : (nv.template at<D>(1) - c);      // v = u_d/h_d
 #endif
             }
             return v * der;
@@ -487,7 +501,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
     {
         const int gi0 = cx + a.goff[0], gi1 = HAS_Y ? cy + a.goff[1] : 0;
-        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM>(a.adv, a, gi0, gi1, pre_adv);
+        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED>(a.adv, a, gi0, gi1, pre_adv);
         if constexpr (NM != 0) coeff_prep<NDIM, 1>(a.nm, a, gi0, gi1, pre_nm);
         if constexpr (CURV != 0) coeff_prep<NDIM, 1>(a.curv, a, gi0, gi1, pre_curv);
     }
