@@ -270,7 +270,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         double g2 = 0.0;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) g2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
-        Lnm = v * lsm_sqrt(g2);
+        Lnm = v * fast_norm(g2);
 #endif
     }
 
@@ -356,7 +356,11 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) n2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
 #endif
+#if LSM_STRICT
         const double nrm = lsm_sqrt(n2);
+#else
+        const double nrm = fast_norm(n2);
+#endif
         double S;
         if constexpr (EIK == 1) {
             S = s;
