@@ -195,3 +195,124 @@ def test_volume_perimeter_known_answers_and_parity(lsm, orc):
     assert st[(3, 4, 5)] == f3.vals[3, 4, 5]
     st[(3, 4, 5)] = 7.5
     assert st.values()[3, 4, 5] == 7.5 and st.ghosts_dirty
+
+
+class _FakeWorld:
+    """In-process stand-in for a torch.distributed group: the ranks are threads of this process, point-to-point
+    messages are device-tensor copies through FIFO mailboxes (matched in posting order per pair, as RCCL does)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.cond = threading.Condition()
+        self.mail = {}
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def post(self, src, dst, t):
+        with self.cond:
+            self.mail.setdefault((src, dst), []).append(t.clone())
+            self.cond.notify_all()
+
+    def take(self, src, dst):
+        with self.cond:
+            assert self.cond.wait_for(lambda: self.mail.get((src, dst)), timeout=120), "exchange deadlock"
+            return self.mail[(src, dst)].pop(0)
+
+    def exchange(self, rank, value):
+        self.slots[rank] = value
+        self.barrier.wait()
+        out = list(self.slots)
+        self.barrier.wait()
+        return out
+
+
+class _FakeRank:
+    def __init__(self, w, rank):
+        self.w, self.rank = w, rank
+
+
+def _patch_dist(monkeypatch):
+    import collections
+    import torch.distributed as dist
+    P2P = collections.namedtuple("P2POp", "op tensor peer group")
+    monkeypatch.setattr(dist, "get_rank", lambda g=None: g.rank)
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: g.w.world)
+    monkeypatch.setattr(dist, "P2POp", lambda op, tensor, peer, group=None: P2P(op, tensor, peer, group))
+    monkeypatch.setattr(dist, "isend", "isend")
+    monkeypatch.setattr(dist, "irecv", "irecv")
+
+    class Work:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def wait(self):
+            self.fn()
+
+    def batch(ops):
+        works = []
+        for o in ops:
+            g = o.group
+            if o.op == "isend":
+                g.w.post(g.rank, o.peer, o.tensor)
+            else:
+                works.append(Work(lambda o=o, g=g: o.tensor.copy_(g.w.take(o.peer, g.rank))))
+        return works
+
+    def all_reduce(x, op=None, group=None):
+        vals = group.w.exchange(group.rank, x.clone())
+        r = vals[0].clone()
+        for v in vals[1:]:
+            r = torch_min(r, v) if op == dist.ReduceOp.MIN else r + v
+        x.copy_(r)
+
+    import torch
+    torch_min = torch.minimum
+
+    def all_gather_object(parts, v, group=None):
+        vals = group.w.exchange(group.rank, v)
+        for i, x in enumerate(vals):
+            parts[i] = x
+
+    monkeypatch.setattr(dist, "batch_isend_irecv", batch)
+    monkeypatch.setattr(dist, "all_reduce", all_reduce)
+    monkeypatch.setattr(dist, "all_gather_object", all_gather_object)
+
+
+@pytest.mark.parametrize("world,bc,overlap", [(2, "neumann", True), (3, "neumann", False), (3, "periodic", True), (2, "periodic", False)])
+def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkeypatch, world, bc, overlap):
+    """True slab handles (plane offset, LSM_BC_NONE interfaces, plane-range stages, the exchange driver of
+    api.py) on the GPU: `world` ranks run as threads of this process over an in-process stand-in for the RCCL
+    group.  The concatenated slabs must equal the single-device run bit for bit, Δt reduction included."""
+    import threading
+    _patch_dist(monkeypatch)
+    monkeypatch.setenv("LSM_SLAB_OVERLAP", "1" if overlap else "0")
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (24, 20, 41))
+    ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.4) ** 2) - 0.2, grid)
+    bcs = lsm.PeriodicBC() if bc == "periodic" else lsm.NeumannBC()
+    mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()),
+                                                  lsm.EikonalReinitializationTerm()), ic=ic, bc=bcs, integrator=lsm.RK3(), **kw)
+    ref = mk()
+    lsm.integrate_(ref, 0.03)
+    want = ref.current_state().values()
+    w = _FakeWorld(world)
+    got, errs = [None] * world, []
+
+    def run(r):
+        try:
+            eq = mk(comm=_FakeRank(w, r))
+            lsm.integrate_(eq, 0.03)
+            got[r] = eq.current_state().values()
+        except BaseException as e:   # noqa: BLE001 - reported by the main thread
+            errs.append((r, repr(e)))
+            w.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    full = np.concatenate(got, axis=2)
+    assert full.shape == want.shape
+    assert np.array_equal(full, want), np.abs(full - want).max()
