@@ -188,8 +188,8 @@ def main():
     }
     # HBM traffic of the stage kernel: PMC counters cannot be collected from inside this process, so the
     # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/r1/,
-    # tools_profile.sh), corrected as calibrated on gfx950 with known-traffic kernels of the same access
-    # width (tools_configs.py calib): FETCH_SIZE counts 1/2 of 8-byte-per-lane reads, WRITE_SIZE is exact.
+    # tools/profile.sh), corrected as calibrated on gfx950 with known-traffic kernels of the same access
+    # width (tools/configs.py calib): FETCH_SIZE counts 1/2 of 8-byte-per-lane reads, WRITE_SIZE is exact.
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch.json")))
         st = next(v for k, v in pj.items() if "stage_kernel<3, 2, 0, 0, 2" in k)
@@ -198,7 +198,7 @@ def main():
     except Exception:
         pass
     # the binding resource is the fp64 vector pipe: ~250 fp64 VALU instructions per node-stage, of which 75 are
-    # FMAs: 320 flop (opcode histogram of the loop body, tools_isa_hist.py)
+    # FMAs: 320 flop (opcode histogram of the loop body, tools/isa_hist.py)
     flop_per_node_stage = 320.0
     out["fp64_vector"] = {"achieved_tflops": round(local_cells * 3 * args.steps * flop_per_node_stage / (stage_ms * 1e-3) / 1e12, 2)
                           if n_launch else 0.0, "peak_tflops": FP64_PEAK_TFLOPS,

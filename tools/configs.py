@@ -8,6 +8,9 @@ import time
 import numpy as np
 import torch
 
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import lsm_amd as lsm
 
 

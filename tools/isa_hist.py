@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Opcode histogram of the largest loop of one kernel in a hipcc -S listing: tools_isa_hist.py file.s <mangled-prefix>"""
+"""Opcode histogram of the largest loop of one kernel in a hipcc -S listing: tools/isa_hist.py file.s <mangled-prefix>"""
 import collections, re, sys
 lines = open(sys.argv[1]).read().split('\n')
 pref = sys.argv[2]

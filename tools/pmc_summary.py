@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Aggregate the PMC passes of tools_profile.sh into per-kernel averages per dispatch:
-tools_pmc_summary.py <profile-dir> <out.json>   (counters as reported; FETCH_SIZE / WRITE_SIZE in KiB)"""
+"""Aggregate the PMC passes of tools/profile.sh into per-kernel averages per dispatch:
+tools/pmc_summary.py <profile-dir> <out.json>   (counters as reported; FETCH_SIZE / WRITE_SIZE in KiB)"""
 import collections
 import csv
 import glob

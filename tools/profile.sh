@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_profile.sh <outdir>  — rocprofv3 kernel trace + PMC passes of the bench (GPU box)
+# usage: tools/profile.sh <outdir>  — rocprofv3 kernel trace + PMC passes of the bench (GPU box)
 set -u
 OUT=$1
 mkdir -p $OUT
