@@ -120,6 +120,11 @@ enum {
                              within 1e-13*max|phi| of the reference arithmetic per stage */
     LSM_MODE_STRICT = 1   /* literal reference operation order, IEEE division, no contraction */
 };
+/* storage type of the level-set fields of a handle (ϕ, stage buffers, extension targets).  LSM_DTYPE_F32 is a
+ * storage format only: values widen exactly on load, every computation is fp64, results are rounded to nearest
+ * on store (the reference's Float32 fields compute in mixed Float32/Float64 by Julia's promotion rules; its
+ * results differ from the fp64 ones by O(1e-7) relative, and so do these).  Coefficient fields, frozen signs and
+ * frozen masks ("side arrays") are fp64 for either dtype, and so is every reduction. */
 enum { LSM_DTYPE_F64 = 0, LSM_DTYPE_F32 = 1 };
 
 typedef struct LsmHandle LsmHandle;
@@ -144,6 +149,9 @@ int lsm_set_stream(LsmHandle* h, void* stream);
 int lsm_layout(const LsmHandle* h, LsmLayout* out);
 int lsm_upload(LsmHandle* h, void* dev_padded, const void* host_dense);     /* interior only; synchronous */
 int lsm_download(LsmHandle* h, const void* dev_padded, void* host_dense);   /* interior only; synchronous */
+/* the same for the fp64 side arrays of a handle of either dtype (host dense array of double) */
+int lsm_upload_f64(LsmHandle* h, void* dev_padded, const void* host_dense);
+int lsm_download_f64(LsmHandle* h, const void* dev_padded, void* host_dense);
 
 /* ---- ghost resolution: _getindexbc + bc_stencil (src/meshfield.jl:248-260,
  *      src/boundaryconditions.jl:107-153) materialised into the ghost layers, dim 1 -> dim N.

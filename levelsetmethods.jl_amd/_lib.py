@@ -23,6 +23,7 @@ TIME_ONE, TIME_COS = 0, 1
 BASE_PSI, BASE_RK3_S2, BASE_RK3_S3, BASE_OTHER = 0, 1, 2, 3
 MODE_FAST, MODE_STRICT = 0, 1
 DTYPE_F64 = 0
+DTYPE_F32 = 1
 
 
 class LsmGrid(C.Structure):
@@ -67,6 +68,8 @@ _SIGS = [
     ("lsm_layout", C.c_int, [_H, C.POINTER(LsmLayout)]),
     ("lsm_upload", C.c_int, [_H, C.c_void_p, C.c_void_p]),
     ("lsm_download", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("lsm_upload_f64", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("lsm_download_f64", C.c_int, [_H, C.c_void_p, C.c_void_p]),
     ("lsm_fill_ghosts", C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     ("lsm_stage", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                             C.c_double, C.c_double, C.c_double, C.c_void_p]),

@@ -151,7 +151,13 @@ class MeshField:
     grid.n in Fortran order (the reference's column-major Array), or shape (ncomp, *grid.n) for
     vector-valued coefficient fields."""
 
-    def __init__(self, vals_or_f, grid, bc=None):
+    def __init__(self, vals_or_f, grid, bc=None, dtype=None):
+        # element type as in the reference (the eltype of `vals`): float64, or float32 storage when asked for / given
+        if dtype is None:
+            dtype = np.float32 if getattr(vals_or_f, "dtype", None) == np.float32 else np.float64
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError(f"unsupported element type {dtype}: float64 or float32")
         if callable(vals_or_f):
             xs = np.meshgrid(*grid.coords(), indexing="ij", sparse=True)
             v = vals_or_f(tuple(xs))
@@ -159,9 +165,9 @@ class MeshField:
                 v = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), grid.n) for c in v])
             else:
                 v = np.broadcast_to(np.asarray(v, dtype=np.float64), grid.n)
-            vals = np.array(v, dtype=np.float64)
+            vals = np.array(v, dtype=dtype)
         else:
-            vals = np.array(vals_or_f, dtype=np.float64)
+            vals = np.array(vals_or_f, dtype=dtype)
         if vals.shape[-grid.ndim:] != grid.n:
             raise ValueError(f"values of shape {vals.shape} do not match the grid {grid.n}")
         self.vals = np.asfortranarray(vals) if vals.ndim == grid.ndim else vals
@@ -175,7 +181,7 @@ class MeshField:
         return self.vals
 
     def copy(self):
-        m = MeshField(self.vals.copy(order="K"), self.mesh)
+        m = MeshField(self.vals.copy(order="K"), self.mesh, dtype=self.vals.dtype)
         m.bcs = self.bcs
         return m
 
@@ -228,8 +234,9 @@ class LazyMeshField:
     """MeshField(f, grid) whose samples are only ever materialised slab by slab (large grids,
     multi-GPU): `f` receives a tuple of broadcastable coordinate arrays like MeshField's."""
 
-    def __init__(self, f, grid, bc=None):
+    def __init__(self, f, grid, bc=None, dtype=np.float64):
         self.f, self.mesh = f, grid
+        self.dtype = np.dtype(dtype)
         self.bcs = None if bc is None else _normalize_bc(bc, grid.ndim)
 
     def has_boundary_conditions(self):
@@ -500,7 +507,7 @@ class _Coeff:
                 self.c.sep[k] = t.data_ptr()
         elif isinstance(spec, (MeshField, ROCMeshField)) or callable(spec):
             self.c.kind = L.COEFF_FIELD
-            self.fields = [backend.alloc() for _ in range(ncomp)]
+            self.fields = [getattr(backend, "alloc_side", backend.alloc)() for _ in range(ncomp)]
             for k, t in enumerate(self.fields):
                 self.c.field[k] = t.data_ptr()
             if callable(spec):
@@ -526,7 +533,7 @@ class _Coeff:
         if vals.ndim == self.grid.ndim:
             vals = vals[None]
         for k in range(self.ncomp):
-            self.backend.upload(self.fields[k], self._local(vals[k]))
+            getattr(self.backend, "upload_side", self.backend.upload)(self.fields[k], self._local(vals[k]))
 
     def refresh(self, t):
         """Slow path: re-sample a python callable f(x, t) on the host."""
@@ -609,7 +616,7 @@ class EikonalReinitializationTerm(LevelSetTerm):
             src = backend.alloc()
             v = self.phi0.vals if isinstance(self.phi0, MeshField) else np.asarray(self.phi0)
             backend.upload(src, v if slab is None else v[..., slab[0]:slab[0] + slab[1]])
-        self.s0 = backend.alloc()
+        self.s0 = getattr(backend, "alloc_side", backend.alloc)()
         backend.eikonal_sign(src, self.s0)
 
     def __repr__(self):
@@ -707,10 +714,19 @@ class LevelSetEquation:
             periodic = bcs[N - 1][0].kind == L.BC_PERIODIC
             slab_faces = (self.rank > 0 or (periodic and self.world > 1), self.rank < self.world - 1 or (periodic and self.world > 1))
             self.periodic_last = periodic
+        # storage type of the state = element type of `ic` (side arrays and all arithmetic stay float64)
+        if isinstance(ic, ROCMeshField):
+            self.dtype = ic.backend.dtype if hasattr(ic.backend, "dtype") else np.dtype(np.float64)
+        elif isinstance(ic, LazyMeshField):
+            self.dtype = ic.dtype
+        else:
+            self.dtype = np.dtype(ic.vals.dtype)
         factory = backend_factory
         if factory is None:
             from .backend import HipBackend
-            factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device)
+            factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device, dtype=self.dtype)
+        elif self.dtype != np.float64:
+            raise ValueError("float32 fields need the HIP backend")
         self.backend = factory(grid._c(), _bc_c(bcs, N, slab_faces), self.slab)
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
         self.band = isinstance(ic, NarrowBandMeshField)
@@ -1028,13 +1044,13 @@ def extend_along_normals_(F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_
     fz = None
     if frozen is not None:
         if isinstance(frozen, ROCMeshField):
-            fz = frozen.buf
+            fz = frozen.buf if str(frozen.buf.dtype) == "torch.float64" else frozen.buf.double()   # side arrays are float64
         else:
             a = np.asarray(frozen.vals if isinstance(frozen, MeshField) else frozen)
             if a.shape != phi.mesh.n:
                 raise ValueError("frozen mask must have the same size as ϕ")
-            fz = b.alloc()
-            b.upload(fz, a.astype(np.float64))
+            fz = getattr(b, "alloc_side", b.alloc)()
+            getattr(b, "upload_side", b.upload)(fz, a.astype(np.float64))
     b.extend_along_normals(F.buf, phi.buf, fz, int(nb_iters), float(cfl), float(interface_band), float(min_norm))
     F.ghosts_dirty = True
     return F

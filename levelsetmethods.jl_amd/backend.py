@@ -17,7 +17,7 @@ from . import _lib as L
 class HipBackend:
     name = "hip"
 
-    def __init__(self, grid_c, bc_c, slab=None, mode="fast", device=0):
+    def __init__(self, grid_c, bc_c, slab=None, mode="fast", device=0, dtype=np.float64):
         import torch
 
         if not torch.cuda.is_available():
@@ -31,9 +31,13 @@ class HipBackend:
         self._grid = grid_c
         self._bc = bc_c
         self.slab = slab
+        self.dtype = np.dtype(dtype)          # storage of the level-set fields (float64 | float32); side arrays are float64
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError(f"unsupported field dtype {self.dtype}: float64 or float32")
         h = C.c_void_p()
         slab_c = L.LsmSlab(slab[0], slab[1]) if slab is not None else None
-        code = self.lib.lsm_create(C.byref(grid_c), bc_c, C.byref(slab_c) if slab_c is not None else None, L.DTYPE_F64,
+        code = self.lib.lsm_create(C.byref(grid_c), bc_c, C.byref(slab_c) if slab_c is not None else None,
+                                   L.DTYPE_F32 if self.dtype == np.float32 else L.DTYPE_F64,
                                    L.MODE_STRICT if mode == "strict" else L.MODE_FAST, device, C.byref(h))
         if code != L.OK:
             raise L.LsmError(f"lsm_create failed ({code}): {self.lib.lsm_last_error(None).decode()}")
@@ -57,6 +61,12 @@ class HipBackend:
 
     # ---- memory
     def alloc(self):
+        """A level-set field (ϕ, stage buffer, extension target) in the handle's storage type."""
+        tdt = self.torch.float32 if self.dtype == np.float32 else self.torch.float64
+        return self.torch.zeros(int(self.lay.total), dtype=tdt, device=self.device)
+
+    def alloc_side(self):
+        """A side array (coefficient field, frozen sign / mask): always float64."""
         return self.torch.zeros(int(self.lay.total), dtype=self.torch.float64, device=self.device)
 
     def clone(self, t):
@@ -72,13 +82,23 @@ class HipBackend:
         return tuple(int(self.lay.n[d]) for d in range(self.ndim))
 
     def upload(self, t, dense):
-        a = np.asfortranarray(dense, dtype=np.float64)
+        a = np.asfortranarray(dense, dtype=self.dtype)
         assert a.shape == self.local_shape(), (a.shape, self.local_shape())
         L.check(self.h, self.lib.lsm_upload(self.h, self.ptr(t), a.ctypes.data_as(C.c_void_p)), "lsm_upload")
 
     def download(self, t):
-        out = np.empty(self.local_shape(), dtype=np.float64, order="F")
+        out = np.empty(self.local_shape(), dtype=self.dtype, order="F")
         L.check(self.h, self.lib.lsm_download(self.h, self.ptr(t), out.ctypes.data_as(C.c_void_p)), "lsm_download")
+        return out
+
+    def upload_side(self, t, dense):
+        a = np.asfortranarray(dense, dtype=np.float64)
+        assert a.shape == self.local_shape(), (a.shape, self.local_shape())
+        L.check(self.h, self.lib.lsm_upload_f64(self.h, self.ptr(t), a.ctypes.data_as(C.c_void_p)), "lsm_upload_f64")
+
+    def download_side(self, t):
+        out = np.empty(self.local_shape(), dtype=np.float64, order="F")
+        L.check(self.h, self.lib.lsm_download_f64(self.h, self.ptr(t), out.ctypes.data_as(C.c_void_p)), "lsm_download_f64")
         return out
 
     def table(self, arr):
@@ -130,7 +150,7 @@ class HipBackend:
         return lo.value, hi.value
 
     def extend_along_normals(self, F, phi, frozen, nb_iters, cfl, interface_band, min_norm):
-        work = [self.alloc() for _ in range(self.ndim + 1)]
+        work = [self.alloc()] + [self.alloc_side() for _ in range(self.ndim)]   # F staging + the normal components
         w = [self.ptr(x) for x in work] + [None] * (4 - len(work))
         L.check(self.h, self.lib.lsm_extend_along_normals(self.h, self.ptr(F), self.ptr(phi), self.ptr(frozen), w[0], w[1], w[2], w[3],
                                                           nb_iters, cfl, interface_band, min_norm), "lsm_extend_along_normals")

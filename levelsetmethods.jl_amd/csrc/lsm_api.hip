@@ -94,6 +94,11 @@ static int fail(LsmHandle* h, int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(h, LSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// storage of a field value: 8 bytes, or 4 for LSM_DTYPE_F32 handles (coefficient fields, frozen signs and every
+// reduction stay fp64)
+static inline int is_f32(const LsmHandle* h) { return h->dtype == LSM_DTYPE_F32 ? 1 : 0; }
+static inline size_t esize(const LsmHandle* h) { return h->dtype == LSM_DTYPE_F32 ? sizeof(float) : sizeof(double); }
+
 // _lagrange_extrap_weight — src/boundaryconditions.jl:90-97
 static double lagrange_w(int j, int k, int P) {
     double w = 1.0;
@@ -114,7 +119,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
                LsmHandle** out) {
     if (!grid || !bc || !out) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: null argument");
     if (grid->ndim < 1 || grid->ndim > 3) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: ndim must be 1, 2 or 3");
-    if (dtype != LSM_DTYPE_F64) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: only LSM_DTYPE_F64 is implemented");
+    if (dtype != LSM_DTYPE_F64 && dtype != LSM_DTYPE_F32) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: dtype must be LSM_DTYPE_F64 or LSM_DTYPE_F32");
     if (mode != LSM_MODE_FAST && mode != LSM_MODE_STRICT) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad mode");
     const int N = grid->ndim;
     for (int d = 0; d < 3; ++d) {
@@ -257,27 +262,36 @@ int lsm_layout(const LsmHandle* h, LsmLayout* out) {
     return LSM_OK;
 }
 
-static int copy_interior(LsmHandle* h, void* dev, void* host, bool to_dev) {
+static int copy_interior(LsmHandle* h, void* dev, void* host, bool to_dev, size_t es) {
     LSM_HIP(h, hipSetDevice(h->device));
-    const size_t row = sizeof(double) * (size_t)h->nloc[0];
+    const size_t row = es * (size_t)h->nloc[0];
     for (int k = 0; k < h->nloc[2]; ++k) {
-        double* d = (double*)dev + h->lay.origin + (long long)k * h->lay.stride[2];
-        double* s = (double*)host + (size_t)k * h->nloc[0] * h->nloc[1];
+        char* d = (char*)dev + es * (size_t)(h->lay.origin + (long long)k * h->lay.stride[2]);
+        char* s = (char*)host + es * ((size_t)k * h->nloc[0] * h->nloc[1]);
         if (to_dev)
-            LSM_HIP(h, hipMemcpy2DAsync(d, sizeof(double) * h->lay.stride[1], s, row, row, h->nloc[1], hipMemcpyHostToDevice, h->stream));
+            LSM_HIP(h, hipMemcpy2DAsync(d, es * h->lay.stride[1], s, row, row, h->nloc[1], hipMemcpyHostToDevice, h->stream));
         else
-            LSM_HIP(h, hipMemcpy2DAsync(s, row, d, sizeof(double) * h->lay.stride[1], row, h->nloc[1], hipMemcpyDeviceToHost, h->stream));
+            LSM_HIP(h, hipMemcpy2DAsync(s, row, d, es * h->lay.stride[1], row, h->nloc[1], hipMemcpyDeviceToHost, h->stream));
     }
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     return LSM_OK;
 }
 int lsm_upload(LsmHandle* h, void* dev_padded, const void* host_dense) {
     if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
-    return copy_interior(h, dev_padded, (void*)host_dense, true);
+    return copy_interior(h, dev_padded, (void*)host_dense, true, esize(h));
 }
 int lsm_download(LsmHandle* h, const void* dev_padded, void* host_dense) {
     if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
-    return copy_interior(h, (void*)dev_padded, host_dense, false);
+    return copy_interior(h, (void*)dev_padded, host_dense, false, esize(h));
+}
+// the fp64 side arrays of a handle of either dtype: coefficient fields, frozen masks, frozen signs
+int lsm_upload_f64(LsmHandle* h, void* dev_padded, const void* host_dense) {
+    if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
+    return copy_interior(h, dev_padded, (void*)host_dense, true, sizeof(double));
+}
+int lsm_download_f64(LsmHandle* h, const void* dev_padded, void* host_dense) {
+    if (!h || !dev_padded || !host_dense) return LSM_ERR_INVALID;
+    return copy_interior(h, (void*)dev_padded, host_dense, false, sizeof(double));
 }
 
 static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s) {
@@ -288,7 +302,7 @@ static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill
     for (int d = 0; d < 3; ++d)
         for (int sd = 0; sd < 2; ++sd) { a.kind[d][sd] = h->bc[d][sd].kind; a.degree[d][sd] = h->bc[d][sd].degree; }
     a.w = h->d_w;
-    a.v = (double*)field;
+    a.v = field; a.f32 = is_f32(h);
     a.mb = mb; a.me = me; a.fill_last = fill_last;
     launch_ghost_fill_all(N, a, s);
     LSM_HIP(h, hipGetLastError());
@@ -311,7 +325,7 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
         a.dim = d;
         for (int sd = 0; sd < 2; ++sd) { a.kind[sd] = h->bc[d][sd].kind; a.degree[sd] = h->bc[d][sd].degree; }
         memcpy(a.w, h->w[d], sizeof(a.w));
-        a.v = (double*)field;
+        a.v = field; a.f32 = is_f32(h);
         launch_ghost_fill(N, a, s);
     }
     LSM_HIP(h, hipGetLastError());
@@ -342,6 +356,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.dxmin = h->dxmin;
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
+    a.f32 = is_f32(h);
 }
 
 static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
@@ -594,7 +609,7 @@ int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, vo
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));
-    LSM_HIP(h, hipMemcpyAsync(phi, buf1, sizeof(double) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));   // copy!(ϕ, dst)
+    LSM_HIP(h, hipMemcpyAsync(phi, buf1, esize(h) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));   // copy!(ϕ, dst)
     return lsm_fill_ghosts(h, phi, 7, nullptr);
 }
 
@@ -634,7 +649,7 @@ int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream)
     if (!h || !phi0 || !s0_out) return LSM_ERR_INVALID;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     launch_eikonal_sign(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->dxmin,
-                        (const double*)phi0, (double*)s0_out, s);
+                        phi0, is_f32(h), (double*)s0_out, s);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
@@ -643,7 +658,7 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     if (!h || !phi || !vmin || !vmax) return LSM_ERR_INVALID;
     int nb = cfl_blocks(h->grid.ndim, h->nloc);
     if (nb > MAXB) nb = MAXB;
-    launch_extrema(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, (const double*)phi, h->d_partial,
+    launch_extrema(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, phi, is_f32(h), h->d_partial,
                    h->d_partial + MAXB, nb, h->d_result, h->stream);
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
@@ -662,7 +677,7 @@ static int measure(LsmHandle* h, int mode, void* phi, double* out) {
     double scale = 1.0;
     for (int d = 0; d < N; ++d) scale = d == 0 ? h->h[0] : scale * h->h[d];            // prod(δ)
     launch_measure(mode, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, h->dxmin, scale,
-                   (const double*)phi, h->d_partial, nb, h->d_result, h->stream);
+                   phi, is_f32(h), h->d_partial, nb, h->d_result, h->stream);
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     *out = h->h_result[0];
@@ -690,7 +705,7 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
     void* comp[3] = {work1, work2, work3};
     launch_signed_normals(N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, delta, interface_band * delta,
-                          min_norm * min_norm, (const double*)phi, (const double*)frozen, (double*)comp[0], (double*)comp[1],
+                          min_norm * min_norm, phi, is_f32(h), (const double*)frozen, (double*)comp[0], (double*)comp[1],
                           (double*)comp[2], h->stream);
     LSM_HIP(h, hipGetLastError());
     LsmTerm term;
@@ -706,7 +721,7 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
         LSM_TRY(lsm_stage(h, &term, 1, cur, nullptr, nxt, nullptr, LSM_BASE_PSI, tau, 0.0, 0.0, nullptr));
         void* t = cur; cur = nxt; nxt = t;
     }
-    if (cur != F) LSM_HIP(h, hipMemcpyAsync(F, cur, sizeof(double) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));
+    if (cur != F) LSM_HIP(h, hipMemcpyAsync(F, cur, esize(h) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));
     return LSM_OK;
 }
 
@@ -727,6 +742,7 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.nbm = a.ndim >= 2 ? (h->nloc[a.ndim - 1] + mc - 1) / mc : 1;
     a.work = work;
     a.list = nullptr; a.nlist = 0;
+    a.f32 = is_f32(h);
     return a;
 }
 
@@ -812,7 +828,7 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
             launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
     if (halo_count) LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
     launch_band_extrapolate(a, nullptr, (unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
-                            (const double*)vals, nullptr, h->d_miss, halo_count ? (BandEntry*)halo_list : nullptr,
+                            vals, nullptr, h->d_miss, halo_count ? (BandEntry*)halo_list : nullptr,
                             (unsigned*)halo_count, halo_list && halo_count ? (unsigned)halo_cap : 0u, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -856,19 +872,19 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     const bool fused = band_grow_fits(a, nlayers);
     if (fused) {
         // cut cells, seeds, dilations and the tile flags in one LDS-resident kernel; A is written on every visited tile
-        launch_band_grow(a, (const double*)vals, old_mask, nlayers, A, (unsigned char*)tiles, h->stream);
+        launch_band_grow(a, vals, old_mask, nlayers, A, (unsigned char*)tiles, h->stream);
     } else {
         LSM_HIP(h, hipMemsetAsync(A, 0, bytes, h->stream));
         LSM_HIP(h, hipMemsetAsync(B, 0, bytes, h->stream));
-        launch_band_cut(a, (const double*)vals, old_mask, A, h->stream);
+        launch_band_cut(a, vals, old_mask, A, h->stream);
         for (int l = 0; l < nlayers; ++l) {
             launch_band_dilate(a, A, B, h->stream);
             unsigned char* t = A; A = B; B = t;
         }
     }
     if (!from_dense)
-        launch_band_extrapolate(a, A, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds, (const double*)vals,
-                                (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
+        launch_band_extrapolate(a, A, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds, vals,
+                                vals, h->d_miss, nullptr, nullptr, 0, h->stream);
     launch_band_copy(a, A, (unsigned char*)mask, h->stream);   // the old band lies inside the visited tiles
     if (!fused) launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
     LSM_HIP(h, hipGetLastError());
@@ -908,7 +924,7 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
         a.work = h->d_work;
     }
     launch_band_extrapolate(a, (const unsigned char*)targets, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
-                            (const double*)vals, (double*)vals, h->d_miss, nullptr, nullptr, 0, h->stream);
+                            vals, vals, h->d_miss, nullptr, nullptr, 0, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
@@ -918,7 +934,7 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
 int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap, const void* halo_count) {
     if (!h || !vals || !mask || !halo_list || !halo_count) return LSM_ERR_INVALID;
     launch_band_apply(band_args(h, 8, nullptr), (const BandEntry*)halo_list, (const unsigned*)halo_count, (unsigned)halo_cap,
-                      (const unsigned char*)mask, (const double*)vals, (double*)vals, h->stream);
+                      (const unsigned char*)mask, vals, vals, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
 }

@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(256) ghost_fill_kernel(const GhostArgs a, int 
     I[2] = lo[2] + (int)(t / ((long long)ext[0] * ext[1]));
     const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
     I[d] = 0;
-    double* line = a.v + a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;   // node 0 of this line
+    const long long line0 = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;   // node 0 of this line
+    auto line = [&](long long off) { return ld_val(a.v, line0 + off, a.f32); };
     const int n = a.n[d];
     for (int side = 0; side < 2; ++side) {
         const int kind = a.kind[side];
@@ -42,13 +43,13 @@ __global__ void __launch_bounds__(256) ghost_fill_kernel(const GhostArgs a, int 
             double acc = 0.0;
             if (kind == LSM_BC_PERIODIC) {
                 const int j = side == 0 ? (n - 1) - k : k;          // period n-1 (src/boundaryconditions.jl:107-119)
-                acc += 1.0 * line[j * sd];
+                acc += 1.0 * line(j * sd);
             } else if (kind == LSM_BC_EXTRAPOLATION) {
-                for (int j = 0; j <= a.degree[side]; ++j) acc += a.w[side][k - 1][j] * line[(b + dir * j) * sd];
+                for (int j = 0; j <= a.degree[side]; ++j) acc += a.w[side][k - 1][j] * line((b + dir * j) * sd);
             } else {
-                acc += 1.0 * line[(b + dir * k) * sd];              // mirror about the boundary node
+                acc += 1.0 * line((b + dir * k) * sd);              // mirror about the boundary node
             }
-            line[(b - dir * k) * sd] = acc;
+            st_val(a.v, line0 + (b - dir * k) * sd, a.f32, acc);
         }
     }
 }
@@ -76,7 +77,7 @@ void launch_ghost_fill(int ndim, const GhostArgs& a, hipStream_t s) {
 template <int D>
 __device__ __forceinline__ double ghost_resolve(const GhostAllArgs& a, int I0, int I1, int I2) {
     if constexpr (D < 0) {
-        return a.v[a.origin + I0 + I1 * a.s1 + I2 * a.s2];
+        return ld_val(a.v, a.origin + I0 + I1 * a.s1 + I2 * a.s2, a.f32);
     } else {
         const int i = D == 0 ? I0 : (D == 1 ? I1 : I2);
         const int n = a.n[D];
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
         else { I1 = (int)((u / (2 * G)) % a.n[1]); I2 = a.mb + (int)(u / ((long long)2 * G * a.n[1])); }
     }
     const double val = ghost_resolve<NDIM - 1>(a, I0, I1, I2);
-    a.v[a.origin + I0 + I1 * a.s1 + I2 * a.s2] = val;
+    st_val(a.v, a.origin + I0 + I1 * a.s1 + I2 * a.s2, a.f32, val);
 }
 
 void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
@@ -440,12 +441,12 @@ void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, do
 // extrema of the interior (show, src/meshfield.jl:300-303)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) extrema_kernel(int n0, int n1, int n2, long long s1, long long s2, long long origin,
-                                                      const double* v, double* pmin, double* pmax) {
+                                                      const void* v, int f32, double* pmin, double* pmax) {
     const long long total = (long long)n0 * n1 * n2;
     double lo = __builtin_inf(), hi = -__builtin_inf();
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
-        const double x = v[origin + i0 + i1 * s1 + i2 * s2];
+        const double x = ld_val(v, origin + i0 + i1 * s1 + i2 * s2, f32);
         lo = x < lo ? x : lo;
         hi = x > hi ? x : hi;
     }
@@ -481,9 +482,9 @@ __global__ void __launch_bounds__(256) extrema_final_kernel(const double* pmin, 
         out2[1] = hi;
     }
 }
-void launch_extrema(int /*ndim*/, const int n[3], long long s1, long long s2, long long origin, const double* v,
+void launch_extrema(int /*ndim*/, const int n[3], long long s1, long long s2, long long origin, const void* v, int f32,
                     double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s) {
-    hipLaunchKernelGGL(extrema_kernel, dim3(nblocks), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, v, partial_min,
+    hipLaunchKernelGGL(extrema_kernel, dim3(nblocks), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, v, f32, partial_min,
                        partial_max);
     hipLaunchKernelGGL(extrema_final_kernel, dim3(1), dim3(256), 0, s, partial_min, partial_max, nblocks, out2);
 }
@@ -510,22 +511,23 @@ __device__ __forceinline__ double smooth_delta(double x, double alpha) {       /
 // mode 0: volume, 1: perimeter
 __global__ void __launch_bounds__(256) measure_kernel(int mode, int ndim, int n0, int n1, int n2, long long s1, long long s2,
                                                       long long origin, double h0, double h1, double h2, double dmin,
-                                                      const double* v, double* partial) {
+                                                      const void* vp, int f32, double* partial) {
+    auto v = [&](long long i) { return ld_val(vp, i, f32); };
     const long long total = (long long)n0 * n1 * n2;
     double acc = 0.0;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
         const long long q = origin + i0 + i1 * s1 + i2 * s2;
-        const double c = v[q];
+        const double c = v(q);
         if (mode == 0) {
             acc += smooth_heaviside(-c, dmin);
         } else {
             const double d = smooth_delta(c, dmin);
             if (d != 0.0) {   // ‖∇ϕ‖ from D⁰ (src/levelsetops.jl:212-215), only inside the delta's support
-                double g0 = (v[q + 1] - v[q - 1]) / (2 * h0);
+                double g0 = (v(q + 1) - v(q - 1)) / (2 * h0);
                 double nrm2 = g0 * g0;
-                if (ndim > 1) { double g1 = (v[q + s1] - v[q - s1]) / (2 * h1); nrm2 = nrm2 + g1 * g1; }
-                if (ndim > 2) { double g2 = (v[q + s2] - v[q - s2]) / (2 * h2); nrm2 = nrm2 + g2 * g2; }
+                if (ndim > 1) { double g1 = (v(q + s1) - v(q - s1)) / (2 * h1); nrm2 = nrm2 + g1 * g1; }
+                if (ndim > 2) { double g2 = (v(q + s2) - v(q - s2)) / (2 * h2); nrm2 = nrm2 + g2 * g2; }
                 acc += d * __builtin_sqrt(nrm2);
             }
         }
@@ -548,9 +550,9 @@ __global__ void __launch_bounds__(256) measure_final_kernel(const double* partia
     if (threadIdx.x == 0) out[0] = scale * ((ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
 }
 void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
-                    double dmin, double scale, const double* v, double* partial, int nblocks, double* out, hipStream_t s) {
+                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s) {
     hipLaunchKernelGGL(measure_kernel, dim3(nblocks), dim3(256), 0, s, mode, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2],
-                       dmin, v, partial);
+                       dmin, v, f32, partial);
     hipLaunchKernelGGL(measure_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, scale, out);
 }
 
@@ -563,18 +565,19 @@ void launch_measure(int mode, int ndim, const int n[3], long long s1, long long 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) signed_normals_kernel(int ndim, int n0, int n1, int n2, long long s1, long long s2,
                                                              long long origin, double h0, double h1, double h2, double delta,
-                                                             double band_width, double min_norm2, const double* phi,
+                                                             double band_width, double min_norm2, const void* phip, int f32,
                                                              const double* frozen, double* c0, double* c1, double* c2) {
+    auto phi = [&](long long i) { return ld_val(phip, i, f32); };
     const long long total = (long long)n0 * n1 * n2;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
         const long long q = origin + i0 + i1 * s1 + i2 * s2;
-        const double c = phi[q];
+        const double c = phi(q);
         double g[3] = {0, 0, 0};
-        g[0] = (phi[q + 1] - phi[q - 1]) / (2 * h0);
+        g[0] = (phi(q + 1) - phi(q - 1)) / (2 * h0);
         double nrm2 = g[0] * g[0];
-        if (ndim > 1) { g[1] = (phi[q + s1] - phi[q - s1]) / (2 * h1); nrm2 = nrm2 + g[1] * g[1]; }
-        if (ndim > 2) { g[2] = (phi[q + s2] - phi[q - s2]) / (2 * h2); nrm2 = nrm2 + g[2] * g[2]; }
+        if (ndim > 1) { g[1] = (phi(q + s1) - phi(q - s1)) / (2 * h1); nrm2 = nrm2 + g[1] * g[1]; }
+        if (ndim > 2) { g[2] = (phi(q + s2) - phi(q - s2)) / (2 * h2); nrm2 = nrm2 + g[2] * g[2]; }
         const bool fz = frozen ? frozen[q] != 0.0 : __builtin_fabs(c) <= band_width;
         double a[3] = {0, 0, 0};
         if (!fz && !(nrm2 <= min_norm2)) {
@@ -590,34 +593,34 @@ __global__ void __launch_bounds__(256) signed_normals_kernel(int ndim, int n0, i
     }
 }
 void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double delta,
-                           double band_width, double min_norm2, const double* phi, const double* frozen, double* c0, double* c1,
+                           double band_width, double min_norm2, const void* phi, int f32, const double* frozen, double* c0, double* c1,
                            double* c2, hipStream_t s) {
     const long long total = (long long)n[0] * n[1] * n[2];
     long long b = (total + 255) / 256;
     const int nb = (int)(b > 4096 ? 4096 : b);
     hipLaunchKernelGGL(signed_normals_kernel, dim3(nb), dim3(256), 0, s, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2],
-                       delta, band_width, min_norm2, phi, frozen, c0, c1, c2);
+                       delta, band_width, min_norm2, phi, f32, frozen, c0, c1, c2);
 }
 
 // ---------------------------------------------------------------------------------------------
 // EikonalReinitializationTerm(ϕ₀): S₀ = v / sqrt(v² + Δx²) on the interior (src/levelsetterms.jl:217-221)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eikonal_sign_kernel(int n0, int n1, int n2, long long s1, long long s2,
-                                                           long long origin, double dx, const double* phi0, double* s0) {
+                                                           long long origin, double dx, const void* phi0, int f32, double* s0) {
     const long long total = (long long)n0 * n1 * n2;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
         const long long q = origin + i0 + i1 * s1 + i2 * s2;
-        const double v = phi0[q];
+        const double v = ld_val(phi0, q, f32);
         s0[q] = v / __builtin_sqrt(v * v + dx * dx);
     }
 }
 void launch_eikonal_sign(int /*ndim*/, const int n[3], long long s1, long long s2, long long origin, double dxmin,
-                         const double* phi0, double* s0, hipStream_t s) {
+                         const void* phi0, int f32, double* s0, hipStream_t s) {
     const long long total = (long long)n[0] * n[1] * n[2];
     long long b = (total + 255) / 256;
     const int nb = (int)(b > 4096 ? 4096 : b);
-    hipLaunchKernelGGL(eikonal_sign_kernel, dim3(nb), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, dxmin, phi0, s0);
+    hipLaunchKernelGGL(eikonal_sign_kernel, dim3(nb), dim3(256), 0, s, n[0], n[1], n[2], s1, s2, origin, dxmin, phi0, f32, s0);
 }
 
 }  // namespace lsm

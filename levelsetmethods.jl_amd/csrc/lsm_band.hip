@@ -95,7 +95,7 @@ __device__ __forceinline__ void stage_box(const BandArgs& a, const Box& b, int x
 // update_band! (src/meshfield.jl:555-588) for one tile, entirely in LDS: node flags (in the old band,
 // value <= 0, value >= 0) on the tile + apron nl+1 -> cut cells -> seeds (corners of cut cells) -> nl
 // von-Neumann dilations -> new band on the tile, and the tile's activity flag.
-__global__ void __launch_bounds__(256) band_grow_kernel(BandArgs a, const double* v, const unsigned char* old_mask, int nl,
+__global__ void __launch_bounds__(256) band_grow_kernel(BandArgs a, const void* v, const unsigned char* old_mask, int nl,
                                                         unsigned char* new_mask, unsigned char* tiles) {
     if (a.work && !a.work[LSM_TILE_ID(a)]) {
         if (threadIdx.x == 0) tiles[LSM_TILE_ID(a)] = 0;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) band_grow_kernel(BandArgs a, const double
     stage_box<8>(a, b, x0_, y0_, m0_, nx_, ny_, nm_, sy_, sm_, f,
                  [&](long long q) -> unsigned char { return old_mask ? old_mask[q] : (unsigned char)1; },
                  [&](long long q, unsigned char inband) -> unsigned char {
-                     const double x = v[inband ? q : a.origin];      // unconditional load from a valid address
+                     const double x = ld_val(v, inband ? q : a.origin, a.f32);      // unconditional load from a valid address
                      return inband ? (unsigned char)(1 | (x <= 0.0 ? 2 : 0) | (x >= 0.0 ? 4 : 0)) : (unsigned char)0;
                  });
     __syncthreads();
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) band_grow_kernel(BandArgs a, const double
     if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) band_cut_kernel(BandArgs a, const double* v, const unsigned char* old_mask,
+__global__ void __launch_bounds__(256) band_cut_kernel(BandArgs a, const void* v, const unsigned char* old_mask,
                                                        unsigned char* seed) {
     LSM_TILE_PROLOGUE(a)
     const int nc = 1 << a.ndim;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) band_cut_kernel(BandArgs a, const double*
             // corner offsets in the field's own dimensions: bit 0 -> dim 1, bit 1 -> dim 2, bit 2 -> dim 3
             const long long qc = q + (c & 1) + ((c >> 1) & 1) * a.s1 + ((c >> 2) & 1) * a.s2;
             if (old_mask && !old_mask[qc]) { ok = false; break; }
-            const double xv = v[qc];
+            const double xv = ld_val(v, qc, a.f32);
             vmin = xv < vmin ? xv : vmin;
             vmax = xv > vmax ? xv : vmax;
         }
@@ -228,7 +228,7 @@ __device__ __forceinline__ bool ring_scan_global(const BandArgs& a, const unsign
 // what follows the search for node I (padded index q) with nearest band node P: record the pair and / or
 // write the affine extrapolant (_extrapolate_to_ghost, src/meshfield.jl:494-511)
 __device__ __forceinline__ void finish_node(const BandArgs& a, long long q, const int I[3], const int P[3], bool found,
-                                            const unsigned char* src_mask, const double* src, double* dst, int* miss, BandEntry* list,
+                                            const unsigned char* src_mask, const void* src, void* dst, int* miss, BandEntry* list,
                                             unsigned* list_count, unsigned list_cap) {
     if (!found) { atomicOr(miss, 1); return; }   // the reference throws: farther than the search radius
     const long long qp = a.origin + P[0] + P[1] * a.s1 + P[2] * a.s2;
@@ -247,20 +247,20 @@ __device__ __forceinline__ void finish_node(const BandArgs& a, long long q, cons
         }
     }
     if (!dst) return;
-    const double phiP = src[qp];
+    const double phiP = ld_val(src, qp, a.f32);
     double val = phiP;
     for (int d = 0; d < a.ndim; ++d) {
         const int delta = I[d] - P[d];
         if (delta == 0) continue;
         const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
         double slope = 0.0;                                   // _axis_slope: + neighbour first, then -
-        if (P[d] + 1 < a.n[d] && src_mask[qp + sd]) slope = src[qp + sd] - phiP;
-        else if (P[d] - 1 >= 0 && src_mask[qp - sd]) slope = phiP - src[qp - sd];
+        if (P[d] + 1 < a.n[d] && src_mask[qp + sd]) slope = ld_val(src, qp + sd, a.f32) - phiP;
+        else if (P[d] - 1 >= 0 && src_mask[qp - sd]) slope = phiP - ld_val(src, qp - sd, a.f32);
         val += (double)delta * slope;
     }
     // never let extrapolation invent a sign change far from the band
     const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
-    dst[q] = (phiP == 0.0 || sv == sp) ? val : phiP;
+    st_val(dst, q, a.f32, (phiP == 0.0 || sv == sp) ? val : phiP);
 }
 
 // _extrapolate_to_ghost (src/meshfield.jl:494-511).
@@ -277,7 +277,7 @@ __device__ __forceinline__ void finish_node(const BandArgs& a, long long q, cons
 constexpr int RL = 3;
 __global__ void __launch_bounds__(256) band_extrapolate_kernel(BandArgs a, const unsigned char* target, unsigned char* halo,
                                                                const unsigned char* src_mask, const signed char* ring, int nring,
-                                                               int nring_lds, const double* src, double* dst, int* miss,
+                                                               int nring_lds, const void* src, void* dst, int* miss,
                                                                BandEntry* list, unsigned* list_count, unsigned list_cap) {
     LSM_TILE_PROLOGUE(a)
     if (target) {   // nothing to do in most tiles: skip them before staging anything
@@ -406,7 +406,7 @@ __device__ __forceinline__ void stage_rows(const BandArgs& a, int ap, int bx, in
 }
 
 // update_band! for one 32×8×mc tile (see band_grow_kernel)
-__global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const double* v, const unsigned char* old_mask, int nl,
+__global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void* v, const unsigned char* old_mask, int nl,
                                                          unsigned char* new_mask, unsigned char* tiles) {
     const unsigned tile = LSM_TILE_ID(a);
     if (a.work && !a.work[tile]) {
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const doubl
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             on[k] = (B[rows[k]] >> lane) & 1ull;
-            xv[k] = v[on[k] ? q[k] : a.origin];
+            xv[k] = ld_val(v, on[k] ? q[k] : a.origin, a.f32);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) f[k] = on[k] ? ((xv[k] <= 0.0 ? 1u : 0u) | (xv[k] >= 0.0 ? 2u : 0u)) : 0u;
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const doubl
 template <int J>
 __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const unsigned char* target, unsigned char* halo,
                                                            const unsigned char* src_mask, const signed char* ring, int nring,
-                                                           int nring_lds, const double* src, double* dst, int* miss,
+                                                           int nring_lds, const void* src, void* dst, int* miss,
                                                            BandEntry* list, unsigned* list_count, unsigned list_cap) {
     const unsigned tile = LSM_TILE_ID(a);
     if (a.work && !a.work[tile]) return;
@@ -648,25 +648,25 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
 
 // _extrapolate_to_ghost from a precomputed (node, nearest band node) list: one thread per entry
 __global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
-                                                         const unsigned char* src_mask, const double* src, double* dst) {
+                                                         const unsigned char* src_mask, const void* src, void* dst) {
     unsigned n = *list_count;
     n = n < list_cap ? n : list_cap;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const BandEntry e = list[i];
         const long long qp = e.q + e.rel;
-        const double phiP = src[qp];
+        const double phiP = ld_val(src, qp, a.f32);
         double val = phiP;
         for (int d = 0; d < a.ndim; ++d) {
             const int delta = e.d[d];
             if (delta == 0) continue;
             const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
             double slope = 0.0;                                   // mask ghosts are 0: no bounds test needed
-            if (src_mask[qp + sd]) slope = src[qp + sd] - phiP;
-            else if (src_mask[qp - sd]) slope = phiP - src[qp - sd];
+            if (src_mask[qp + sd]) slope = ld_val(src, qp + sd, a.f32) - phiP;
+            else if (src_mask[qp - sd]) slope = phiP - ld_val(src, qp - sd, a.f32);
             val += (double)delta * slope;
         }
         const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
-        dst[e.q] = (phiP == 0.0 || sv == sp) ? val : phiP;
+        st_val(dst, e.q, a.f32, (phiP == 0.0 || sv == sp) ? val : phiP);
     }
 }
 
@@ -818,7 +818,7 @@ static bool no_tiles(const BandArgs& a) { return a.list && a.nlist == 0; }
 static long long box_bytes(const BandArgs& a, long long ap) {
     return (a.tx + 2 * ap) * (a.ndim == 3 ? a.ty + 2 * ap : 1) * (a.ndim >= 2 ? a.tm + 2 * ap : 1);
 }
-void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s) {
+void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s) {
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_cut_kernel, tile_grid(a), dim3(256), 0, s, a, v, old_mask, seed);
 }
@@ -826,7 +826,7 @@ void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned cha
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_dilate_kernel, tile_grid(a), dim3(256), 0, s, a, in, out);
 }
-void launch_band_grow(const BandArgs& a, const double* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
+void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
                       unsigned char* tiles, hipStream_t s) {
     if (fast3(a, nl + 1, 5)) {
         const size_t lds = (size_t)5 * 8 * (a.ty + 2 * (nl + 1)) * (a.tm + 2 * (nl + 1));
@@ -843,7 +843,7 @@ void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char*
     hipLaunchKernelGGL(band_copy_kernel, tile_grid(a), dim3(256), 0, s, a, in, out);
 }
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
-                             const signed char* ring, int nring, int nring_lds, const double* src, double* dst, int* miss,
+                             const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s) {
     if (fast3(a, RL, 1)) {
         const size_t lds = (size_t)8 * ((a.ty + 2 * RL) * (a.tm + 2 * RL) + a.ty * a.tm);
@@ -858,7 +858,7 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
                        src_mask, ring, nring, nring_lds, src, dst, miss, list, list_count, list_cap);
 }
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
-                       const unsigned char* src_mask, const double* src, double* dst, hipStream_t s) {
+                       const unsigned char* src_mask, const void* src, void* dst, hipStream_t s) {
     unsigned blocks = (list_cap + 255) / 256;
     blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(band_apply_kernel, dim3(blocks), dim3(256), 0, s, a, list, list_count, list_cap, src_mask, src, dst);

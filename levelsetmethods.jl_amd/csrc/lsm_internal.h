@@ -6,6 +6,16 @@
 
 namespace lsm {
 
+// Field values are fp64, or fp32 for LSM_DTYPE_F32 handles (widened exactly on load, rounded to nearest on
+// store; every computation is fp64).  The small kernels take the storage type as a run-time flag.
+__device__ __forceinline__ double ld_val(const void* p, long long i, int f32) {
+    return f32 ? (double)static_cast<const float*>(p)[i] : static_cast<const double*>(p)[i];
+}
+__device__ __forceinline__ void st_val(void* p, long long i, int f32, double v) {
+    if (f32) static_cast<float*>(p)[i] = (float)v;
+    else static_cast<double*>(p)[i] = v;
+}
+
 // term-kind slots inside a fused stage kernel
 enum { SLOT_ADV = 0, SLOT_NM = 1, SLOT_CURV = 2, SLOT_EIK = 3, NSLOTS = 4 };
 
@@ -54,6 +64,7 @@ struct StageArgs {
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
     unsigned ntile_list;
+    int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
 };
 
 struct GhostArgs {
@@ -63,7 +74,8 @@ struct GhostArgs {
     int kind[2];         // per side
     int degree[2];
     double w[2][LSM_GHOST][8];  // Lagrange weights per side, ghost distance k-1, node j
-    double* v;
+    void* v;
+    int f32;
 };
 
 // all dimensions at once (fused ghost fill)
@@ -73,7 +85,8 @@ struct GhostAllArgs {
     int kind[3][2];
     int degree[3][2];
     const double* w;   // device copy of the Lagrange weights [3][2][LSM_GHOST][8] (no dynamic kernarg indexing)
-    double* v;
+    void* v;
+    int f32;
     int mb, me;        // planes [mb, me) of the last dimension whose lower-dimension ghosts are filled
     int fill_last;     // also fill the (physical) ghosts of the last dimension
 };
@@ -108,12 +121,13 @@ struct BandArgs {
     const unsigned char* work;   // per-tile flags: tiles to visit (NULL = all)
     const int* list;             // compact list of the tiles to visit (NULL = every tile gets a block)
     unsigned nlist;
+    int f32;                     // the value arrays hold float
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
-void launch_band_cut(const BandArgs& a, const double* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
+void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
-void launch_band_grow(const BandArgs& a, const double* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
+void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
                       unsigned char* tiles, hipStream_t s);
 bool band_grow_fits(const BandArgs& a, int nl);
 struct BandEntry {          // a halo node and its nearest band node (16 bytes)
@@ -122,10 +136,10 @@ struct BandEntry {          // a halo node and its nearest band node (16 bytes)
     signed char d[4];       // I - P per dimension
 };
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
-                             const signed char* ring, int nring, int nring_lds, const double* src, double* dst, int* miss,
+                             const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
-                       const unsigned char* src_mask, const double* src, double* dst, hipStream_t s);
+                       const unsigned char* src_mask, const void* src, void* dst, hipStream_t s);
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s);
@@ -157,14 +171,14 @@ void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double*
 void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
                       int pass, hipStream_t s);
-void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const double* v,
+void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const void* v, int f32,
                     double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s);
 void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
-                    double dmin, double scale, const double* v, double* partial, int nblocks, double* out, hipStream_t s);
+                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s);
 void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double delta,
-                           double band_width, double min_norm2, const double* phi, const double* frozen, double* c0, double* c1,
+                           double band_width, double min_norm2, const void* phi, int f32, const double* frozen, double* c0, double* c1,
                            double* c2, hipStream_t s);
 void launch_eikonal_sign(int ndim, const int n[3], long long s1, long long s2, long long origin, double dxmin,
-                         const double* phi0, double* s0, hipStream_t s);
+                         const void* phi0, int f32, double* s0, hipStream_t s);
 
 }  // namespace lsm

@@ -38,11 +38,15 @@ constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
 
 // load/store through a wave-uniform base pointer plus a 32-bit unsigned BYTE offset: this is the
 // shape (sgpr base + zext(vgpr32)) that selects global_load/store's saddr addressing mode.
-LSM_DEV double ldg(const double* base, unsigned boff) {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+// ST is the storage type of the field (double, or float for LSM_DTYPE_F32: values widen exactly on load,
+// all arithmetic is fp64, the result is rounded to nearest on store).
+template <class ST>
+LSM_DEV double ldg(const ST* base, unsigned boff) {
+    return (double)*reinterpret_cast<const ST*>(reinterpret_cast<const char*>(base) + boff);
 }
-LSM_DEV void stg(double* base, unsigned boff, double v) {
-    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+template <class ST>
+LSM_DEV void stg(ST* base, unsigned boff, double v) {
+    *reinterpret_cast<ST*>(reinterpret_cast<char*>(base) + boff) = (ST)v;
 }
 
 // _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h),
@@ -111,7 +115,8 @@ LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre
 // where a node reads/writes its pointwise operands: uniform plane offset + per-thread in-plane offset
 struct NodeIO {
     long long plane_off;   // offset of the plane's lowest (ghost) corner (wave-uniform)
-    unsigned ocol;         // in-plane BYTE offset of this thread from that corner
+    unsigned ocol;         // in-plane BYTE offset of this thread from that corner, in the field's storage type
+    unsigned ocold;        // the same for the fp64 side arrays (coefficient fields, frozen sign) and, /8, the band mask
     int gim;               // global march index
 };
 
@@ -198,7 +203,7 @@ LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
     return weno5_upwind(q, hs, ihs, 1.0e-99 * a.h2[D]);
 }
 
-template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class NV>
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class ST, class NV>
 LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, const double pre_adv[3], const double pre_nm[3],
                          const double pre_curv[3], bool active) {
     const double c = nv.c;
@@ -214,7 +219,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
     if constexpr (ADV != 0) {
         double u[3];
-        coeff_eval<NDIM, NDIM, ADV_SCALED>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocol, u);   // FAST: u_d/h_d
+        coeff_eval<NDIM, NDIM, ADV_SCALED>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocold, u);   // FAST: u_d/h_d
         auto one = [&](auto Dc) {
             constexpr int D = decltype(Dc)::value;
             const double v = u[D];
@@ -254,7 +259,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     // ---- NormalMotionTerm — src/levelsetterms.jl:156-170
     if constexpr (NM) {
         double vv[3];
-        coeff_eval<NDIM, 1>(a.nm, a, pre_nm, io.gim, io.plane_off, io.ocol, vv);
+        coeff_eval<NDIM, 1>(a.nm, a, pre_nm, io.gim, io.plane_off, io.ocold, vv);
         const double v = vv[0];
 #if LSM_STRICT
         double gp = 0.0, gm = 0.0;
@@ -277,7 +282,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     // ---- CurvatureTerm: b κ |∇ϕ| — src/levelsetterms.jl:111-121, src/levelsetops.jl:197-244
     if constexpr (CURV) {
         double bb[3];
-        coeff_eval<NDIM, 1>(a.curv, a, pre_curv, io.gim, io.plane_off, io.ocol, bb);
+        coeff_eval<NDIM, 1>(a.curv, a, pre_curv, io.gim, io.plane_off, io.ocold, bb);
         double gr[3] = {0, 0, 0}, Hd[3] = {0, 0, 0};
         double H01 = 0, H02 = 0, H12 = 0;
         auto first = [&](auto Dc) {
@@ -339,7 +344,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- EikonalReinitializationTerm: S (|∇ϕ| - 1) — src/levelsetterms.jl:234-265
     if constexpr (EIK != 0) {
-        const double s = EIK == 1 ? ldg(a.s0 + io.plane_off, io.ocol) : c;
+        const double s = EIK == 1 ? ldg(a.s0 + io.plane_off, io.ocold) : c;
 #if LSM_STRICT
         const bool vpos = s > 0;
         double mA = 0.0, mB = 0.0;
@@ -379,19 +384,19 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     // ---- stage combination — src/timestepping.jl:129-136,147-163,172-200
     if (!active) return;
     // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
-    if (a.mask && !*(reinterpret_cast<const unsigned char*>(a.mask) + io.plane_off + (io.ocol >> 3))) return;
+    if (a.mask && !*(reinterpret_cast<const unsigned char*>(a.mask) + io.plane_off + (io.ocold >> 3))) return;
     double base;
     if (a.base_mode == LSM_BASE_PSI) base = c;
-    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * ldg(a.phin + io.plane_off, io.ocol) + 0.25 * c;
+    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 0.25 * c;
     else if (a.base_mode == LSM_BASE_RK3_S3)
 #if LSM_STRICT
-        base = (ldg(a.phin + io.plane_off, io.ocol) + 2 * c) / 3;
+        base = (ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 2 * c) / 3;
 #else
-        base = (ldg(a.phin + io.plane_off, io.ocol) + 2 * c) * (1.0 / 3);
+        base = (ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 2 * c) * (1.0 / 3);
 #endif
-    else base = ldg(a.phin + io.plane_off, io.ocol);
+    else base = ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol);
     double b2 = 0.0;
-    if (a.out2) b2 = a.out2_accum ? ldg(a.out2 + io.plane_off, io.ocol) : c;
+    if (a.out2) b2 = a.out2_accum ? ldg(reinterpret_cast<const ST*>(a.out2) + io.plane_off, io.ocol) : c;
     for (int k = 0; k < a.nterms; ++k) {
         const int o = a.order[k];
         double L = Ladv;
@@ -401,8 +406,8 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         base -= a.cdt * L;
         b2 -= a.cdt2 * L;
     }
-    stg(a.out + io.plane_off, io.ocol, base);
-    if (a.out2) stg(a.out2 + io.plane_off, io.ocol, b2);
+    stg(reinterpret_cast<ST*>(a.out) + io.plane_off, io.ocol, base);
+    if (a.out2) stg(reinterpret_cast<ST*>(a.out2) + io.plane_off, io.ocol, b2);
 }
 
 #ifndef LSM_WAVES_PER_EU
@@ -413,7 +418,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 #else
 #define LSM_BARRIER() __syncthreads()
 #endif
-template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC>
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST>
 __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const StageArgs a) {
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
     constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
@@ -462,13 +467,14 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     // unsigned in-plane offset from the plane's lowest (ghost) corner: with a wave-uniform base this
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
-    const unsigned ocol = 8u * ((unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
+    const unsigned ocole = (unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy;         // elements
+    const unsigned ocol = (unsigned)sizeof(ST) * ocole, ocold = 8u * ocole;                                // bytes
     const int mc = a.mc > 0 ? a.mc : MC;
     const int m0 = MARCH ? a.mb + (int)tbm * mc : 0;
     const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
-    auto plane = [&](int p) { return a.psi + (corner + (long long)clampM(p) * sm); };
+    auto plane = [&](int p) { return reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm); };
 
     // halo elements owned by this thread: LDS offset within a plane, global offset within a plane
     int hl[HPT > 0 ? HPT : 1];
@@ -497,7 +503,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             Y = Y > ny + G - 1 ? ny + G - 1 : Y;
         }
         hl[h] = ly * W + lx;
-        hg[h] = 8u * ((unsigned)(X + G) + (unsigned)(Y + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
+        hg[h] = (unsigned)sizeof(ST) * ((unsigned)(X + G) + (unsigned)(Y + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
     }
     const int lpos = (ty + (HAS_Y ? G : 0)) * W + tx + G;
 
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     }
 
     if constexpr (!MARCH) {
-        const double* P = plane(0);
+        const ST* P = plane(0);
         const double c = ldg(P, ocol);
         tile[lpos] = c;
 #pragma unroll
@@ -519,8 +525,8 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             if (hv[h]) tile[hl[h]] = ldg(P, hg[h]);
         __syncthreads();
         NodeView<NDIM, G, W> nv{tile + lpos, nullptr, nullptr, nullptr, c};
-        const NodeIO io{corner, ocol, 0};
-        node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
+        const NodeIO io{corner, ocol, ocold, 0};
+        node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
     } else {
         double zl[2 * G + 1];
 #pragma unroll
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
             const int slot = pl + LEAD;
             tile[slot * HW + lpos] = zl[G + pl];
-            const double* P = plane(m0 + pl);
+            const ST* P = plane(m0 + pl);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) tile[slot * HW + hl[h]] = ldg(P, hg[h]);
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             // issue the next plane's global loads early; they land in LDS after this plane's arithmetic
             const double nxt = ldg(plane(m + 1 + G), ocol);
             double hn[HPT > 0 ? HPT : 1];
-            const double* Pn = plane(m + 1 + LEAD);
+            const ST* Pn = plane(m + 1 + LEAD);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) hn[h] = ldg(Pn, hg[h]);
@@ -551,8 +557,8 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
             const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
             NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
-            const NodeIO io{corner + (long long)m * sm, ocol, m + a.goff[NDIM - 1]};
-            node_update<NDIM, ADV, NM, CURV, EIK, G, W>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
+            const NodeIO io{corner + (long long)m * sm, ocol, ocold, m + a.goff[NDIM - 1]};
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
             // shift the register line, write the next plane to its ring slot
 #pragma unroll
             for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
@@ -603,7 +609,8 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
-    hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC>), grid, block, 0, s, b);
+    if (b.f32) hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, float>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, double>), grid, block, 0, s, b);
 }
 
 // the instantiated fused combinations (keep in sync with combo_available in lsm_api.hip)

@@ -11,7 +11,7 @@ from oracle import oracle as orc
 
 
 class Case:
-    def __init__(self, shape, bcspec, lc=None, hc=None, mode="strict"):
+    def __init__(self, shape, bcspec, lc=None, hc=None, mode="strict", dtype=np.float64):
         import torch
         self.torch = torch
         nd = len(shape)
@@ -23,7 +23,8 @@ class Case:
         self.olay = orc.layout(self.grid)
         gc = L.LsmGrid.from_buffer_copy(bytes(self.grid.c))
         bcc = L.BcArray.from_buffer_copy(bytes(self.bc))
-        self.be = HipBackend(gc, bcc, mode=mode)
+        self.dtype = np.dtype(dtype)     # storage of the level-set fields; side arrays (coefficients, S0) stay float64
+        self.be = HipBackend(gc, bcc, mode=mode, dtype=dtype)
         self.lay = self.be.lay
         self.keep = []
 
@@ -35,13 +36,15 @@ class Case:
         off = int(lay.origin) - sum(int(lay.g[d]) * int(lay.stride[d]) for d in range(nd))
         return np.lib.stride_tricks.as_strided(flat[off:], shape=shape, strides=strides)
 
-    def to_dev(self, padded):
+    def to_dev(self, padded, side=False):
         flat = np.zeros(int(self.lay.total), dtype=np.float64)
         self._view(flat)[...] = padded
+        if not side and self.dtype == np.float32:
+            flat = flat.astype(np.float32)
         return self.torch.from_numpy(flat).to(self.be.device)
 
     def to_host(self, t):
-        flat = t.cpu().numpy()
+        flat = t.cpu().numpy().astype(np.float64)
         return np.asfortranarray(self._view(flat).copy())
 
     def pad(self, dense, fill=True):
@@ -89,7 +92,7 @@ class Case:
             oc = orc.field(*padded)
             hc.kind = L.COEFF_FIELD
             for i, p in enumerate(padded):
-                t = self.to_dev(p)
+                t = self.to_dev(p, side=True)
                 self.keep.append(t)
                 hc.field[i] = t.data_ptr()
         self.keep.append(oc)
@@ -118,7 +121,7 @@ class Case:
                     s0 = orc.eikonal_sign(self.grid, np.asfortranarray(s[1]))
                     p = self.pad(s0, fill=False)
                     ot.append(orc.eikonal(p))
-                    t = self.to_dev(np.nan_to_num(p, nan=0.0))
+                    t = self.to_dev(np.nan_to_num(p, nan=0.0), side=True)
                     self.keep.append(t)
                     arr[i].s0 = t.data_ptr()
         self.keep.append(ot)

@@ -78,7 +78,7 @@ def test_create_validates_arguments(lsm):
     bad[0][0].kind = L.BC_PERIODIC                            # periodic on one face only
     assert L.lib().lsm_create(C.byref(g), bad, None, 0, 0, 0, C.byref(h)) == L.ERR_INVALID
     assert b"periodic" in L.lib().lsm_last_error(None)
-    assert L.lib().lsm_create(C.byref(g), _bc_c(_normalize_bc(lsm.NeumannBC(), 2), 2), None, 1, 0, 0, C.byref(h)) == L.ERR_INVALID  # f32
+    assert L.lib().lsm_create(C.byref(g), _bc_c(_normalize_bc(lsm.NeumannBC(), 2), 2), None, 7, 0, 0, C.byref(h)) == L.ERR_INVALID  # neither LSM_DTYPE_F64 nor LSM_DTYPE_F32
 
 
 def test_normalize_bc(lsm):
