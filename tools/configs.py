@@ -56,6 +56,57 @@ def config3(n=512, steps=10):
             "Mcells_s": n ** 3 / ms / 1e3, "GBs_algorithmic": n ** 3 * 64 / 3 / kms / 1e6}
 
 
+def config5(n=768, steps=10, nlayers=3):
+    """BASELINE config 5 on ONE device: float32 storage, sphere, rigid rotation (WENO5) + curvature, RK3, narrow band."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    f = lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5
+    terms = lambda: (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.01))
+    res = {"config": f"3D {n}^3 float32 narrow band (nlayers {nlayers}), rotation WENO5 + curvature, RK3"}
+    for dt in (np.float32, np.float64):
+        vals = lsm.LazyMeshField(f, grid).local_values(None).astype(dt)
+        eq = lsm.LevelSetEquation(terms=terms(), ic=lsm.NarrowBandMeshField(lsm.MeshField(vals, grid, dtype=dt), nlayers=nlayers),
+                                  bc=lsm.NeumannBC(), integrator=lsm.RK3())
+        del vals
+        tc = 0.0
+
+        def one(tc):
+            eq._update_terms(eq.state, tc)
+            step = eq.integrator.cfl * eq.compute_cfl(tc)
+            eq._advance(tc, step)
+            eq.update_band()
+            return tc + step
+        for _ in range(2):
+            tc = one(tc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tc = one(tc)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        c = eq.state.active_count()
+        res[np.dtype(dt).name] = {"ms_per_step": round(ms, 3), "active_nodes": c, "active_fraction": round(c / n ** 3, 4),
+                                  "Mcells_s_grid": round(n ** 3 / ms / 1e3, 1), "Mcells_s_active": round(c / ms / 1e3, 1)}
+        del eq
+        torch.cuda.empty_cache()
+    return res
+
+
+def upwind(n=512, steps=10):
+    """An HBM-bound member of the family: first-order upwind advection, ForwardEuler, both storage types."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    res = {"config": f"3D {n}^3 upwind advection, ForwardEuler"}
+    for dt in (np.float64, np.float32):
+        ic = lsm.LazyMeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, grid, dtype=dt)
+        eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0, 0.5, -0.25), lsm.Upwind()),), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.ForwardEuler())
+        ms, kms, nl = timed(eq, steps)
+        es = np.dtype(dt).itemsize
+        res[np.dtype(dt).name] = {"ms_per_step": round(ms, 3), "stage_ms": round(kms, 4), "Mcells_s": round(n ** 3 / ms / 1e3, 1),
+                                  "GBs_algorithmic_stage": round(n ** 3 * 2 * es / kms / 1e6, 1)}
+        del eq
+        torch.cuda.empty_cache()
+    return res
+
+
 def calib(n=512):
     """Known-traffic kernels for the FETCH_SIZE/WRITE_SIZE calibration (run under rocprofv3 --pmc):
     extrema reads n^3*8 B with 8-byte-per-lane loads; eikonal_sign reads and writes n^3*8 B."""
@@ -78,6 +129,10 @@ if __name__ == "__main__":
         out.append(config2())
     if mode in ("all", "3"):
         out.append(config3())
+    if mode in ("all", "5"):
+        out.append(config5())
+    if mode in ("all", "upwind"):
+        out.append(upwind())
     if mode == "calib":
         out.append(calib())
     print(json.dumps(out, indent=1))
