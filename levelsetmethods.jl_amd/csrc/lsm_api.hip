@@ -64,6 +64,7 @@ struct LsmHandle {
     bool lists_host_valid;
     unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
     bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
+    bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
     double* d_result;    // 2 doubles
@@ -158,6 +159,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
     h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
     h->no_lists = getenv("LSM_BAND_NO_LISTS") != nullptr;
+    h->band_bytes = getenv("LSM_BAND_BYTES") != nullptr;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
     if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
@@ -743,6 +745,7 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.work = work;
     a.list = nullptr; a.nlist = 0;
     a.f32 = is_f32(h);
+    a.force_bytes = h->band_bytes ? 1 : 0;
     return a;
 }
 

@@ -811,8 +811,8 @@ __global__ void __launch_bounds__(256) band_count_kernel(BandArgs a, const unsig
 static dim3 tile_grid(const BandArgs& a) { return dim3(a.list ? a.nlist : a.nbx * a.nby * a.nbm); }
 // the row-word kernels need 32×8 tiles whose x-lines (with apron) fit a 64-bit word, and `words` words per row in LDS
 static bool fast3(const BandArgs& a, int ap, int words) {
-    return a.ndim == 3 && a.tx == 32 && a.ty == 8 && a.tx + 2 * ap <= 64 &&
-           (long long)words * 8 * (a.ty + 2 * ap) * (a.tm + 2 * ap) + 8 * a.ty * a.tm <= 65536 && !getenv("LSM_BAND_BYTES");
+    return !a.force_bytes && a.ndim == 3 && a.tx == 32 && a.ty == 8 && a.tx + 2 * ap <= 64 &&
+           (long long)words * 8 * (a.ty + 2 * ap) * (a.tm + 2 * ap) + 8 * a.ty * a.tm <= 65536;
 }
 static bool no_tiles(const BandArgs& a) { return a.list && a.nlist == 0; }
 static long long box_bytes(const BandArgs& a, long long ap) {

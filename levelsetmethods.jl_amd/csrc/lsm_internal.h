@@ -122,6 +122,7 @@ struct BandArgs {
     const int* list;             // compact list of the tiles to visit (NULL = every tile gets a block)
     unsigned nlist;
     int f32;                     // the value arrays hold float
+    int force_bytes;             // A/B switch (LSM_BAND_BYTES at lsm_create): byte-mask kernels in 3-D too
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);

@@ -281,3 +281,23 @@ def test_band_stage_reads_reference_values_at_the_grid_boundary(shape, bcspec):
         else:
             assert np.array_equal(g[band], w[band])
         assert np.all(g[~band] == 0.0)                 # only band nodes are stored
+
+
+@pytest.mark.parametrize("env", ["LSM_BAND_BYTES", "LSM_BAND_NO_LISTS"])
+def test_fallback_band_paths_give_the_same_band_and_values(lsm, monkeypatch, env):
+    """The A/B switches select the generic paths (byte-mask kernels in 3-D; launches over every tile instead of the
+    compact lists).  Both must step a 3-D band to bitwise the same state as the default path."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (40, 36, 44))
+    phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.1) ** 2 + x[1] ** 2 + (x[2] + 0.05) ** 2) - 0.55, grid)
+    mk = lambda: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02)),
+                                      ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2), integrator=lsm.RK3())
+    ref = mk()
+    lsm.integrate_(ref, 0.03)
+    monkeypatch.setenv(env, "1")
+    alt = mk()                      # the switches are read when the handle is created
+    monkeypatch.delenv(env)
+    lsm.integrate_(alt, 0.03)
+    a, b = ref.current_state(), alt.current_state()
+    m = a.active_mask()
+    assert m.sum() > 1000 and np.array_equal(m, b.active_mask())
+    assert np.array_equal(a.values()[m], b.values()[m])
