@@ -525,7 +525,8 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
             static const bool single_env = getenv("LSM_CFL_SINGLE_PASS") != nullptr;   // A/B switch
-            const bool two_pass = !single_env && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
+            // (on a band the exact divisions run on the few band nodes only: one pass)
+            const bool two_pass = !single_env && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
             // u(x)·g(t): the nodes that can attain the maximum are the same for every t (recorded once, with g = 1)
             static const bool nocand_env = getenv("LSM_CFL_NO_CANDIDATES") != nullptr;   // A/B switch
             const bool sep_time = two_pass && !nocand_env && h->cfl_cache_on && !h->band_mask && tm.coeff.kind == LSM_COEFF_SEPARABLE &&
