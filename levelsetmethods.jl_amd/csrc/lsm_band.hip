@@ -363,45 +363,68 @@ __global__ void __launch_bounds__(256) band_extrapolate_kernel(BandArgs a, const
 // cells, dilations, the halo test and the nearest-node search handle a whole x-line per operation.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
+#ifndef LSM_BAND_GK
+#define LSM_BAND_GK 16
+#endif
+constexpr int GK = LSM_BAND_GK;   // x-line loads a wave keeps in flight while staging
 
-// stage one flag word per x-line of the box: wave per row, lanes along x, K rows in flight per wave.
-// flags(q, ok, row, f): f[k] = flag bits of this lane's node of row[k] (bit wd goes to out[wd][row]).
-template <int K, int NW, typename F>
+// Stage one flag word per x-line of the box: a wave takes a contiguous run of rows, lanes along x.  The row
+// bookkeeping (coordinates, validity, base address) is computed for 64 rows at once, one row per LANE, and
+// broadcast row by row with v_readlane; the ballots are gathered back one row per lane and stored with a single
+// LDS write per 64 rows.  (A version that did the row arithmetic on the scalar unit was bound by it: ~35 scalar
+// instructions per row against ~8 here.)
+// load(q, ok, rowB) -> flag bits of this lane's node (bit wd goes to out[wd][row]); q is always a valid address;
+// rowB = Bin[row] (the band word of the row, for the second pass) or 0.
+__device__ __forceinline__ u64 readlane64(u64 v, int k) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), k);
+    return ((u64)hi << 32) | lo;
+}
+template <int U, int NW, typename F>
 __device__ __forceinline__ void stage_rows(const BandArgs& a, int ap, int bx, int by, int bm, int x0, int y0, int m0, u64* const (&out)[NW],
-                                           F flags) {
+                                           const u64* Bin, F load) {
     const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the row arithmetic below is scalar
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrows = by * bm;
+    const int rpw = (nrows + nwv - 1) / nwv;
+    const int rbeg = wv * rpw, rend = rbeg + rpw < nrows ? rbeg + rpw : nrows;
     const int gx = x0 - ap + lane;
     const bool xok = (lane < bx) & ((unsigned)gx < (unsigned)a.n[0]);
-    const long long qx = a.origin + (xok ? gx : 0);
-    for (int row0 = wv * K; row0 < nrows; row0 += nwv * K) {
-        long long q[K];
-        bool ok[K];
-        int rows[K];
-        unsigned f[K];
-        int lm = row0 / by, ly = row0 - lm * by;
+    const long long xoff = xok ? gx : 0;
+    const float rby = 1.0f / (float)by;
+    for (int c0 = rbeg; c0 < rend; c0 += 64) {
+        const int cnt = rend - c0 < 64 ? rend - c0 : 64;      // wave-uniform
+        // lane j prepares row c0 + j
+        const int row = c0 + lane < nrows ? c0 + lane : nrows - 1;
+        int lm = (int)((float)row * rby), ly = row - lm * by;
+        if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+        const int gy = y0 - ap + ly, gm = m0 - ap + lm;
+        const int rok = (lane < cnt) & ((unsigned)gy < (unsigned)a.n[1]) & ((unsigned)gm < (unsigned)a.n[2]);
+        const u64 base = (u64)(a.origin + (rok ? gy * a.s1 + gm * a.s2 : 0ll));
+        const u64 bin = Bin ? Bin[row] : 0ull;
+        u64 word[NW];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            // branch-free: out-of-range rows and nodes load from a valid address and are masked afterwards
-            const int gy = y0 - ap + ly, gm = m0 - ap + lm;
-            const bool rok = (row0 + k < nrows) & ((unsigned)gy < (unsigned)a.n[1]) & ((unsigned)gm < (unsigned)a.n[2]);
-            ok[k] = xok & rok;
-            q[k] = qx + (rok ? gy * a.s1 + gm * a.s2 : 0ll);
-            rows[k] = row0 + k < nrows ? row0 + k : 0;
-            ++ly;
-            const bool wrap = ly >= by;
-            ly = wrap ? 0 : ly;
-            lm += wrap ? 1 : 0;
-        }
-        flags(q, ok, rows, f);                 // K independent loads per lane
+        for (int wd = 0; wd < NW; ++wd) word[wd] = 0;
+        for (int k0 = 0; k0 < cnt; k0 += U) {
+            unsigned f[U];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int wd = 0; wd < NW; ++wd) {
-                const u64 bal = __ballot((f[k] >> wd) & 1u);
-                if (lane == 0 && row0 + k < nrows) out[wd][row0 + k] = bal;
+            for (int u = 0; u < U; ++u) {                      // U independent loads in flight
+                const int k = k0 + u < cnt ? k0 + u : cnt - 1;
+                const long long q = (long long)readlane64(base, k) + xoff;
+                const bool ok = xok & (__builtin_amdgcn_readlane(rok, k) != 0) & (k0 + u < cnt);
+                f[u] = load(q, ok, readlane64(bin, k));
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int wd = 0; wd < NW; ++wd) {
+                    const u64 bal = __ballot((f[u] >> wd) & 1u);
+                    if (lane == k0 + u) word[wd] = bal;       // v_cndmask, no exec juggling
+                }
+        }
+        if (lane < cnt)
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) out[wd][c0 + lane] = word[wd];
     }
 }
 
@@ -419,11 +442,9 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
     u64 *B = w3, *LE = w3 + nrows, *GE = w3 + 2 * nrows, *S0 = w3 + 3 * nrows, *S1 = w3 + 4 * nrows;
     // pass 1: the old band's row words; tiles whose box holds no band node have no cut cell -> empty
     u64* const out1[1] = {B};
-    stage_rows<16, 1>(a, ap, bx, by, bm, x0, y0, m0, out1, [&](const long long (&q)[16], const bool (&ok)[16], const int (&)[16], unsigned (&f)[16]) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = old_mask ? (unsigned)old_mask[q[k]] : 1u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = ok[k] ? f[k] : 0u;
+    stage_rows<GK, 1>(a, ap, bx, by, bm, x0, y0, m0, out1, nullptr, [&](long long q, bool ok, u64) -> unsigned {
+        const unsigned f = old_mask ? (unsigned)old_mask[q] : 1u;
+        return ok ? f : 0u;
     });
     __syncthreads();
     // tile is 32 × 8 × tm; the block's 256-thread groups take planes pg, pg + npg, ...
@@ -441,17 +462,10 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
     }
     // pass 2: values of the band nodes -> (<= 0) and (>= 0) row words
     u64* const out2[2] = {LE, GE};
-    stage_rows<16, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, [&](const long long (&q)[16], const bool (&)[16], const int (&rows)[16], unsigned (&f)[16]) {
-        const int lane = threadIdx.x & 63;
-        double xv[16];
-        bool on[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            on[k] = (B[rows[k]] >> lane) & 1ull;
-            xv[k] = ld_val(v, on[k] ? q[k] : a.origin, a.f32);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = on[k] ? ((xv[k] <= 0.0 ? 1u : 0u) | (xv[k] >= 0.0 ? 2u : 0u)) : 0u;
+    stage_rows<GK, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, B, [&](long long q, bool, u64 rowB) -> unsigned {
+        const bool on = (rowB >> (threadIdx.x & 63)) & 1ull;
+        const double xv = ld_val(v, on ? q : a.origin, a.f32);
+        return on ? ((xv <= 0.0 ? 1u : 0u) | (xv >= 0.0 ? 2u : 0u)) : 0u;
     });
     __syncthreads();
     const float rby = 1.0f / (float)by;
@@ -540,11 +554,9 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
     extern __shared__ u64 w3[];
     u64 *B = w3, *T = w3 + nrows;            // T: halo words of the tile rows (ty × tm)
     u64* const outs[1] = {B};
-    stage_rows<16, 1>(a, RL, bx, by, bm, x0, y0, m0, outs, [&](const long long (&q)[16], const bool (&ok)[16], const int (&)[16], unsigned (&f)[16]) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = src_mask[q[k]];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) f[k] = ok[k] ? f[k] : 0u;
+    stage_rows<GK, 1>(a, RL, bx, by, bm, x0, y0, m0, outs, nullptr, [&](long long q, bool ok, u64) -> unsigned {
+        const unsigned f = src_mask[q];
+        return ok ? f : 0u;
     });
     __syncthreads();
     if (halo) {
