@@ -269,6 +269,17 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
 int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask,
                          const void* tiles, int mc, double t, double* dt_out);
 
+/* ---- reinitialize!(ϕ; order = 3, upsample = 2, maxiters = 20, xtol, ftol) (src/reinitializer.jl:12-42):
+ *      every active node (every node when mask == NULL, the band nodes otherwise) is overwritten with
+ *      sign(ϕ)·distance to the zero set of the piecewise-polynomial interpolant of ϕ (NewtonSDF, src/sdf.jl:
+ *      interface samples by Newton projection, nearest sample as seed, Newton–Lagrange closest point on the
+ *      seed cell's Bernstein patch).  phi: ghosts filled (lsm_fill_ghosts) and, with a mask, the band halo
+ *      filled (lsm_band_prepare); work: a field-sized scratch array.  order in 1..5.
+ *      Out: candidate cells sampled, nodes whose solve did not converge (the reference warns), nodes left
+ *      untouched because the field has no interface sample at all. */
+int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int order, int upsample, int maxiters,
+                     double xtol, double ftol, int64_t* ncandidate_cells, int64_t* nfail, int64_t* nfar);
+
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ---- */
 int lsm_profile_enable(LsmHandle* h, int on);
 int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total);   /* synchronises; resets */

@@ -11,7 +11,7 @@ from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm
                   ExtrapolationBC, ForwardEuler, LazyMeshField, LevelSetEquation, LevelSetTerm, LinearExtrapolationBC, MeshField,
                   NarrowBandMeshField, NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField,
                   ROCNarrowBandMeshField, SeparableCoefficient,
-                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_,
+                  SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_, reinitialize_,
                   perimeter, volume,
                   vortex_deformation)
 
@@ -21,5 +21,5 @@ __all__ = [
     "NarrowBandMeshField", "ROCNarrowBandMeshField", "NeumannBC", "NormalMotionTerm", "PeriodicBC", "RK2", "RK3",
     "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
-    "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "LsmError", "build",
+    "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "reinitialize_", "LsmError", "build",
 ]

@@ -93,6 +93,8 @@ _SIGS = [
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_band_halo", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_band_fill_list", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("lsm_reinitialize", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("lsm_band_prepare", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]),
     ("lsm_band_status", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("lsm_band_fill", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

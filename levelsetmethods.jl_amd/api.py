@@ -1056,6 +1056,38 @@ def extend_along_normals_(F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_
     return F
 
 
+def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
+    """reinitialize!(ϕ; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
+    (src/reinitializer.jl:12-42): overwrite every active node of ϕ with its signed distance to the interface,
+    by the Newton closest-point method on the piecewise-polynomial interpolant of ϕ (NewtonSDF, src/sdf.jl).
+    `phi` is a device field (or an equation: its current state).  Returns ϕ; warns, like the reference, when
+    the closest-point solver did not converge at some nodes."""
+    import warnings
+    if isinstance(phi, LevelSetEquation):
+        phi = phi.current_state()
+    if not isinstance(phi, ROCMeshField):
+        raise TypeError("reinitialize_ expects a device field (ROCMeshField / ROCNarrowBandMeshField) or a LevelSetEquation")
+    if phi.bcs is None:
+        raise ValueError("the field needs boundary conditions: the interpolation stencils reach outside the grid")
+    b = phi.backend
+    eps = float(np.finfo(getattr(b, "dtype", np.dtype(np.float64))).eps)
+    xtol = math.sqrt(eps) if xtol is None else float(xtol)      # sqrt(eps(T)), T = float(valtype(ϕ)) — src/sdf.jl:66-67
+    ftol = math.sqrt(eps) if ftol is None else float(ftol)
+    band = isinstance(phi, ROCNarrowBandMeshField)
+    if band:
+        phi.prepare(phi.buf)              # stencil nodes off the band: the affine extrapolant, then the BC ghosts
+    else:
+        b.fill_ghosts(phi.buf, 7)
+    ncand, nfail, nfar = b.reinitialize(phi.buf, phi.mask if band else None, order, upsample, maxiters, xtol, ftol)
+    phi.ghosts_dirty = True
+    if nfar:
+        warnings.warn(f"reinitialize!: no interface sample was found ({nfar} nodes left unchanged)")
+    if nfail:
+        n_active = phi.active_count() if band else int(np.prod(phi.mesh.n))
+        warnings.warn(f"reinitialize!: closest-point solver did not converge for {nfail} / {n_active} points")
+    return phi
+
+
 def current_state(ls):
     return ls.current_state()
 

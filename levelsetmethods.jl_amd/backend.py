@@ -237,6 +237,14 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_perimeter(self.h, self.ptr(t), C.byref(out)), "lsm_perimeter")
         return out.value
 
+    def reinitialize(self, phi, mask, order, upsample, maxiters, xtol, ftol):
+        work = self.alloc()
+        nc, nfail, nfar = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.h, self.lib.lsm_reinitialize(self.h, self.ptr(phi), self.ptr(mask), self.ptr(work), int(order), int(upsample),
+                                                  int(maxiters), float(xtol), float(ftol), C.byref(nc), C.byref(nfail), C.byref(nfar)),
+                "lsm_reinitialize")
+        return int(nc.value), int(nfail.value), int(nfar.value)
+
     def sync(self):
         L.check(self.h, self.lib.lsm_sync(self.h), "lsm_sync")
 

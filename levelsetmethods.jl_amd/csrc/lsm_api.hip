@@ -1020,6 +1020,30 @@ int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const v
     return r;
 }
 
+// reinitialize!(ϕ; order, upsample, maxiters, xtol, ftol) — src/reinitializer.jl:12-42.  `phi` must be readable by
+// stencils (ghosts filled; band halo filled when mask != NULL); `work` is a field-sized scratch array.
+int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int order, int upsample, int maxiters, double xtol, double ftol,
+                     int64_t* ncandidate_cells, int64_t* nfail, int64_t* nfar) {
+    if (!h || !phi || !work) return h ? fail(h, LSM_ERR_INVALID, "lsm_reinitialize: null argument") : LSM_ERR_INVALID;
+    if (upsample < 1 || upsample > 16) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: upsample must be in 1..16");
+    if (maxiters < 1) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: maxiters must be positive");
+    if (!(xtol > 0) || !(ftol > 0)) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: tolerances must be positive");
+    LSM_TRY(check_single_device(h));
+    const int N = h->grid.ndim;
+    double lc[3] = {0, 0, 0};
+    for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
+    long long counts[3] = {0, 0, 0};
+    const char* err = nullptr;
+    const int r = reinit_run(N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, lc, h->h, order, upsample, maxiters, xtol, ftol,
+                             phi, is_f32(h), (const unsigned char*)mask, work, h->stream, counts, &err);
+    if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_reinitialize");
+    if (r) return fail(h, LSM_ERR_HIP, err ? err : "lsm_reinitialize");
+    if (ncandidate_cells) *ncandidate_cells = counts[0];
+    if (nfail) *nfail = counts[1];
+    if (nfar) *nfar = counts[2];
+    return LSM_OK;
+}
+
 int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;

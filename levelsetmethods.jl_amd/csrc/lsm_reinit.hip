@@ -1,0 +1,465 @@
+// lsm_reinit.hip — reinitialize!(ϕ; order, upsample, maxiters, xtol, ftol) on the device: the Newton
+// closest-point signed distance of the reference (src/reinitializer.jl:12-42, src/sdf.jl,
+// src/interpolation.jl, src/bernstein.jl).
+//
+//  * the continuous field is the reference's piecewise interpolant: on the cell with lower corner I, the
+//    tensor-product polynomial whose Bernstein coefficients are kron(M,…,M)·(stencil values), M the
+//    pseudo-inverse of the Bernstein collocation matrix (src/interpolation.jl:52-63,100-151).  It is evaluated
+//    here in the equivalent cardinal form p(x) = Σ_j v_j Π_d L_{j_d}(t_d), L_j(t) = Σ_i M_ij B_i(t): no
+//    per-cell coefficient storage, value / gradient / Hessian are the exact derivatives of the same polynomial
+//    (the reference differentiates it with ForwardDiff).
+//  * sampling (src/sdf.jl:186-221): uniformly spaced start points of every candidate cell are projected onto
+//    the zero set by Newton steps that follow the iterate across cells; converged points that land back in
+//    their own cell are kept.  The reference skips cells it can prove empty from the Bernstein coefficients;
+//    skipping is only an optimisation (a start point of an empty cell never converges back into it), so any
+//    conservative filter yields the same sample set: here |p - c| <= Λ·spread of the stencil values.
+//  * closest point (src/sdf.jl:85-131,223-249): nearest sample (exact: expanding shells of cells, instead of
+//    the reference's KD-tree) seeds a damped Newton–Lagrange solve on the seed cell's patch; up to 4 further
+//    nearest seeds are tried when it fails (the reference tries up to 10).
+// fp64 throughout, -ffp-contract=off.
+#include <cmath>
+#include <vector>
+
+#include "lsm_internal.h"
+
+namespace lsm {
+
+struct ReinitArgs {
+    int ndim;
+    int n[3];              // nodes (local = global: single device)
+    long long s1, s2, origin;
+    double lc[3], h[3];
+    int order, nv, off;    // polynomial degree, stencil size, stencil offset of the cell's lower corner
+    double M[36];          // [order+1][nv]
+    double lambda;         // Lebesgue-type constant of the patch: |p - c| <= lambda * max_j |v_j - c|
+    int upsample, maxiters;
+    double xtol, ftol;
+    const void* phi;       // padded field, ghosts / band halo filled
+    int f32;
+    const unsigned char* mask;   // NULL = dense
+};
+
+__device__ __constant__ double kBinom[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0},
+                                               {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
+
+struct Card { double L[6], dL[6], d2L[6]; };
+
+// degree-m Bernstein basis value with out-of-range indices = 0
+__device__ __forceinline__ double bern(int m, int i, const double* tp, const double* sp) {
+    return (i < 0 || i > m || m < 0) ? 0.0 : kBinom[m][i] * tp[i] * sp[m - i];
+}
+// cardinal functions of one dimension at local coordinate t, derivatives w.r.t. x (1/h folded in)
+__device__ void cardinal(const ReinitArgs& a, double t, double invh, bool second, Card& o) {
+    const int n = a.order;
+    double tp[6], sp[6];
+    tp[0] = sp[0] = 1.0;
+    for (int i = 1; i <= n; ++i) { tp[i] = tp[i - 1] * t; sp[i] = sp[i - 1] * (1.0 - t); }
+    double B[6], dB[6], d2B[6];
+    for (int i = 0; i <= n; ++i) {
+        B[i] = bern(n, i, tp, sp);
+        dB[i] = n * (bern(n - 1, i - 1, tp, sp) - bern(n - 1, i, tp, sp));
+        d2B[i] = second ? n * (n - 1) * (bern(n - 2, i - 2, tp, sp) - 2.0 * bern(n - 2, i - 1, tp, sp) + bern(n - 2, i, tp, sp)) : 0.0;
+    }
+    for (int j = 0; j < a.nv; ++j) {
+        double l = 0.0, dl = 0.0, d2l = 0.0;
+        for (int i = 0; i <= n; ++i) {
+            const double m = a.M[i * a.nv + j];
+            l += m * B[i]; dl += m * dB[i]; d2l += m * d2B[i];
+        }
+        o.L[j] = l; o.dL[j] = dl * invh; o.d2L[j] = d2l * invh * invh;
+    }
+}
+
+// value, gradient and (optionally) Hessian {00,11,22,01,02,12} of the patch of cell I at x
+__device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3], bool second, double& val, double g[3], double H[6]) {
+    Card c[3];
+    for (int d = 0; d < 3; ++d) {
+        if (d < a.ndim) {
+            const double t = (x[d] - (a.lc[d] + (double)I[d] * a.h[d])) / a.h[d];
+            cardinal(a, t, 1.0 / a.h[d], second, c[d]);
+        } else {
+            c[d].L[0] = 1.0; c[d].dL[0] = 0.0; c[d].d2L[0] = 0.0;
+        }
+    }
+    const int nv0 = a.nv, nv1 = a.ndim > 1 ? a.nv : 1, nv2 = a.ndim > 2 ? a.nv : 1;
+    const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
+    val = 0.0; g[0] = g[1] = g[2] = 0.0;
+    for (int k = 0; k < 6; ++k) H[k] = 0.0;
+    for (int j2 = 0; j2 < nv2; ++j2)
+        for (int j1 = 0; j1 < nv1; ++j1) {
+            double s = 0.0, ds = 0.0, d2s = 0.0;
+            const long long q = q0 + j1 * a.s1 + j2 * a.s2;
+            for (int j0 = 0; j0 < nv0; ++j0) {
+                const double v = ld_val(a.phi, q + j0, a.f32);
+                s += v * c[0].L[j0]; ds += v * c[0].dL[j0]; d2s += v * c[0].d2L[j0];
+            }
+            const double L1 = c[1].L[j1], D1 = c[1].dL[j1], E1 = c[1].d2L[j1];
+            const double L2 = c[2].L[j2], D2 = c[2].dL[j2], E2 = c[2].d2L[j2];
+            val += s * L1 * L2;
+            g[0] += ds * L1 * L2; g[1] += s * D1 * L2; g[2] += s * L1 * D2;
+            if (second) {
+                H[0] += d2s * L1 * L2; H[1] += s * E1 * L2; H[2] += s * L1 * E2;
+                H[3] += ds * D1 * L2; H[4] += ds * L1 * D2; H[5] += s * D1 * D2;
+            }
+        }
+}
+
+// compute_index (src/meshes.jl:155-167): cell containing x, clamped to the grid
+__device__ __forceinline__ void cell_of(const ReinitArgs& a, const double x[3], int I[3]) {
+    for (int d = 0; d < 3; ++d) {
+        if (d >= a.ndim) { I[d] = 0; continue; }
+        int i = (int)floor((x[d] - a.lc[d]) / a.h[d]);
+        I[d] = i < 0 ? 0 : (i > a.n[d] - 2 ? a.n[d] - 2 : i);
+    }
+}
+__device__ __forceinline__ long long cell_lin(const ReinitArgs& a, const int I[3]) {   // over the (n-1)^N cells
+    return I[0] + (long long)(a.n[0] - 1) * (I[1] + (long long)(a.ndim > 1 ? a.n[1] - 1 : 1) * I[2]);
+}
+__device__ __forceinline__ long long ncells(const ReinitArgs& a) {
+    return (long long)(a.n[0] - 1) * (a.ndim > 1 ? a.n[1] - 1 : 1) * (a.ndim > 2 ? a.n[2] - 1 : 1);
+}
+__device__ __forceinline__ void cell_unlin(const ReinitArgs& a, long long c, int I[3]) {
+    const long long c0 = a.n[0] - 1, c1 = a.ndim > 1 ? a.n[1] - 1 : 1;
+    I[0] = (int)(c % c0); I[1] = (int)((c / c0) % c1); I[2] = (int)(c / (c0 * c1));
+}
+
+// ---- 1. candidate cells: active (all corners in the band, src/meshfield.jl:364-369) and not provably empty
+__global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* cand_cell, unsigned cand_cap,
+                                                           unsigned* cand_count) {
+    const long long nc = ncells(a);
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (long long)gridDim.x * blockDim.x) {
+        int I[3];
+        cell_unlin(a, c, I);
+        const long long qc = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
+        bool act = true;
+        if (a.mask)
+            for (int k = 0; k < (1 << a.ndim); ++k)
+                act = act && a.mask[qc + (k & 1) + ((k >> 1) & 1) * a.s1 + ((k >> 2) & 1) * a.s2];
+        int id = -1;
+        if (act) {
+            const int nv1 = a.ndim > 1 ? a.nv : 1, nv2 = a.ndim > 2 ? a.nv : 1;
+            const long long q0 = qc + a.off + (a.ndim > 1 ? a.off * a.s1 : 0) + (a.ndim > 2 ? a.off * a.s2 : 0);
+            double lo = __builtin_inf(), hi = -__builtin_inf();
+            for (int j2 = 0; j2 < nv2; ++j2)
+                for (int j1 = 0; j1 < nv1; ++j1)
+                    for (int j0 = 0; j0 < a.nv; ++j0) {
+                        const double v = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+                        lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+                    }
+            const double mid = 0.5 * (lo + hi), spread = 0.5 * (hi - lo);
+            const bool empty = mid - a.lambda * spread > 0.0 || mid + a.lambda * spread < 0.0;   // p cannot vanish
+            if (!empty && lo == lo && hi == hi) {
+                id = (int)atomicAdd(cand_count, 1u);
+                if ((unsigned)id < cand_cap) cand_cell[id] = c;     // pass 2 of the host (pass 1 only counts)
+            }
+        }
+        cand_id[c] = id;
+    }
+}
+
+// ---- 2. interface samples: one thread per (candidate cell, start point)
+__global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
+                                                            unsigned char* valid) {
+    const long long total = (long long)ncand * S;
+    double hmax = a.h[0];
+    for (int d = 1; d < a.ndim; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
+    const int up1 = a.upsample + 1;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long id = w / S;
+        const int s = (int)(w - id * S);
+        int I[3];
+        cell_unlin(a, cand_cell[id], I);
+        const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
+        double x0[3] = {0, 0, 0}, x[3];
+        for (int d = 0; d < a.ndim; ++d) x0[d] = (a.lc[d] + (double)I[d] * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
+        x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2];
+        bool conv = false;
+        for (int it = 0; it < a.maxiters; ++it) {      // _project_to_interface (src/sdf.jl:223-236)
+            int J[3];
+            cell_of(a, x, J);
+            double val, g[3], H[6];
+            patch_eval(a, J, x, false, val, g, H);
+            if (fabs(val) < a.ftol) { conv = true; break; }
+            const double g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (g2 == 0.0 || !(g2 == g2)) break;
+            double dist2 = 0.0;
+            for (int d = 0; d < a.ndim; ++d) { x[d] = x[d] - val * g[d] / g2; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
+            if (sqrt(dist2) > hmax) break;
+        }
+        bool keep = false;
+        if (conv) {
+            int J[3];
+            cell_of(a, x, J);
+            keep = J[0] == I[0] && J[1] == I[1] && J[2] == I[2];
+        }
+        const long long slot = id * S + s;
+        valid[slot] = keep ? 1 : 0;
+        if (keep) { pts[3 * slot] = x[0]; pts[3 * slot + 1] = x[1]; pts[3 * slot + 2] = x[2]; }
+    }
+}
+
+// (N+1)x(N+1) solve with partial pivoting; returns false if singular
+__device__ bool solve_small(int m, double A[4][4], double b[4]) {
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        double best = fabs(A[k][k]);
+        for (int r = k + 1; r < m; ++r)
+            if (fabs(A[r][k]) > best) { best = fabs(A[r][k]); p = r; }
+        if (best == 0.0 || !(best == best)) return false;
+        if (p != k) {
+            for (int cc = 0; cc < m; ++cc) { const double t = A[k][cc]; A[k][cc] = A[p][cc]; A[p][cc] = t; }
+            const double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        for (int r = k + 1; r < m; ++r) {
+            const double f = A[r][k] / A[k][k];
+            for (int cc = k; cc < m; ++cc) A[r][cc] -= f * A[k][cc];
+            b[r] -= f * b[k];
+        }
+    }
+    for (int k = m - 1; k >= 0; --k) {
+        double sacc = b[k];
+        for (int cc = k + 1; cc < m; ++cc) sacc -= A[k][cc] * b[cc];
+        b[k] = sacc / A[k][k];
+    }
+    return true;
+}
+
+// _closest_point (src/sdf.jl:239-272) on the patch of cell I, from x0; returns converged
+__device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const double xq[3], const double x0[3], double safeguard, double cp[3]) {
+    const int N = a.ndim;
+    double val, g[3], H[6];
+    patch_eval(a, I, x0, false, val, g, H);
+    double g2 = 0.0, num = 0.0;
+    for (int d = 0; d < N; ++d) { g2 += g[d] * g[d]; num += (xq[d] - x0[d]) * g[d]; }
+    double lam = g2 == 0.0 ? 0.0 : num / g2;
+    double x[3] = {x0[0], x0[1], x0[2]};
+    double best_res = __builtin_inf();
+    cp[0] = x0[0]; cp[1] = x0[1]; cp[2] = x0[2];
+    const double reg = 1.4901161193847656e-08;   // sqrt(eps(Float64))
+    for (int it = 0; it < a.maxiters; ++it) {
+        patch_eval(a, I, x, true, val, g, H);
+        double res[4], rn2 = 0.0;
+        for (int d = 0; d < N; ++d) { res[d] = x[d] - xq[d] + lam * g[d]; rn2 += res[d] * res[d]; }
+        res[N] = val; rn2 += val * val;
+        const double rn = sqrt(rn2);
+        if (rn < best_res) { best_res = rn; cp[0] = x[0]; cp[1] = x[1]; cp[2] = x[2]; }
+        if (fabs(val) < a.ftol && rn < a.xtol) { cp[0] = x[0]; cp[1] = x[1]; cp[2] = x[2]; return true; }
+        double K[4][4];
+        const double Hm[3][3] = {{H[0], H[3], H[4]}, {H[3], H[1], H[5]}, {H[4], H[5], H[2]}};
+        for (int r = 0; r < N; ++r) {
+            for (int cc = 0; cc < N; ++cc) K[r][cc] = (r == cc ? 1.0 : 0.0) + lam * Hm[r][cc] + (r == cc ? reg : 0.0);
+            K[r][N] = g[r]; K[N][r] = g[r];
+        }
+        K[N][N] = reg;
+        double rhs[4];
+        for (int r = 0; r <= N; ++r) rhs[r] = -res[r];
+        if (!solve_small(N + 1, K, rhs)) return false;
+        double nd = 0.0;
+        for (int d = 0; d < N; ++d) nd += rhs[d] * rhs[d];
+        nd = sqrt(nd);
+        const double alpha = nd > 0.0 ? (safeguard / nd < 1.0 ? safeguard / nd : 1.0) : 1.0;
+        double dist2 = 0.0;
+        for (int d = 0; d < N; ++d) { x[d] += alpha * rhs[d]; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
+        lam += alpha * rhs[N];
+        if (sqrt(dist2) > safeguard) return false;
+    }
+    return false;
+}
+
+// ---- 3. signed distance of every active node
+constexpr int NSEED = 5;
+__global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* valid,
+                                                             void* out, unsigned* nfail, unsigned* nfar) {
+    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
+    double hmin = a.h[0], hmax = a.h[0];
+    for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
+    int smax = 1;
+    for (int d = 0; d < a.ndim; ++d) smax = a.n[d] > smax ? a.n[d] : smax;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
+        const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
+        if (a.mask && !a.mask[q]) continue;
+        double xq[3] = {0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
+        // nearest samples: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then
+        // farther than s*hmin
+        double bd[NSEED];
+        long long bslot[NSEED];
+        for (int k = 0; k < NSEED; ++k) { bd[k] = __builtin_inf(); bslot[k] = -1; }
+        for (int s = 1; s <= smax; ++s) {
+            const int lo[3] = {I[0] - s, a.ndim > 1 ? I[1] - s : 0, a.ndim > 2 ? I[2] - s : 0};
+            const int hi[3] = {I[0] + s - 1, a.ndim > 1 ? I[1] + s - 1 : 0, a.ndim > 2 ? I[2] + s - 1 : 0};
+            for (int c2 = lo[2]; c2 <= hi[2]; ++c2)
+                for (int c1 = lo[1]; c1 <= hi[1]; ++c1) {
+                    const bool edge12 = (a.ndim > 2 && (c2 == lo[2] || c2 == hi[2])) || (a.ndim > 1 && (c1 == lo[1] || c1 == hi[1]));
+                    for (int c0 = lo[0]; c0 <= hi[0]; c0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) {   // shell cells only
+                        if (c0 < 0 || c0 > a.n[0] - 2 || c1 < 0 || c1 > (a.ndim > 1 ? a.n[1] - 2 : 0) || c2 < 0 || c2 > (a.ndim > 2 ? a.n[2] - 2 : 0)) continue;
+                        const int J[3] = {c0, c1, c2};
+                        const int id = cand_id[cell_lin(a, J)];
+                        if (id < 0) continue;
+                        for (int k = 0; k < S; ++k) {
+                            const long long slot = (long long)id * S + k;
+                            if (!valid[slot]) continue;
+                            double d2 = 0.0;
+                            for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                            if (d2 < bd[NSEED - 1]) {           // sorted insertion
+                                int p = NSEED - 1;
+                                while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; bslot[p] = bslot[p - 1]; --p; }
+                                bd[p] = d2; bslot[p] = slot;
+                            }
+                        }
+                    }
+                }
+            if (bslot[0] >= 0 && sqrt(bd[0]) <= (double)s * hmin) break;
+        }
+        double cp[3] = {xq[0], xq[1], xq[2]};
+        bool conv = false;
+        if (bslot[0] < 0) {
+            atomicAdd(nfar, 1u);
+        } else {
+            const double safeguard = 1.5 * hmax;
+            double bestcp[3] = {0, 0, 0}, bestd = __builtin_inf();
+            for (int k = 0; k < NSEED && bslot[k] >= 0 && !conv; ++k) {
+                const double seed[3] = {pts[3 * bslot[k]], pts[3 * bslot[k] + 1], pts[3 * bslot[k] + 2]};
+                int J[3];
+                cell_of(a, seed, J);
+                double c3[3];
+                conv = closest_on_patch(a, J, xq, seed, safeguard, c3);
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
+                if (conv || d2 < bestd) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
+                if (k == 0 && !conv) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
+            }
+            cp[0] = bestcp[0]; cp[1] = bestcp[1]; cp[2] = bestcp[2];
+            if (!conv) atomicAdd(nfail, 1u);
+        }
+        double d2 = 0.0;
+        for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - cp[d]) * (xq[d] - cp[d]);
+        const double v = ld_val(a.phi, q, a.f32);
+        const double sgn = v > 0 ? 1.0 : (v < 0 ? -1.0 : v);
+        st_val(out, q, a.f32, bslot[0] < 0 ? v : sgn * sqrt(d2));
+    }
+}
+
+// copy the new values of the active nodes back (the evaluation phase never writes ϕ: src/reinitializer.jl:21-24)
+__global__ void __launch_bounds__(256) reinit_commit_kernel(ReinitArgs a, const void* src, void* dst) {
+    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long q = a.origin + (t % a.n[0]) + ((t / a.n[0]) % a.n[1]) * a.s1 + (t / ((long long)a.n[0] * a.n[1])) * a.s2;
+        if (a.mask && !a.mask[q]) continue;
+        st_val(dst, q, a.f32, ld_val(src, q, a.f32));
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+// _interpolation_matrix (src/interpolation.jl:52-63): pseudo-inverse of the collocation matrix V (nv x nc) by the
+// normal equations in long double (V is tiny and well conditioned), and the bound Λ = (max_t Σ_j |L_j(t)|)^N
+static bool interp_matrix(int order, int ndim, double M[36], int* nv_out, double* lambda) {
+    const int so = order % 2 ? order : order + 1, nc = order + 1, nv = so + 1;
+    if (order < 1 || order > 5) return false;
+    auto binom = [](int n, int k) { double r = 1; for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i; return r; };
+    const long double a = (so - 1) / (2.0L * so), b = (so + 1) / (2.0L * so);
+    long double V[6][6], G[6][12];
+    for (int i = 0; i < nv; ++i) {
+        const long double x = ((long double)i / so - a) / (b - a);
+        for (int j = 0; j < nc; ++j) V[i][j] = binom(order, j) * powl(x, j) * powl(1 - x, order - j);
+    }
+    for (int r = 0; r < nc; ++r) {          // [VᵀV | I]
+        for (int c = 0; c < nc; ++c) { long double s = 0; for (int i = 0; i < nv; ++i) s += V[i][r] * V[i][c]; G[r][c] = s; }
+        for (int c = 0; c < nc; ++c) G[r][nc + c] = r == c ? 1 : 0;
+    }
+    for (int k = 0; k < nc; ++k) {          // Gauss–Jordan with partial pivoting
+        int p = k;
+        for (int r = k + 1; r < nc; ++r) if (fabsl(G[r][k]) > fabsl(G[p][k])) p = r;
+        if (G[p][k] == 0) return false;
+        for (int c = 0; c < 2 * nc; ++c) { long double t = G[k][c]; G[k][c] = G[p][c]; G[p][c] = t; }
+        const long double piv = G[k][k];
+        for (int c = 0; c < 2 * nc; ++c) G[k][c] /= piv;
+        for (int r = 0; r < nc; ++r) {
+            if (r == k) continue;
+            const long double f = G[r][k];
+            for (int c = 0; c < 2 * nc; ++c) G[r][c] -= f * G[k][c];
+        }
+    }
+    for (int i = 0; i < nc; ++i)            // M = (VᵀV)⁻¹ Vᵀ
+        for (int j = 0; j < nv; ++j) { long double s = 0; for (int c = 0; c < nc; ++c) s += G[i][nc + c] * V[j][c]; M[i * nv + j] = (double)s; }
+    double lam1 = 0;
+    for (int k = 0; k <= 400; ++k) {
+        const double t = k / 400.0;
+        double sum = 0;
+        for (int j = 0; j < nv; ++j) {
+            double l = 0;
+            for (int i = 0; i < nc; ++i) l += M[i * nv + j] * binom(order, i) * pow(t, i) * pow(1 - t, order - i);
+            sum += fabs(l);
+        }
+        lam1 = sum > lam1 ? sum : lam1;
+    }
+    *lambda = pow(lam1 * 1.01, ndim);
+    *nv_out = nv;
+    return true;
+}
+
+// returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
+int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
+               int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask, void* out_field,
+               hipStream_t stream, long long out_counts[3], const char** err) {
+    ReinitArgs a;
+    a.ndim = ndim;
+    for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
+    a.s1 = s1; a.s2 = s2; a.origin = origin;
+    a.order = order; a.upsample = upsample; a.maxiters = maxiters; a.xtol = xtol; a.ftol = ftol;
+    a.phi = phi; a.f32 = f32; a.mask = mask;
+    if (!interp_matrix(order, ndim, a.M, &a.nv, &a.lambda)) { *err = "reinitialize: order must be in 1..5"; return 1; }
+    a.off = -((a.nv - 1) - 1) / 2;
+    if (a.nv + a.off - 1 > LSM_GHOST + 1 || -a.off > LSM_GHOST) { *err = "reinitialize: stencil exceeds the ghost layers"; return 1; }
+    long long nc = 1;
+    for (int d = 0; d < ndim; ++d) nc *= n[d] - 1;
+    int S = 1;
+    for (int d = 0; d < ndim; ++d) S *= upsample + 1;
+    int* cand_id = nullptr;
+    long long* cand_cell = nullptr;
+    unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
+    double* pts = nullptr;
+    unsigned char* valid = nullptr;
+    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); };
+#define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
+    RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
+    RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
+    const unsigned gb = (unsigned)((nc + 255) / 256 > 65535 ? 65535 : (nc + 255) / 256);
+    // two passes: count the candidate cells, then list them (ids are handed out again, consistently with cand_id)
+    unsigned ncand = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
+        hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, cand_cell, pass ? ncand : 0u, counters);
+        if (pass == 0) {
+            RE_HIP(hipMemcpyAsync(&ncand, counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            RE_HIP(hipStreamSynchronize(stream));
+            RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(ncand ? ncand : 1)));
+        }
+    }
+    RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
+    const size_t slots = (size_t)(ncand ? ncand : 1) * S;
+    RE_HIP(hipMalloc((void**)&pts, sizeof(double) * 3 * slots));
+    RE_HIP(hipMalloc((void**)&valid, slots));
+    RE_HIP(hipMemsetAsync(valid, 0, slots, stream));
+    if (ncand) {
+        const long long work = (long long)ncand * S;
+        const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
+        hipLaunchKernelGGL(reinit_sample_kernel, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
+    }
+    const long long nodes = (long long)n[0] * n[1] * n[2];
+    const unsigned gn = (unsigned)((nodes + 127) / 128 > 262144 ? 262144 : (nodes + 127) / 128);
+    hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, valid, out_field, counters + 1, counters + 2);
+    hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
+                       out_field, phi);
+    unsigned cn[4] = {0, 0, 0, 0};
+    RE_HIP(hipMemcpyAsync(cn, counters, sizeof(cn), hipMemcpyDeviceToHost, stream));
+    RE_HIP(hipStreamSynchronize(stream));
+    RE_HIP(hipGetLastError());
+    out_counts[0] = ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
+#undef RE_HIP
+    cleanup();
+    return 0;
+}
+
+}  // namespace lsm
