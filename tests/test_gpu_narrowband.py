@@ -152,7 +152,7 @@ def _nb_full_error(nb_state, full_vals, nlayers, h):
 
 
 def test_integrate_advection_matches_full_grid(lsm):
-    """test/test-levelsetequation.jl:144-154 (without the out-of-scope reinitialize! hooks)"""
+    """test/test-levelsetequation.jl:144-154 without the reinitialize! hooks (with them: further down)"""
     grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (60, 60))
     phi = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2) - 0.5, grid)
     terms = lambda: (lsm.AdvectionTerm((1.0, 0.0)),)
@@ -176,10 +176,10 @@ def test_integrate_full_rotation_and_curvature_match_full_grid(lsm):
     grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (40, 40))
     phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.8) ** 2 + x[1] ** 2) - 0.5, grid)
     terms = lambda: (lsm.AdvectionTerm(lsm.RigidRotation()),)
-    # The reference runs this with nlayers = 3 and the Newton closest-point reinitialize! after every
-    # step (out of scope here); without any reinitialisation the band-edge extrapolation error
-    # accumulates over the ~250 steps (measured: 0.071 / 0.014 / 0.008 for nlayers 3 / 5 / 7), so the
-    # same 0.02 bar is checked with nlayers = 5, and nlayers = 3 over a quarter turn.
+    # WITHOUT any reinitialisation (the reference's own runs, with reinitialize! after every step, are restated
+    # further down): the band-edge extrapolation error accumulates over the ~250 steps (measured: 0.071 /
+    # 0.014 / 0.008 for nlayers 3 / 5 / 7), so the 0.02 bar is met with nlayers = 5, and by nlayers = 3 over a
+    # quarter turn.
     for nl, tf in ((5, 2 * math.pi), (3, math.pi / 2)):
         nb = _eq(lsm, phi, nl, terms=terms())
         full = lsm.LevelSetEquation(terms=terms(), ic=phi, bc=lsm.ExtrapolationBC(2))
@@ -301,3 +301,81 @@ def test_fallback_band_paths_give_the_same_band_and_values(lsm, monkeypatch, env
     m = a.active_mask()
     assert m.sum() > 1000 and np.array_equal(m, b.active_mask())
     assert np.array_equal(a.values()[m], b.values()[m])
+
+
+# ---- the reference's band integration tests with their reinitialize! hooks (test/test-levelsetequation.jl:144-222)
+
+def _reinit(lsm):
+    return lambda eq: lsm.reinitialize_(eq)
+
+
+def test_reference_band_tests_with_reinitialize_hooks(lsm):
+    bc = lsm.ExtrapolationBC(2)
+    # :144-154 advection matches full grid (nlayers 5; both runs reinitialised every step)
+    grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (60, 60))
+    phi = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2) - 0.5, grid)
+    t = lambda: (lsm.AdvectionTerm((1.0, 0.0)),)
+    nb = lsm.LevelSetEquation(terms=t(), ic=lsm.NarrowBandMeshField(phi, nlayers=5), bc=bc)
+    full = lsm.LevelSetEquation(terms=t(), ic=phi, bc=bc)
+    lsm.integrate_(full, 0.1, prehook=_reinit(lsm))
+    lsm.integrate_(nb, 0.1, posthook=_reinit(lsm))
+    assert _nb_full_error(nb.current_state(), full.current_state().values(), 5, min(grid.meshsize())) < 1.0e-3
+    # :156-172 advection with reinitialisation, default nlayers = 3, against the exact translated circle
+    nb = lsm.LevelSetEquation(terms=t(), ic=lsm.NarrowBandMeshField(phi), bc=bc)
+    lsm.integrate_(nb, 0.1, posthook=_reinit(lsm))
+    st = nb.current_state()
+    m, v = st.active_mask(), st.values()
+    X, Y = np.meshgrid(*grid.coords(), indexing="ij")
+    exact = np.sqrt((X - 0.1) ** 2 + Y ** 2) - 0.5
+    near = m & (np.abs(np.nan_to_num(v, nan=1e9)) < 1.5 * min(grid.meshsize()))
+    assert m.sum() > 0 and np.abs(v[near] - exact[near]).max() < 0.01
+
+
+def test_reference_band_full_and_star_rotation_with_reinitialize(lsm):
+    bc = lsm.ExtrapolationBC(2)
+    rot = lambda: (lsm.AdvectionTerm(lsm.RigidRotation()),)
+    # :194-205 full rotation, nlayers = 3, reinitialize! after every step
+    grid = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (40, 40))
+    phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.8) ** 2 + x[1] ** 2) - 0.5, grid)
+    nb = lsm.LevelSetEquation(terms=rot(), ic=lsm.NarrowBandMeshField(phi), bc=bc)
+    full = lsm.LevelSetEquation(terms=rot(), ic=phi, bc=bc)
+    lsm.integrate_(full, 2 * math.pi)
+    lsm.integrate_(nb, 2 * math.pi, posthook=_reinit(lsm))
+    assert nb.current_state().active_count() > 0
+    assert _nb_full_error(nb.current_state(), full.current_state().values(), 3, min(grid.meshsize())) < 0.02
+    # :207-222 star rotation over half a turn
+    g2 = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (40, 40))
+    star = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2) - (0.5 + 0.1 * np.cos(5 * (np.arctan2(x[1], x[0]) - math.pi / 2))), g2)
+    nb = lsm.LevelSetEquation(terms=rot(), ic=lsm.NarrowBandMeshField(star), bc=bc)
+    full = lsm.LevelSetEquation(terms=rot(), ic=star, bc=bc)
+    lsm.integrate_(full, math.pi)
+    lsm.integrate_(nb, math.pi, posthook=_reinit(lsm))
+    assert nb.current_state().active_count() > 0
+    assert _nb_full_error(nb.current_state(), full.current_state().values(), 3, min(g2.meshsize())) < 0.05
+
+
+def test_reference_band_spiral_curvature_flow_with_reinitialize(lsm):
+    """:174-192 — a spiral whose arms are closer than the band is wide stresses the band rebuild."""
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (50, 50))
+    r0, th0, al = 0.5, -math.pi / 3, math.pi / 100
+    R = np.array([[math.cos(al), -math.sin(al)], [math.sin(al), math.cos(al)]])
+    M = R @ np.array([[1 / 0.06 ** 2, 0.0], [0.0, 1 / (4 * math.pi ** 2)]]) @ R.T
+
+    def spiral(x):
+        r, th = np.sqrt(x[0] ** 2 + x[1] ** 2), np.arctan2(x[1], x[0])
+        best = None
+        for i in range(5):
+            v0, v1 = r - r0, th + (2 * i - 4) * math.pi - th0
+            q = np.sqrt(M[0, 0] * v0 * v0 + 2 * M[0, 1] * v0 * v1 + M[1, 1] * v1 * v1) - 1
+            best = q if best is None else np.minimum(best, q)
+        return best
+    phi = lsm.MeshField(spiral, grid)
+    bc = lsm.ExtrapolationBC(2)
+    nb = lsm.LevelSetEquation(terms=(lsm.CurvatureTerm(-0.1),), ic=lsm.NarrowBandMeshField(phi), bc=bc)
+    full = lsm.LevelSetEquation(terms=(lsm.CurvatureTerm(-0.1),), ic=phi, bc=bc)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # the reference warns on non-converged nodes too
+        lsm.integrate_(full, 0.1, prehook=_reinit(lsm))
+        lsm.integrate_(nb, 0.1, posthook=_reinit(lsm))
+    assert _nb_full_error(nb.current_state(), full.current_state().values(), 3, min(grid.meshsize())) < 0.05
