@@ -235,6 +235,19 @@ function LSM.extend_along_normals!(F::ROCMeshField, ϕ::ROCMeshField; nb_iters =
     return F
 end
 
+# reinitialize!(ϕ; ...) (src/reinitializer.jl:12-42)
+function LSM.reinitialize!(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
+    xt, ft = something(xtol, sqrt(eps(Float64))), something(ftol, sqrt(eps(Float64)))
+    _check(ϕ.handle, ccall((:lsm_fill_ghosts, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}), ϕ.handle, pointer(ϕ.buf), 7, C_NULL), "lsm_fill_ghosts")
+    work = similar(ϕ.buf)
+    nc, nfail, nfar = Ref{Int64}(), Ref{Int64}(), Ref{Int64}()
+    _check(ϕ.handle, ccall((:lsm_reinitialize, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ref{Int64}, Ref{Int64}, Ref{Int64}),
+        ϕ.handle, pointer(ϕ.buf), C_NULL, pointer(work), order, upsample, maxiters, xt, ft, nc, nfail, nfar), "lsm_reinitialize")
+    nfail[] > 0 && @warn "reinitialize!: closest-point solver did not converge for $(nfail[]) points"
+    return ϕ
+end
+
 # NarrowBandMeshField on the device (src/meshfield.jl:314-588): dense padded values + byte masks.
 const BAND_MC = 8
 mutable struct ROCNarrowBandMeshField{N,T,B} <: LSM.AbstractMeshField{N,T,Float64}

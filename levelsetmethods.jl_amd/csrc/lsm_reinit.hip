@@ -198,6 +198,36 @@ __global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const 
     }
 }
 
+// per candidate cell: move its kept samples to the front of its S slots, count them, and flag the coarse block
+// (RB^N cells) of every cell that holds a sample — the far-field search walks blocks, not cells
+constexpr int RB = 8;
+__device__ __forceinline__ long long blk_lin(const ReinitArgs& a, const int B[3]) {
+    const long long b0 = (a.n[0] - 1 + RB - 1) / RB, b1 = a.ndim > 1 ? (a.n[1] - 1 + RB - 1) / RB : 1;
+    return B[0] + b0 * (B[1] + b1 * B[2]);
+}
+__global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
+                                                             const unsigned char* valid, unsigned char* cnt, unsigned char* blk) {
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
+        int m = 0;
+        for (int k = 0; k < S; ++k) {
+            const long long slot = (long long)id * S + k;
+            if (!valid[slot]) continue;
+            if (k != m) {
+                const long long dst = (long long)id * S + m;
+                pts[3 * dst] = pts[3 * slot]; pts[3 * dst + 1] = pts[3 * slot + 1]; pts[3 * dst + 2] = pts[3 * slot + 2];
+            }
+            ++m;
+        }
+        cnt[id] = (unsigned char)(m > 255 ? 255 : m);
+        if (m) {
+            int I[3];
+            cell_unlin(a, cand_cell[id], I);
+            const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
+            blk[blk_lin(a, B)] = 1;
+        }
+    }
+}
+
 // (N+1)x(N+1) solve with partial pivoting; returns false if singular
 __device__ bool solve_small(int m, double A[4][4], double b[4]) {
     for (int k = 0; k < m; ++k) {
@@ -268,49 +298,92 @@ __device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const doub
 
 // ---- 3. signed distance of every active node
 constexpr int NSEED = 5;
-__global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* valid,
-                                                             void* out, unsigned* nfail, unsigned* nfar) {
+constexpr int FINE_SHELLS = 6;
+__global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
+                                                             const unsigned char* blk, void* out, unsigned* nfail, unsigned* nfar) {
     const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
-    int smax = 1;
-    for (int d = 0; d < a.ndim; ++d) smax = a.n[d] > smax ? a.n[d] : smax;
+    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};      // cells per dimension
+    const int nb_[3] = {(nc_[0] + RB - 1) / RB, (nc_[1] + RB - 1) / RB, (nc_[2] + RB - 1) / RB};  // blocks per dimension
+    int rmax = 1;
+    for (int d = 0; d < a.ndim; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
         if (a.mask && !a.mask[q]) continue;
         double xq[3] = {0, 0, 0};
         for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
-        // nearest samples: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then
-        // farther than s*hmin
+        // the NSEED nearest samples, nearest first
         double bd[NSEED];
         long long bslot[NSEED];
         for (int k = 0; k < NSEED; ++k) { bd[k] = __builtin_inf(); bslot[k] = -1; }
-        for (int s = 1; s <= smax; ++s) {
+        // squared distance from the node to the box of cells [c, c + w) per dimension (0 inside)
+        auto box_d2 = [&](int c0, int c1, int c2, int w) {
+            const int c[3] = {c0, c1, c2};
+            double d2 = 0.0;
+            for (int d = 0; d < a.ndim; ++d) {
+                const int gap = I[d] < c[d] ? c[d] - I[d] : (I[d] > c[d] + w ? I[d] - (c[d] + w) : 0);
+                const double e = (double)gap * a.h[d];
+                d2 += e * e;
+            }
+            return d2;
+        };
+        auto scan_cell = [&](int c0, int c1, int c2) {
+            if (c0 < 0 || c0 >= nc_[0] || c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) return;
+            if (box_d2(c0, c1, c2, 1) > bd[0]) return;       // cannot hold a nearer sample than the best so far
+            const int J[3] = {c0, c1, c2};
+            const int id = cand_id[cell_lin(a, J)];
+            if (id < 0) return;
+            const int m = cnt[id];
+            for (int k = 0; k < m; ++k) {
+                const long long slot = (long long)id * S + k;
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                if (d2 < bd[NSEED - 1]) {                 // sorted insertion, once per sample
+                    bool dup = false;
+                    for (int p = 0; p < NSEED; ++p) dup = dup || bslot[p] == slot;
+                    if (dup) continue;
+                    int p = NSEED - 1;
+                    while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; bslot[p] = bslot[p - 1]; --p; }
+                    bd[p] = d2; bslot[p] = slot;
+                }
+            }
+        };
+        // near field: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then
+        // farther than s*hmin
+        bool done = false;
+        for (int s = 1; s <= FINE_SHELLS && !done; ++s) {
             const int lo[3] = {I[0] - s, a.ndim > 1 ? I[1] - s : 0, a.ndim > 2 ? I[2] - s : 0};
             const int hi[3] = {I[0] + s - 1, a.ndim > 1 ? I[1] + s - 1 : 0, a.ndim > 2 ? I[2] + s - 1 : 0};
             for (int c2 = lo[2]; c2 <= hi[2]; ++c2)
                 for (int c1 = lo[1]; c1 <= hi[1]; ++c1) {
                     const bool edge12 = (a.ndim > 2 && (c2 == lo[2] || c2 == hi[2])) || (a.ndim > 1 && (c1 == lo[1] || c1 == hi[1]));
-                    for (int c0 = lo[0]; c0 <= hi[0]; c0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) {   // shell cells only
-                        if (c0 < 0 || c0 > a.n[0] - 2 || c1 < 0 || c1 > (a.ndim > 1 ? a.n[1] - 2 : 0) || c2 < 0 || c2 > (a.ndim > 2 ? a.n[2] - 2 : 0)) continue;
-                        const int J[3] = {c0, c1, c2};
-                        const int id = cand_id[cell_lin(a, J)];
-                        if (id < 0) continue;
-                        for (int k = 0; k < S; ++k) {
-                            const long long slot = (long long)id * S + k;
-                            if (!valid[slot]) continue;
-                            double d2 = 0.0;
-                            for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
-                            if (d2 < bd[NSEED - 1]) {           // sorted insertion
-                                int p = NSEED - 1;
-                                while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; bslot[p] = bslot[p - 1]; --p; }
-                                bd[p] = d2; bslot[p] = slot;
-                            }
+                    for (int c0 = lo[0]; c0 <= hi[0]; c0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) scan_cell(c0, c1, c2);   // shell cells only
+                }
+            done = bslot[0] >= 0 && sqrt(bd[0]) <= (double)s * hmin;
+        }
+        // far field: the same over blocks of RB^N cells, skipping blocks without samples; after block radius r every
+        // unseen sample is farther than (RB*r - 1)*hmin (the node lies inside the central block)
+        if (!done) {
+            const int Bn[3] = {(I[0] < nc_[0] ? I[0] : nc_[0] - 1) / RB, (I[1] < nc_[1] ? I[1] : nc_[1] - 1) / RB, (I[2] < nc_[2] ? I[2] : nc_[2] - 1) / RB};
+            for (int r = 0; r <= rmax && !done; ++r) {
+                const int lo[3] = {Bn[0] - r, a.ndim > 1 ? Bn[1] - r : 0, a.ndim > 2 ? Bn[2] - r : 0};
+                const int hi[3] = {Bn[0] + r, a.ndim > 1 ? Bn[1] + r : 0, a.ndim > 2 ? Bn[2] + r : 0};
+                for (int b2 = lo[2]; b2 <= hi[2]; ++b2)
+                    for (int b1 = lo[1]; b1 <= hi[1]; ++b1) {
+                        const bool edge12 = (a.ndim > 2 && (b2 == lo[2] || b2 == hi[2])) || (a.ndim > 1 && (b1 == lo[1] || b1 == hi[1]));
+                        for (int b0 = lo[0]; b0 <= hi[0]; b0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) {
+                            if (b0 < 0 || b0 >= nb_[0] || b1 < 0 || b1 >= nb_[1] || b2 < 0 || b2 >= nb_[2]) continue;
+                            const int B[3] = {b0, b1, b2};
+                            if (!blk[blk_lin(a, B)] || box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[0]) continue;
+                            for (int c2 = b2 * RB; c2 < (a.ndim > 2 ? (b2 + 1) * RB : 1); ++c2)
+                                for (int c1 = b1 * RB; c1 < (a.ndim > 1 ? (b1 + 1) * RB : 1); ++c1)
+                                    for (int c0 = b0 * RB; c0 < (b0 + 1) * RB; ++c0) scan_cell(c0, c1, c2);
                         }
                     }
-                }
-            if (bslot[0] >= 0 && sqrt(bd[0]) <= (double)s * hmin) break;
+                done = bslot[0] >= 0 && r >= 1 && sqrt(bd[0]) <= (double)(RB * r - 1) * hmin;
+            }
         }
         double cp[3] = {xq[0], xq[1], xq[2]};
         bool conv = false;
@@ -420,8 +493,9 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     long long* cand_cell = nullptr;
     unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
     double* pts = nullptr;
-    unsigned char* valid = nullptr;
-    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); };
+    unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
+    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
+                          (void)hipFree(blk); };
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
@@ -442,14 +516,21 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     RE_HIP(hipMalloc((void**)&pts, sizeof(double) * 3 * slots));
     RE_HIP(hipMalloc((void**)&valid, slots));
     RE_HIP(hipMemsetAsync(valid, 0, slots, stream));
+    size_t nblk = 1;
+    for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
+    RE_HIP(hipMalloc((void**)&cnt, (size_t)(ncand ? ncand : 1)));
+    RE_HIP(hipMalloc((void**)&blk, nblk));
+    RE_HIP(hipMemsetAsync(cnt, 0, (size_t)(ncand ? ncand : 1), stream));
+    RE_HIP(hipMemsetAsync(blk, 0, nblk, stream));
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
         hipLaunchKernelGGL(reinit_sample_kernel, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
+        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk);
     }
     const long long nodes = (long long)n[0] * n[1] * n[2];
     const unsigned gn = (unsigned)((nodes + 127) / 128 > 262144 ? 262144 : (nodes + 127) / 128);
-    hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, valid, out_field, counters + 1, counters + 2);
+    hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, cnt, blk, out_field, counters + 1, counters + 2);
     hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
                        out_field, phi);
     unsigned cn[4] = {0, 0, 0, 0};
