@@ -297,21 +297,43 @@ __device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const doub
 }
 
 // ---- 3. signed distance of every active node
+// band fields: the active nodes as a compact list, so that the closest-point kernel runs with full waves instead of
+// one lane in eight (one atomic per wave)
+__global__ void __launch_bounds__(256) reinit_nodes_kernel(ReinitArgs a, long long* list, unsigned* count) {
+    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
+    const long long span = (total + 255) / 256 * 256;      // whole waves reach the ballot
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < span; t += (long long)gridDim.x * blockDim.x) {
+        bool on = false;
+        if (t < total) {
+            const long long q = a.origin + (t % a.n[0]) + ((t / a.n[0]) % a.n[1]) * a.s1 + (t / ((long long)a.n[0] * a.n[1])) * a.s2;
+            on = a.mask[q] != 0;
+        }
+        const unsigned long long bal = __ballot(on);
+        if (!bal) continue;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(bal));
+        base = __shfl(base, leader, 64);
+        if (on && list) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;   // list == NULL: count only
+    }
+}
+
 constexpr int NSEED = 5;
 constexpr int FINE_SHELLS = 6;
 __global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
-                                                             const unsigned char* blk, void* out, unsigned* nfail, unsigned* nfar) {
-    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
+                                                             const unsigned char* blk, const long long* node_list, long long nlist,
+                                                             void* out, unsigned* nfail, unsigned* nfar) {
+    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
     const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};      // cells per dimension
     const int nb_[3] = {(nc_[0] + RB - 1) / RB, (nc_[1] + RB - 1) / RB, (nc_[2] + RB - 1) / RB};  // blocks per dimension
     int rmax = 1;
     for (int d = 0; d < a.ndim; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
-        if (a.mask && !a.mask[q]) continue;
         double xq[3] = {0, 0, 0};
         for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
         // the NSEED nearest samples, nearest first
@@ -494,8 +516,9 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
+    long long* node_list = nullptr;
     auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
-                          (void)hipFree(blk); };
+                          (void)hipFree(blk); (void)hipFree(node_list); };
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
@@ -529,8 +552,23 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
         hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk);
     }
     const long long nodes = (long long)n[0] * n[1] * n[2];
-    const unsigned gn = (unsigned)((nodes + 127) / 128 > 262144 ? 262144 : (nodes + 127) / 128);
-    hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, cnt, blk, out_field, counters + 1, counters + 2);
+    long long nwork = nodes;
+    if (mask) {
+        unsigned nact = 0;
+        const unsigned gl = (unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256);
+        hipLaunchKernelGGL(reinit_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, (long long*)nullptr, counters + 3);
+        RE_HIP(hipMemcpyAsync(&nact, counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RE_HIP(hipStreamSynchronize(stream));
+        RE_HIP(hipMalloc((void**)&node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
+        RE_HIP(hipMemsetAsync(counters + 3, 0, sizeof(unsigned), stream));
+        hipLaunchKernelGGL(reinit_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, node_list, counters + 3);
+        nwork = nact;
+    }
+    if (nwork) {
+        const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
+        hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, cnt, blk, node_list, nwork, out_field,
+                           counters + 1, counters + 2);
+    }
     hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
                        out_field, phi);
     unsigned cn[4] = {0, 0, 0, 0};
