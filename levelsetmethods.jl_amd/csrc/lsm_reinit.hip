@@ -320,9 +320,10 @@ __global__ void __launch_bounds__(256) reinit_nodes_kernel(ReinitArgs a, long lo
 
 constexpr int NSEED = 5;
 constexpr int FINE_SHELLS = 6;
-__global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
-                                                             const unsigned char* blk, const long long* node_list, long long nlist,
-                                                             void* out, unsigned* nfail, unsigned* nfar) {
+// (a) nearest samples of every active node -> seeds[NSEED * w .. ]   (latency-bound: keep it light on registers)
+__global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
+                                                            const unsigned char* blk, const long long* node_list, long long nlist,
+                                                            long long* seeds) {
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
@@ -372,9 +373,48 @@ __global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const
                 }
             }
         };
-        // near field: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then
-        // farther than s*hmin
         bool done = false;
+        // guided search: the first-order closest-point estimate x - ϕ∇ϕ/|∇ϕ|² (centred differences) lands next to the
+        // nearest samples when ϕ is anywhere near a distance function; the cells around it give a tight upper bound,
+        // and scanning every cell that meets the ball of that radius around the node then makes the result exact.
+        {
+            const double vq = ld_val(a.phi, q, a.f32);
+            double g[3] = {0, 0, 0}, g2 = 0.0;
+            for (int d = 0; d < a.ndim; ++d) {
+                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+                g[d] = (ld_val(a.phi, q + sd, a.f32) - ld_val(a.phi, q - sd, a.f32)) / (2.0 * a.h[d]);
+                g2 += g[d] * g[d];
+            }
+            if (g2 > 0.0 && g2 == g2 && vq == vq) {
+                double xe[3] = {0, 0, 0};
+                for (int d = 0; d < a.ndim; ++d) xe[d] = xq[d] - vq * g[d] / g2;
+                int E[3];
+                cell_of(a, xe, E);
+                for (int c2 = E[2] - (a.ndim > 2 ? 1 : 0); c2 <= E[2] + (a.ndim > 2 ? 1 : 0); ++c2)
+                    for (int c1 = E[1] - (a.ndim > 1 ? 1 : 0); c1 <= E[1] + (a.ndim > 1 ? 1 : 0); ++c1)
+                        for (int c0 = E[0] - 1; c0 <= E[0] + 1; ++c0) scan_cell(c0, c1, c2);
+            }
+            const double R0 = bslot[0] >= 0 ? sqrt(bd[0]) : __builtin_inf();
+            if (R0 <= 10.0 * hmin) {
+                // gap (in cells) between the node and cell c of dimension d
+                auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
+                const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
+                for (int c2 = I[2] - k2 - (a.ndim > 2 ? 1 : 0); c2 <= I[2] + k2; ++c2) {
+                    const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0;
+                    if (dz * dz > bd[0]) continue;
+                    for (int c1 = I[1] - k1 - (a.ndim > 1 ? 1 : 0); c1 <= I[1] + k1; ++c1) {
+                        const double dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
+                        const double rem = bd[0] - dz * dz - dy * dy;
+                        if (rem < 0.0) continue;
+                        const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
+                        for (int c0 = I[0] - k0 - 1; c0 <= I[0] + k0; ++c0) scan_cell(c0, c1, c2);
+                    }
+                }
+                done = true;
+            }
+        }
+        // otherwise: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then farther
+        // than s*hmin
         for (int s = 1; s <= FINE_SHELLS && !done; ++s) {
             const int lo[3] = {I[0] - s, a.ndim > 1 ? I[1] - s : 0, a.ndim > 2 ? I[2] - s : 0};
             const int hi[3] = {I[0] + s - 1, a.ndim > 1 ? I[1] + s - 1 : 0, a.ndim > 2 ? I[2] + s - 1 : 0};
@@ -407,6 +447,23 @@ __global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const
                 done = bslot[0] >= 0 && r >= 1 && sqrt(bd[0]) <= (double)(RB * r - 1) * hmin;
             }
         }
+        for (int k = 0; k < NSEED; ++k) seeds[NSEED * w + k] = bslot[k];
+    }
+}
+
+// (b) closest point from the seeds, signed distance
+__global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S, const double* pts, const long long* node_list, long long nlist,
+                                                            const long long* seeds, void* out, unsigned* nfail, unsigned* nfar) {
+    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    double hmax = a.h[0];
+    for (int d = 1; d < a.ndim; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long t = node_list ? node_list[w] : w;
+        const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
+        const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
+        double xq[3] = {0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
+        const long long* bslot = seeds + NSEED * w;
         double cp[3] = {xq[0], xq[1], xq[2]};
         bool conv = false;
         if (bslot[0] < 0) {
@@ -423,7 +480,6 @@ __global__ void __launch_bounds__(128) reinit_closest_kernel(ReinitArgs a, const
                 double d2 = 0.0;
                 for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
                 if (conv || d2 < bestd) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
-                if (k == 0 && !conv) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
             }
             cp[0] = bestcp[0]; cp[1] = bestcp[1]; cp[2] = bestcp[2];
             if (!conv) atomicAdd(nfail, 1u);
@@ -516,9 +572,9 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
-    long long* node_list = nullptr;
+    long long *node_list = nullptr, *seeds = nullptr;
     auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
-                          (void)hipFree(blk); (void)hipFree(node_list); };
+                          (void)hipFree(blk); (void)hipFree(node_list); (void)hipFree(seeds); };
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
@@ -565,9 +621,12 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
         nwork = nact;
     }
     if (nwork) {
+        RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
+        const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
+        hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
-        hipLaunchKernelGGL(reinit_closest_kernel, dim3(gn), dim3(128), 0, stream, a, cand_id, S, pts, cnt, blk, node_list, nwork, out_field,
-                           counters + 1, counters + 2);
+        hipLaunchKernelGGL(reinit_newton_kernel, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1,
+                           counters + 2);
     }
     hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
                        out_field, phi);
