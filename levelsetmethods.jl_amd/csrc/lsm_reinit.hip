@@ -205,8 +205,13 @@ __device__ __forceinline__ long long blk_lin(const ReinitArgs& a, const int B[3]
     const long long b0 = (a.n[0] - 1 + RB - 1) / RB, b1 = a.ndim > 1 ? (a.n[1] - 1 + RB - 1) / RB : 1;
     return B[0] + b0 * (B[1] + b1 * B[2]);
 }
+__device__ __forceinline__ long long bits_row(const ReinitArgs& a, int c1, int c2) {   // first word of the cell row (c1, c2)
+    const long long wpr = (a.n[0] - 1 + 63) / 64, c1n = a.ndim > 1 ? a.n[1] - 1 : 1;
+    return wpr * (c1 + c1n * (long long)c2);
+}
 __global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
-                                                             const unsigned char* valid, unsigned char* cnt, unsigned char* blk) {
+                                                             const unsigned char* valid, unsigned char* cnt, unsigned char* blk,
+                                                             unsigned long long* bits) {
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
         int m = 0;
         for (int k = 0; k < S; ++k) {
@@ -224,6 +229,7 @@ __global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const
             cell_unlin(a, cand_cell[id], I);
             const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
             blk[blk_lin(a, B)] = 1;
+            atomicOr(bits + bits_row(a, I[1], I[2]) + I[0] / 64, 1ull << (I[0] & 63));     // one bit per cell with samples
         }
     }
 }
@@ -322,8 +328,8 @@ constexpr int NSEED = 5;
 constexpr int FINE_SHELLS = 6;
 // (a) nearest samples of every active node -> seeds[NSEED * w .. ]   (latency-bound: keep it light on registers)
 __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
-                                                            const unsigned char* blk, const long long* node_list, long long nlist,
-                                                            long long* seeds) {
+                                                            const unsigned char* blk, const unsigned long long* bits,
+                                                            const long long* node_list, long long nlist, long long* seeds) {
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
@@ -373,6 +379,23 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                 }
             }
         };
+        // the cells c0 in [lo, hi] of row (c1, c2) that hold samples, straight from the occupancy bits (one or two word
+        // loads instead of a probe per cell)
+        auto scan_row = [&](int lo, int hi, int c1, int c2) {
+            if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) return;
+            lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
+            const long long row = bits_row(a, c1, c2);
+            for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
+                unsigned long long m = bits[row + w0];
+                if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
+                if (w0 == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    scan_cell(w0 * 64 + b, c1, c2);
+                }
+            }
+        };
         bool done = false;
         // guided search: the first-order closest-point estimate x - ϕ∇ϕ/|∇ϕ|² (centred differences) lands next to the
         // nearest samples when ϕ is anywhere near a distance function; the cells around it give a tight upper bound,
@@ -392,7 +415,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                 cell_of(a, xe, E);
                 for (int c2 = E[2] - (a.ndim > 2 ? 1 : 0); c2 <= E[2] + (a.ndim > 2 ? 1 : 0); ++c2)
                     for (int c1 = E[1] - (a.ndim > 1 ? 1 : 0); c1 <= E[1] + (a.ndim > 1 ? 1 : 0); ++c1)
-                        for (int c0 = E[0] - 1; c0 <= E[0] + 1; ++c0) scan_cell(c0, c1, c2);
+                        scan_row(E[0] - 1, E[0] + 1, c1, c2);
             }
             const double R0 = bslot[0] >= 0 ? sqrt(bd[0]) : __builtin_inf();
             if (R0 <= 10.0 * hmin) {
@@ -407,7 +430,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                         const double rem = bd[0] - dz * dz - dy * dy;
                         if (rem < 0.0) continue;
                         const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
-                        for (int c0 = I[0] - k0 - 1; c0 <= I[0] + k0; ++c0) scan_cell(c0, c1, c2);
+                        scan_row(I[0] - k0 - 1, I[0] + k0, c1, c2);
                     }
                 }
                 done = true;
@@ -441,7 +464,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                             if (!blk[blk_lin(a, B)] || box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[0]) continue;
                             for (int c2 = b2 * RB; c2 < (a.ndim > 2 ? (b2 + 1) * RB : 1); ++c2)
                                 for (int c1 = b1 * RB; c1 < (a.ndim > 1 ? (b1 + 1) * RB : 1); ++c1)
-                                    for (int c0 = b0 * RB; c0 < (b0 + 1) * RB; ++c0) scan_cell(c0, c1, c2);
+                                    scan_row(b0 * RB, (b0 + 1) * RB - 1, c1, c2);
                         }
                     }
                 done = bslot[0] >= 0 && r >= 1 && sqrt(bd[0]) <= (double)(RB * r - 1) * hmin;
@@ -573,8 +596,9 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
     long long *node_list = nullptr, *seeds = nullptr;
+    unsigned long long* bits = nullptr;
     auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
-                          (void)hipFree(blk); (void)hipFree(node_list); (void)hipFree(seeds); };
+                          (void)hipFree(blk); (void)hipFree(node_list); (void)hipFree(seeds); (void)hipFree(bits); };
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
@@ -601,11 +625,15 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     RE_HIP(hipMalloc((void**)&blk, nblk));
     RE_HIP(hipMemsetAsync(cnt, 0, (size_t)(ncand ? ncand : 1), stream));
     RE_HIP(hipMemsetAsync(blk, 0, nblk, stream));
+    size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
+    for (int d = 1; d < ndim; ++d) nwords *= (size_t)(n[d] - 1);
+    RE_HIP(hipMalloc((void**)&bits, sizeof(unsigned long long) * nwords));
+    RE_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long) * nwords, stream));
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
         hipLaunchKernelGGL(reinit_sample_kernel, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
-        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk);
+        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk, bits);
     }
     const long long nodes = (long long)n[0] * n[1] * n[2];
     long long nwork = nodes;
@@ -623,7 +651,7 @@ int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long o
     if (nwork) {
         RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
-        hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, node_list, nwork, seeds);
+        hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         hipLaunchKernelGGL(reinit_newton_kernel, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1,
                            counters + 2);
