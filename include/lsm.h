@@ -255,6 +255,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
                     void* halo_mask, void* tiles, int mc, void* halo_list, int64_t halo_cap, void* halo_count);
 int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc,
                   void* halo_list, int64_t halo_cap, void* halo_count);
+int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc);   /* tile flags + lists of a mask changed from outside */
 int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,
                        const void* halo_count);
 int lsm_band_prepare(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,

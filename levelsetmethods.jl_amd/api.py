@@ -671,6 +671,8 @@ def _eps(x):
 # ----------------------------------------------------------------------------- levelsetequation.jl
 
 class LevelSetEquation:
+    BAND_OVERLAP = 10   # planes of each neighbour a slab of a band keeps: nearest-band-node radius 6 + slope 1 + stencil 3
+
     """LevelSetEquation(; terms, integrator = RK2(), ic, bc = nothing, t = 0) — src/levelsetequation.jl:59-78.
 
     Extra keywords of this implementation: mode ('fast' | 'strict' arithmetic), device, and
@@ -711,6 +713,20 @@ class LevelSetEquation:
             lo = sum(counts[:self.rank])
             self.slab = (lo, counts[self.rank])
             self.counts = counts
+            self.own = (0, counts[self.rank])      # local plane range of the planes this rank owns
+            if isinstance(ic, NarrowBandMeshField) and self.world > 1:
+                # a band needs its neighbours' mask AND values up to 7 planes deep (nearest band node within 6, its
+                # slope neighbour) plus the stencil reach: every rank keeps BAND_OVERLAP planes of its neighbours as
+                # ordinary planes of its own (extended) slab, computes everything on them redundantly — results are
+                # right at least BAND_OVERLAP planes away from the cut faces, i.e. on the owned planes — and refreshes
+                # them from their owners after every stage and every band update.
+                W = self.BAND_OVERLAP
+                if min(counts) < W or ic.nlayers + 1 > W:
+                    raise ValueError(f"a slab-decomposed band needs at least {W} planes per rank and nlayers < {W}")
+                wlo = W if self.rank > 0 else 0
+                whi = W if self.rank < self.world - 1 else 0
+                self.own = (wlo, counts[self.rank])
+                self.slab = (lo - wlo, counts[self.rank] + wlo + whi)
             periodic = bcs[N - 1][0].kind == L.BC_PERIODIC
             slab_faces = (self.rank > 0 or (periodic and self.world > 1), self.rank < self.world - 1 or (periodic and self.world > 1))
             self.periodic_last = periodic
@@ -731,11 +747,12 @@ class LevelSetEquation:
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
         self.band = isinstance(ic, NarrowBandMeshField)
         if self.band:
-            if comm is not None:
-                raise ValueError("a NarrowBandMeshField cannot be slab-decomposed yet (single device only)")
             self.state = ROCNarrowBandMeshField(self.backend, grid, bcs, ic.nlayers)
-            self.backend.upload(self.state.buf, ic.vals)
+            v = ic.vals
+            self.backend.upload(self.state.buf, v if self.slab is None else v[..., self.slab[0]:self.slab[0] + self.slab[1]])
             self.state.rebuild(from_dense=True)   # NarrowBandMeshField(ϕ; nlayers): seed every node, then update_band!
+            if self.comm is not None and self.world > 1:
+                self._band_sync_after_update()
         else:
             self.state = ROCMeshField(self.backend, grid, bcs)
         if self.band:
@@ -875,6 +892,8 @@ class LevelSetEquation:
         sb = lambda psi, phin, out, out2, mode, c1, c2, t: b.stage_band(T(), n, psi, phin, out, out2, mode, c1, c2, t,
                                                                       st.mask, st.tiles, st.MC)
         fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)
+        slabbed = self.comm is not None and self.world > 1
+        sync = (lambda buf: self._overlap_refresh(buf)) if slabbed else (lambda buf: None)   # stencil inputs: owners' values
         st.prepare(phi)
         self._update_terms(st, tc)
         if name == "fe":
@@ -883,23 +902,62 @@ class LevelSetEquation:
             b.copy_(phi, b1)
         elif name == "rk2":
             sb(phi, None, b1, b2, L.BASE_PSI, dt, 0.5 * dt, tc)
+            sync(b1)
             st.prepare(b1)
             self._update_terms(fld(b1), tc + dt)
             sb(b1, b2, phi, None, L.BASE_OTHER, 0.5 * dt, 0.0, tc + dt)
         else:
             sb(phi, None, b1, None, L.BASE_PSI, dt, 0.0, tc)
+            sync(b1)
             st.prepare(b1)
             self._update_terms(fld(b1), tc + dt)
             sb(b1, phi, b2, None, L.BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt)
+            sync(b2)
             st.prepare(b2)
             self._update_terms(fld(b2), tc + 0.5 * dt)
             sb(b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
+        sync(phi)
         st.ghosts_dirty = True
 
     def update_band(self):
         """update_band!(ϕ) after an accepted step (src/timestepping.jl:115): no-op on a dense field."""
         if self.band:
             self.state.rebuild(from_dense=False)
+            if self.comm is not None and self.world > 1:
+                self._band_sync_after_update()
+
+    def _band_sync_after_update(self):
+        """Slab of a band: the band set and the values of newly active nodes are only right away from the cut faces;
+        take both from the owners on the overlap planes, then re-derive tiles, lists and the halo from the full mask."""
+        st = self.state
+        self._overlap_refresh(st.mask)
+        self._overlap_refresh(st.buf)
+        st.backend.band_retile(st.mask, st.tiles, st.MC)
+        st.backend.band_status(st._hcount)
+        st.backend.band_halo(st.buf, st.mask, st.halo, st.tiles, st.MC, st._hlist, st._hcount)
+        st._check_halo()
+
+    def _overlap_refresh(self, buf):
+        """Overwrite the overlap planes of `buf` (values or mask) with the owners' planes (RCCL point-to-point)."""
+        import torch.distributed as dist
+        b = self.backend
+        N = self.mesh_.ndim
+        G, W = L.GHOST, self.BAND_OVERLAP
+        sl = int(b.lay.stride[N - 1])
+        wlo, own_n = self.own
+        plane = lambda k0, k1: buf[(k0 + G) * sl:(k1 + G) * sl]
+        up = self.rank + 1 if self.rank < self.world - 1 else None
+        dn = self.rank - 1 if self.rank > 0 else None
+        ops = []
+        if up is not None:
+            ops.append(dist.P2POp(dist.isend, plane(wlo + own_n - W, wlo + own_n), up, group=self.comm))
+        if dn is not None:
+            ops.append(dist.P2POp(dist.irecv, plane(0, W), dn, group=self.comm))
+            ops.append(dist.P2POp(dist.isend, plane(wlo, wlo + W), dn, group=self.comm))
+        if up is not None:
+            ops.append(dist.P2POp(dist.irecv, plane(wlo + own_n, wlo + own_n + W), up, group=self.comm))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
 
     def _stage_slab(self, arr, n, psi, phin, out, out2, mode, cdt, cdt2, t):
         """One stage of a slab followed by its ghost resolution.  With overlap, the G+1 planes next to
@@ -971,6 +1029,7 @@ class LevelSetEquation:
         v = self.state.values()
         if self.comm is None or self.world == 1:
             return v
+        v = v[..., self.own[0]:self.own[0] + self.own[1]]       # a band slab also holds copies of its neighbours' planes
         import torch
         import torch.distributed as dist
         N = self.mesh_.ndim

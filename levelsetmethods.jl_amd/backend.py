@@ -182,6 +182,9 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_band_halo(self.h, self.ptr(vals), self.ptr(mask), self.ptr(halo), self.ptr(tiles), int(mc),
                                                self.ptr(hlist), hlist.numel() // 2, self.ptr(hcount)), "lsm_band_halo")
 
+    def band_retile(self, mask, tiles, mc):
+        L.check(self.h, self.lib.lsm_band_retile(self.h, self.ptr(mask), self.ptr(tiles), int(mc)), "lsm_band_retile")
+
     def band_fill_list(self, vals, mask, hlist, hcount):
         L.check(self.h, self.lib.lsm_band_fill_list(self.h, self.ptr(vals), self.ptr(mask), self.ptr(hlist), hlist.numel() // 2,
                                                     self.ptr(hcount)), "lsm_band_fill_list")

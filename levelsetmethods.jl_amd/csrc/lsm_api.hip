@@ -914,6 +914,22 @@ int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_m
     return band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, nullptr, -1);
 }
 
+// tiles := per-tile activity flags of `mask`, and the compact tile lists of it — after the mask was changed from
+// outside (a slab that received its overlap planes from the neighbouring ranks); follow with lsm_band_status and
+// lsm_band_halo
+int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
+    if (!h || !mask || !tiles || mc < 1) return LSM_ERR_INVALID;
+    LSM_TRY(ensure_ring(h));
+    BandArgs a = band_args(h, mc, nullptr);
+    LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
+    launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
+    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+    launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+    h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
 // ϕ[I] for the non-band nodes flagged in `targets`: _extrapolate_to_ghost materialised
 // (src/meshfield.jl:481-511) by a fresh nearest-node search over the whole grid (scalar getindex path).
 int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* targets, const void* tiles, int mc) {

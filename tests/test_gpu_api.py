@@ -316,3 +316,48 @@ def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkey
     full = np.concatenate(got, axis=2)
     assert full.shape == want.shape
     assert np.array_equal(full, want), np.abs(full - want).max()
+
+
+@pytest.mark.parametrize("world,integ", [(2, "rk3"), (3, "rk2"), (3, "fe")])
+def test_slab_decomposed_narrow_band_matches_single_device(lsm, monkeypatch, world, integ):
+    """BASELINE config 5's decomposition: a narrow band cut into slabs.  Each rank carries BAND_OVERLAP planes of its
+    neighbours and refreshes them after every stage and band update; on the planes a rank owns, the band set and
+    the values must equal the single-device band run bit for bit (ranks = threads over the in-process group)."""
+    import threading
+    _patch_dist(monkeypatch)
+    n = (28, 24, 66)
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), n)
+    phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.05) ** 2 + x[1] ** 2 + (x[2] + 0.02) ** 2) - 0.62, grid)
+    I = {"rk3": lsm.RK3, "rk2": lsm.RK2, "fe": lsm.ForwardEuler}[integ]
+    mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02)),
+                                           ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2), integrator=I(), **kw)
+    ref = mk()
+    lsm.integrate_(ref, 0.04)
+    st = ref.current_state()
+    want_m, want_v = st.active_mask(), st.values()
+    assert want_m[:, :, 20:46].any() and 2000 < want_m.sum()       # the band crosses every slab interface
+    w = _FakeWorld(world)
+    got, errs = [None] * world, []
+
+    def run(r):
+        try:
+            eq = mk(comm=_FakeRank(w, r))
+            lsm.integrate_(eq, 0.04)
+            o0, on = eq.own
+            s = eq.current_state()
+            got[r] = (s.active_mask()[..., o0:o0 + on], s.values()[..., o0:o0 + on])
+        except BaseException as e:   # noqa: BLE001 - reported by the main thread
+            import traceback
+            errs.append((r, traceback.format_exc()))
+            w.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    m = np.concatenate([g[0] for g in got], axis=2)
+    v = np.concatenate([g[1] for g in got], axis=2)
+    assert np.array_equal(m, want_m)
+    assert np.array_equal(v[m], want_v[m])
