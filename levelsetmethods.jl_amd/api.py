@@ -1070,14 +1070,22 @@ def _sum_over_ranks(ls, x):
     return float(t.item())
 
 
+def _dense_only(ls, what):
+    # the reference sums over every node through getindex, which throws away from the band (src/meshfield.jl:499-500)
+    if getattr(ls, "band", False):
+        raise ValueError(f"{what} needs values on the whole grid: not defined for a NarrowBandMeshField state")
+
+
 def volume(ls):
     """volume(eq) — measure of {ϕ ≤ 0} with the smoothed Heaviside (src/levelsetops.jl:27-33,
     src/levelsetequation.jl:165); the standard posthook diagnostic (docs/src/levelset-equation.md:142-149)."""
+    _dense_only(ls, "volume")
     return _sum_over_ranks(ls, ls.backend.volume_local(ls.state.buf))
 
 
 def perimeter(ls):
     """perimeter(eq) — measure of {ϕ = 0} with the smoothed Dirac delta (src/levelsetops.jl:139-149)."""
+    _dense_only(ls, "perimeter")
     if ls.comm is not None and ls.world > 1:
         ls._halo(ls.state.buf)          # slab interfaces: the centred gradient needs the neighbours' planes
     return _sum_over_ranks(ls, ls.backend.perimeter_local(ls.state.buf))
