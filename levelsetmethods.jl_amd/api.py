@@ -930,34 +930,72 @@ class LevelSetEquation:
         """Slab of a band: the band set and the values of newly active nodes are only right away from the cut faces;
         take both from the owners on the overlap planes, then re-derive tiles, lists and the halo from the full mask."""
         st = self.state
-        self._overlap_refresh(st.mask)
+        self._sparse = None
+        self._overlap_refresh(st.mask)                 # full planes of mask bytes
+        self._sparse = self._overlap_indices(st.mask)  # from here on only the band nodes of those planes travel
         self._overlap_refresh(st.buf)
         st.backend.band_retile(st.mask, st.tiles, st.MC)
         st.backend.band_status(st._hcount)
         st.backend.band_halo(st.buf, st.mask, st.halo, st.tiles, st.MC, st._hlist, st._hcount)
         st._check_halo()
 
-    def _overlap_refresh(self, buf):
-        """Overwrite the overlap planes of `buf` (values or mask) with the owners' planes (RCCL point-to-point)."""
-        import torch.distributed as dist
-        b = self.backend
-        N = self.mesh_.ndim
-        G, W = L.GHOST, self.BAND_OVERLAP
-        sl = int(b.lay.stride[N - 1])
+    def _overlap_ranges(self):
+        """(neighbour, planes I send, planes I receive) per direction, local plane indices"""
+        W = self.BAND_OVERLAP
         wlo, own_n = self.own
-        plane = lambda k0, k1: buf[(k0 + G) * sl:(k1 + G) * sl]
-        up = self.rank + 1 if self.rank < self.world - 1 else None
-        dn = self.rank - 1 if self.rank > 0 else None
-        ops = []
-        if up is not None:
-            ops.append(dist.P2POp(dist.isend, plane(wlo + own_n - W, wlo + own_n), up, group=self.comm))
-        if dn is not None:
-            ops.append(dist.P2POp(dist.irecv, plane(0, W), dn, group=self.comm))
-            ops.append(dist.P2POp(dist.isend, plane(wlo, wlo + W), dn, group=self.comm))
-        if up is not None:
-            ops.append(dist.P2POp(dist.irecv, plane(wlo + own_n, wlo + own_n + W), up, group=self.comm))
+        out = []
+        if self.rank < self.world - 1:
+            out.append((self.rank + 1, (wlo + own_n - W, wlo + own_n), (wlo + own_n, wlo + own_n + W)))
+        if self.rank > 0:
+            out.append((self.rank - 1, (wlo, wlo + W), (0, W)))
+        return out
+
+    def _plane_view(self, buf, k0, k1):
+        N = self.mesh_.ndim
+        sl = int(self.backend.lay.stride[N - 1])
+        return buf[(k0 + L.GHOST) * sl:(k1 + L.GHOST) * sl]
+
+    def _overlap_indices(self, mask):
+        """Positions of the band nodes inside the exchanged plane ranges.  Sender and receiver hold the same mask on
+        those planes, so both enumerate the same nodes in the same (index) order: no index needs to travel."""
+        import torch
+        idx = {}
+        for peer, snd, rcv in self._overlap_ranges():
+            idx[peer] = (torch.nonzero(self._plane_view(mask, *snd)).flatten(), torch.nonzero(self._plane_view(mask, *rcv)).flatten())
+        return idx
+
+    def _overlap_refresh(self, buf):
+        """Overwrite the overlap planes of `buf` with the owners' data (RCCL point-to-point): whole planes for the
+        mask, only the band nodes' values otherwise."""
+        import torch
+        import torch.distributed as dist
+        sparse = self._sparse if buf.dtype != torch.uint8 else None
+        ops, post = [], []
+        # op order [send up, recv dn, send dn, recv up]: messages between a pair of ranks match in posting order
+        rng = {peer: (snd, rcv) for peer, snd, rcv in self._overlap_ranges()}
+        up, dn = self.rank + 1, self.rank - 1
+        for peer, what in ((up, "send"), (dn, "recv"), (dn, "send"), (up, "recv")):
+            if peer not in rng:
+                continue
+            snd, rcv = rng[peer]
+            if sparse is None:
+                t = self._plane_view(buf, *(snd if what == "send" else rcv))
+            else:
+                si, ri = sparse[peer]
+                if what == "send":
+                    if si.numel() == 0:
+                        continue
+                    t = self._plane_view(buf, *snd).index_select(0, si)
+                else:
+                    if ri.numel() == 0:
+                        continue
+                    t = torch.empty(ri.numel(), dtype=buf.dtype, device=buf.device)
+                    post.append((self._plane_view(buf, *rcv), ri, t))
+            ops.append(dist.P2POp(dist.isend if what == "send" else dist.irecv, t, peer, group=self.comm))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
+        for view, ri, t in post:
+            view.index_copy_(0, ri, t)
 
     def _stage_slab(self, arr, n, psi, phin, out, out2, mode, cdt, cdt2, t):
         """One stage of a slab followed by its ghost resolution.  With overlap, the G+1 planes next to
