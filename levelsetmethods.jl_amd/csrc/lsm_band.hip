@@ -553,6 +553,17 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
     const int bx = a.tx + 2 * RL, by = a.ty + 2 * RL, bm = a.tm + 2 * RL, nrows = by * bm;
     extern __shared__ u64 w3[];
     u64 *B = w3, *T = w3 + nrows;            // T: halo words of the tile rows (ty × tm)
+    // xkey[pattern]: (o_x² << 9) | (o_x + RL) of the set bit nearest to the centre of a 7-bit line pattern, the lower x
+    // winning ties; an empty pattern gets a key no real candidate can reach
+    unsigned* xkey = reinterpret_cast<unsigned*>(T + a.ty * a.tm);
+    for (int p = threadIdx.x; p < 128; p += blockDim.x) {
+        unsigned k = 1u << 20;
+        for (int d = RL; d >= 0; --d) {          // farthest first, so the nearest (and on ties the lower x) is written last
+            if (p & (1 << (RL + d))) k = ((unsigned)(d * d) << 9) | (unsigned)(RL + d);
+            if (p & (1 << (RL - d))) k = ((unsigned)(d * d) << 9) | (unsigned)(RL - d);
+        }
+        xkey[p] = k;
+    }
     u64* const outs[1] = {B};
     stage_rows<GK, 1>(a, RL, bx, by, bm, x0, y0, m0, outs, nullptr, [&](long long q, bool ok, u64) -> unsigned {
         const unsigned f = src_mask[q];
@@ -605,16 +616,14 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
                 // _nearest_band_node inside the (2·RL+1)^3 cube: the first ring hit is the set bit with the smallest
                 // (|off|², o_z, o_y, o_x) — the ring is the column-major offset list stably sorted by |off|².
                 // Per x-line: the nearest set bit to lx, the lower x winning ties.
+                // (the per-line part of the key comes from a 128-entry table over the 7-bit pattern around lx)
                 unsigned best = 0xffffffffu;
+#pragma unroll
                 for (int dm = -RL; dm <= RL; ++dm)
+#pragma unroll
                     for (int dy = -RL; dy <= RL; ++dy) {
                         const unsigned pat = (unsigned)(B[r + dy + dm * by] >> (lx - RL)) & 0x7fu;   // bit j <-> o_x = j - RL
-                        if (!pat) continue;
-                        const unsigned lo = pat & 0xfu, hi = pat >> 4;                                // o_x <= 0 | o_x >= 1
-                        const int kl = lo ? RL - (31 - __clz((int)lo)) : 99;                         // distance of the nearest o_x <= 0
-                        const int kr = hi ? __ffs((int)hi) : 99;                                      // distance of the nearest o_x >= 1
-                        const int ox = kl <= kr ? -kl : kr;
-                        const unsigned key = ((unsigned)(ox * ox + dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7 + (ox + RL));
+                        const unsigned key = xkey[pat] + (((unsigned)(dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7));
                         best = key < best ? key : best;
                     }
                 bool found = false;
@@ -858,7 +867,7 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s) {
     if (fast3(a, RL, 1)) {
-        const size_t lds = (size_t)8 * ((a.ty + 2 * RL) * (a.tm + 2 * RL) + a.ty * a.tm);
+        const size_t lds = (size_t)8 * ((a.ty + 2 * RL) * (a.tm + 2 * RL) + a.ty * a.tm) + 128 * sizeof(unsigned);
         if (no_tiles(a)) return;
         hipLaunchKernelGGL(band_search3_kernel<8>, tile_grid(a), dim3(256), lds, s, a, target, halo, src_mask, ring, nring, nring_lds, src,
                            dst, miss, list, list_count, list_cap);
