@@ -671,7 +671,7 @@ def _eps(x):
 # ----------------------------------------------------------------------------- levelsetequation.jl
 
 class LevelSetEquation:
-    BAND_OVERLAP = 10   # planes of each neighbour a slab of a band keeps: nearest-band-node radius 6 + slope 1 + stencil 3
+    BAND_OVERLAP = 10   # least number of planes of each neighbour a slab of a band keeps: nearest-band-node radius 6 + slope 1 + stencil 3
 
     """LevelSetEquation(; terms, integrator = RK2(), ic, bc = nothing, t = 0) — src/levelsetequation.jl:59-78.
 
@@ -720,7 +720,11 @@ class LevelSetEquation:
                 # ordinary planes of its own (extended) slab, computes everything on them redundantly — results are
                 # right at least BAND_OVERLAP planes away from the cut faces, i.e. on the owned planes — and refreshes
                 # them from their owners after every stage and every band update.
-                W = self.BAND_OVERLAP
+                # reinitialize! measures physical distances: a band node lies up to (nlayers + 2)·max(h) from the interface,
+                # and the ball it searches for nearer samples must stay clear of the cut faces (2 planes of wrong patches)
+                hs = grid.meshsize()
+                W = max(self.BAND_OVERLAP, int(math.ceil((ic.nlayers + 2) * max(hs) / hs[N - 1])) + 3)
+                self.BAND_OVERLAP = W
                 if min(counts) < W or ic.nlayers + 1 > W:
                     raise ValueError(f"a slab-decomposed band needs at least {W} planes per rank and nlayers < {W}")
                 wlo = W if self.rank > 0 else 0
@@ -1168,8 +1172,9 @@ def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
     `phi` is a device field (or an equation: its current state).  Returns ϕ; warns, like the reference, when
     the closest-point solver did not converge at some nodes."""
     import warnings
-    if isinstance(phi, LevelSetEquation):
-        phi = phi.current_state()
+    eq = phi if isinstance(phi, LevelSetEquation) else None
+    if eq is not None:
+        phi = eq.current_state()
     if not isinstance(phi, ROCMeshField):
         raise TypeError("reinitialize_ expects a device field (ROCMeshField / ROCNarrowBandMeshField) or a LevelSetEquation")
     if phi.bcs is None:
@@ -1185,6 +1190,11 @@ def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
         b.fill_ghosts(phi.buf, 7)
     ncand, nfail, nfar = b.reinitialize(phi.buf, phi.mask if band else None, order, upsample, maxiters, xtol, ftol)
     phi.ghosts_dirty = True
+    if eq is not None and eq.comm is not None and eq.world > 1:
+        if not band:
+            raise ValueError("reinitialize! of a slab-decomposed dense field is not supported")
+        eq._overlap_refresh(phi.buf)     # the neighbours' planes: their owners' values
+        nfail = nfar = 0                 # counted on the extended slab, cut faces included: not meaningful per rank
     if nfar:
         warnings.warn(f"reinitialize!: no interface sample was found ({nfar} nodes left unchanged)")
     if nfail:

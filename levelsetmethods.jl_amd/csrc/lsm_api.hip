@@ -1044,13 +1044,15 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
     if (upsample < 1 || upsample > 16) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: upsample must be in 1..16");
     if (maxiters < 1) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: maxiters must be positive");
     if (!(xtol > 0) || !(ftol > 0)) return fail(h, LSM_ERR_INVALID, "lsm_reinitialize: tolerances must be positive");
-    LSM_TRY(check_single_device(h));
+    // a slab is fine for a band whose slab carries its neighbours' planes (every node's samples and patches lie
+    // within the band's reach; the caller refreshes the overlap planes afterwards); a dense slab is not
+    if (!mask) LSM_TRY(check_single_device(h));
     const int N = h->grid.ndim;
     double lc[3] = {0, 0, 0};
     for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
     long long counts[3] = {0, 0, 0};
     const char* err = nullptr;
-    const int r = reinit_run(N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, lc, h->h, order, upsample, maxiters, xtol, ftol,
+    const int r = reinit_run(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, lc, h->h, order, upsample, maxiters, xtol, ftol,
                              phi, is_f32(h), (const unsigned char*)mask, work, h->stream, counts, &err);
     if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_reinitialize");
     if (r) return fail(h, LSM_ERR_HIP, err ? err : "lsm_reinitialize");

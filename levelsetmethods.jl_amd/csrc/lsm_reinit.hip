@@ -26,7 +26,8 @@ namespace lsm {
 
 struct ReinitArgs {
     int ndim;
-    int n[3];              // nodes (local = global: single device)
+    int n[3];              // nodes of the local slab
+    int goff[3];           // global index of local node 0 (coordinates are lc + (I + goff)·h, as on a single device)
     long long s1, s2, origin;
     double lc[3], h[3];
     int order, nv, off;    // polynomial degree, stencil size, stencil offset of the cell's lower corner
@@ -75,7 +76,7 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
     Card c[3];
     for (int d = 0; d < 3; ++d) {
         if (d < a.ndim) {
-            const double t = (x[d] - (a.lc[d] + (double)I[d] * a.h[d])) / a.h[d];
+            const double t = (x[d] - (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d])) / a.h[d];
             cardinal(a, t, 1.0 / a.h[d], second, c[d]);
         } else {
             c[d].L[0] = 1.0; c[d].dL[0] = 0.0; c[d].d2L[0] = 0.0;
@@ -108,7 +109,7 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
 __device__ __forceinline__ void cell_of(const ReinitArgs& a, const double x[3], int I[3]) {
     for (int d = 0; d < 3; ++d) {
         if (d >= a.ndim) { I[d] = 0; continue; }
-        int i = (int)floor((x[d] - a.lc[d]) / a.h[d]);
+        int i = (int)floor((x[d] - a.lc[d]) / a.h[d]) - a.goff[d];
         I[d] = i < 0 ? 0 : (i > a.n[d] - 2 ? a.n[d] - 2 : i);
     }
 }
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const 
         cell_unlin(a, cand_cell[id], I);
         const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
         double x0[3] = {0, 0, 0}, x[3];
-        for (int d = 0; d < a.ndim; ++d) x0[d] = (a.lc[d] + (double)I[d] * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
+        for (int d = 0; d < a.ndim; ++d) x0[d] = (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
         x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2];
         bool conv = false;
         for (int it = 0; it < a.maxiters; ++it) {      // _project_to_interface (src/sdf.jl:223-236)
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
         double xq[3] = {0, 0, 0};
-        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
+        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
         // the NSEED nearest samples, nearest first
         double bd[NSEED];
         long long bslot[NSEED];
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S,
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
         double xq[3] = {0, 0, 0};
-        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)I[d] * a.h[d];
+        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
         const long long* bslot = seeds + NSEED * w;
         double cp[3] = {xq[0], xq[1], xq[2]};
         bool conv = false;
@@ -574,12 +575,12 @@ static bool interp_matrix(int order, int ndim, double M[36], int* nv_out, double
 }
 
 // returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
-int reinit_run(int ndim, const int n[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
+int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
                int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask, void* out_field,
                hipStream_t stream, long long out_counts[3], const char** err) {
     ReinitArgs a;
     a.ndim = ndim;
-    for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
+    for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.goff[d] = goff[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
     a.s1 = s1; a.s2 = s2; a.origin = origin;
     a.order = order; a.upsample = upsample; a.maxiters = maxiters; a.xtol = xtol; a.ftol = ftol;
     a.phi = phi; a.f32 = f32; a.mask = mask;
