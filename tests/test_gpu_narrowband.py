@@ -379,3 +379,22 @@ def test_reference_band_spiral_curvature_flow_with_reinitialize(lsm):
         lsm.integrate_(full, 0.1, prehook=_reinit(lsm))
         lsm.integrate_(nb, 0.1, posthook=_reinit(lsm))
     assert _nb_full_error(nb.current_state(), full.current_state().values(), 3, min(grid.meshsize())) < 0.05
+
+
+def test_field_without_interface(lsm):
+    """No cut cell: the band is empty, stepping and reinitialize! are no-ops; a dense field keeps its values and warns."""
+    import warnings
+    for n in ((30, 26), (20, 18, 16)):
+        grid = lsm.CartesianGrid((-1.0,) * len(n), (1.0,) * len(n), n)
+        phi = lsm.MeshField(lambda x: 1.0 + 0 * x[0], grid)
+        eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0,) * len(n)),), ic=lsm.NarrowBandMeshField(phi), bc=lsm.ExtrapolationBC(2))
+        assert eq.current_state().active_count() == 0
+        lsm.integrate_(eq, 0.05)
+        lsm.reinitialize_(eq)
+        assert eq.current_time() == 0.05 and eq.current_state().active_count() == 0
+        dense = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0,) * len(n)),), ic=phi, bc=lsm.ExtrapolationBC(2))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            lsm.reinitialize_(dense)
+        assert any("no interface sample" in str(x.message) for x in w)
+        assert np.array_equal(dense.current_state().values(), phi.vals)
