@@ -327,10 +327,139 @@ __global__ void __launch_bounds__(256) reinit_nodes_kernel(ReinitArgs a, long lo
 
 constexpr int NSEED = 5;
 constexpr int FINE_SHELLS = 6;
+// (a0) the guided search, GRP lanes per node.  One lane per node spends milliseconds on its chain of dependent loads
+// (row word -> cell id -> sample count -> samples); sixteen lanes share the rows of the ball, keep one best each and
+// merge with shuffles.  Nodes the guided search cannot settle (no usable estimate, ball wider than 10 cells) are
+// flagged for the one-lane-per-node kernel below (seeds[0] = -2).
+constexpr int GRP = 16;
+__global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
+                                                                  const unsigned char* cnt, const unsigned long long* bits,
+                                                                  const long long* node_list, long long nlist, long long* seeds) {
+    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    double hmin = a.h[0];
+    for (int d = 1; d < a.ndim; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
+    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
+    const int lane = threadIdx.x & 63, gl = lane % GRP, gbase = lane - gl;
+    const long long ngroups = (long long)gridDim.x * (blockDim.x / GRP);
+    for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / GRP; w < total; w += ngroups) {
+        const long long t = node_list ? node_list[w] : w;
+        const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
+        double xq[3] = {0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
+        double bd = __builtin_inf();        // this lane's nearest sample so far
+        long long bslot = -1;
+        double bound = __builtin_inf();     // the group's (pruning only)
+        auto scan_cell = [&](int c0, int c1, int c2) {
+            const int c[3] = {c0, c1, c2};
+            double bx = 0.0;                 // squared distance from the node to the cell
+            for (int d = 0; d < a.ndim; ++d) {
+                const int gap = I[d] < c[d] ? c[d] - I[d] : (I[d] > c[d] + 1 ? I[d] - (c[d] + 1) : 0);
+                bx += (double)gap * a.h[d] * ((double)gap * a.h[d]);
+            }
+            if (bx > bd || bx > bound) return;
+            const int id = cand_id[cell_lin(a, c)];
+            if (id < 0) return;
+            const int m = cnt[id];
+            for (int k = 0; k < m; ++k) {
+                const long long slot = (long long)id * S + k;
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                if (d2 < bd) { bd = d2; bslot = slot; }
+            }
+        };
+        auto scan_row = [&](int lo, int hi, int c1, int c2) {
+            if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) return;
+            lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
+            const long long row = bits_row(a, c1, c2);
+            for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
+                unsigned long long m = bits[row + w0];
+                if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
+                if (w0 == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    scan_cell(w0 * 64 + b, c1, c2);
+                }
+            }
+        };
+        auto group_min = [&](double v) {
+            for (int off = GRP / 2; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, GRP); v = o < v ? o : v; }
+            return v;
+        };
+        // the estimate (every lane computes the same; the loads coalesce into broadcasts)
+        double xe[3] = {xq[0], xq[1], xq[2]};
+        bool have = true;
+        for (int it = 0; it < 5 && have; ++it) {
+            int J[3] = {0, 0, 0};
+            long long qj = a.origin;
+            for (int d = 0; d < a.ndim; ++d) {
+                int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
+                j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
+                J[d] = j;
+                qj += (long long)j * (d == 0 ? 1 : (d == 1 ? a.s1 : a.s2));
+            }
+            if (a.mask && !a.mask[qj]) break;
+            const double vj = ld_val(a.phi, qj, a.f32);
+            double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
+            for (int d = 0; d < a.ndim; ++d) {
+                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+                g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
+                g2 += g[d] * g[d];
+                val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
+            }
+            if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
+            for (int d = 0; d < a.ndim; ++d) xe[d] -= val * g[d] / g2;
+            if (val * val < 0.0625 * hmin * hmin * g2) break;
+        }
+        if (have) {     // the rows around the estimate's cell, one per lane
+            int E[3];
+            cell_of(a, xe, E);
+            const int r1 = a.ndim > 1 ? 3 : 1, r2 = a.ndim > 2 ? 3 : 1;
+            if (gl < r1 * r2) scan_row(E[0] - 1, E[0] + 1, E[1] + (a.ndim > 1 ? gl % 3 - 1 : 0), E[2] + (a.ndim > 2 ? gl / 3 - 1 : 0));
+        }
+        bound = group_min(bd);
+        const double R0 = sqrt(bound);
+        if (!(R0 <= 10.0 * hmin)) {            // also when bound == inf
+            if (gl == 0) seeds[NSEED * w] = -2;
+            continue;
+        }
+        // every cell that meets the ball of radius R0 around the node: rows (c1, c2) dealt round-robin to the lanes
+        {
+            auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
+            const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
+            const int n1 = a.ndim > 1 ? 2 * k1 + 2 : 1, n2 = a.ndim > 2 ? 2 * k2 + 2 : 1;
+            for (int idx = gl; idx < n1 * n2; idx += GRP) {
+                const int c1 = a.ndim > 1 ? I[1] - k1 - 1 + idx % n1 : 0, c2 = a.ndim > 2 ? I[2] - k2 - 1 + idx / n1 : 0;
+                const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0, dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
+                const double lim = bd < bound ? bd : bound;
+                const double rem = lim - dz * dz - dy * dy;
+                if (rem < 0.0) continue;
+                const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
+                scan_row(I[0] - k0 - 1, I[0] + k0, c1, c2);
+            }
+        }
+        // the NSEED nearest of the lanes' bests, nearest first (the first is the exact nearest sample)
+        for (int k = 0; k < NSEED; ++k) {
+            const double m = group_min(bd);
+            long long out = -1;
+            if (m < __builtin_inf()) {
+                const unsigned long long bal = __ballot(bd == m);
+                const int owner = gbase + __ffsll((long long)((bal >> gbase) & ((1ull << GRP) - 1ull))) - 1;
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)(unsigned long long)bslot, owner, 64);
+                const unsigned hi = (unsigned)__shfl((int)(unsigned)((unsigned long long)bslot >> 32), owner, 64);
+                out = (long long)(((unsigned long long)hi << 32) | lo);
+                if (lane == owner) bd = __builtin_inf();
+            }
+            if (gl == 0) seeds[NSEED * w + k] = out;
+        }
+    }
+}
+
 // (a) nearest samples of every active node -> seeds[NSEED * w .. ]   (latency-bound: keep it light on registers)
 __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
                                                             const unsigned char* blk, const unsigned long long* bits,
                                                             const long long* node_list, long long nlist, long long* seeds) {
+    // one lane per node, for the nodes the group kernel flagged (seeds[0] == -2)
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
@@ -339,9 +468,9 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
     int rmax = 1;
     for (int d = 0; d < a.ndim; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        if (seeds[NSEED * w] != -2) continue;
         const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
-        const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
         double xq[3] = {0, 0, 0};
         for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
         // the NSEED nearest samples, nearest first
@@ -402,16 +531,33 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         // nearest samples when ϕ is anywhere near a distance function; the cells around it give a tight upper bound,
         // and scanning every cell that meets the ball of that radius around the node then makes the result exact.
         {
-            const double vq = ld_val(a.phi, q, a.f32);
-            double g[3] = {0, 0, 0}, g2 = 0.0;
-            for (int d = 0; d < a.ndim; ++d) {
-                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-                g[d] = (ld_val(a.phi, q + sd, a.f32) - ld_val(a.phi, q - sd, a.f32)) / (2.0 * a.h[d]);
-                g2 += g[d] * g[d];
+            // a few Newton steps on the node-wise linear model ϕ_J + ∇ϕ_J·(x - x_J), J the node nearest to the iterate
+            // (centred differences): cheap, and within a cell of the interface even when ϕ is far from a distance function
+            double xe[3] = {xq[0], xq[1], xq[2]};
+            bool have = true;
+            for (int it = 0; it < 5 && have; ++it) {
+                int J[3] = {0, 0, 0};
+                long long qj = a.origin;
+                for (int d = 0; d < a.ndim; ++d) {
+                    int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
+                    j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
+                    J[d] = j;
+                    qj += (long long)j * (d == 0 ? 1 : (d == 1 ? a.s1 : a.s2));
+                }
+                if (a.mask && !a.mask[qj]) break;              // left the band: keep the last iterate
+                const double vj = ld_val(a.phi, qj, a.f32);
+                double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
+                for (int d = 0; d < a.ndim; ++d) {
+                    const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+                    g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
+                    g2 += g[d] * g[d];
+                    val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
+                }
+                if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
+                for (int d = 0; d < a.ndim; ++d) xe[d] -= val * g[d] / g2;
+                if (val * val < 0.0625 * hmin * hmin * g2) break;   // within a quarter cell of the model's zero
             }
-            if (g2 > 0.0 && g2 == g2 && vq == vq) {
-                double xe[3] = {0, 0, 0};
-                for (int d = 0; d < a.ndim; ++d) xe[d] = xq[d] - vq * g[d] / g2;
+            if (have) {
                 int E[3];
                 cell_of(a, xe, E);
                 for (int c2 = E[2] - (a.ndim > 2 ? 1 : 0); c2 <= E[2] + (a.ndim > 2 ? 1 : 0); ++c2)
@@ -652,6 +798,9 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     if (nwork) {
         RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
+        const long long grp_blocks = (nwork * GRP + 255) / 256;
+        hipLaunchKernelGGL(reinit_search_group_kernel, dim3((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks)), dim3(256), 0, stream, a,
+                           cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
         hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         hipLaunchKernelGGL(reinit_newton_kernel, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1,
