@@ -124,37 +124,103 @@ __device__ __forceinline__ void cell_unlin(const ReinitArgs& a, long long c, int
     I[0] = (int)(c % c0); I[1] = (int)((c / c0) % c1); I[2] = (int)(c / (c0 * c1));
 }
 
-// ---- 1. candidate cells: active (all corners in the band, src/meshfield.jl:364-369) and not provably empty
-__global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* cand_cell, unsigned cand_cap,
-                                                           unsigned* cand_count) {
+// extrema of the Bernstein coefficients of the patch whose stencil starts at padded index q0 (cell_extrema,
+// src/interpolation.jl:262-265): M applied along every dimension in turn
+__device__ void bernstein_extrema(const ReinitArgs& a, long long q0, double& lo, double& hi) {
+    const int nv = a.nv, nc = a.order + 1;
+    const int e1 = a.ndim > 1 ? 1 : 0, e2 = a.ndim > 2 ? 1 : 0;
+    const int v1 = e1 ? nv : 1, v2 = e2 ? nv : 1, c1n = e1 ? nc : 1, c2n = e2 ? nc : 1;
+    double buf0[216], buf1[216];
+    for (int j2 = 0; j2 < v2; ++j2)
+        for (int j1 = 0; j1 < v1; ++j1)
+            for (int j0 = 0; j0 < nv; ++j0) buf0[j0 + nv * (j1 + v1 * j2)] = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+    // dimension 0: (nv, v1, v2) -> (nc, v1, v2)
+    for (int j2 = 0; j2 < v2; ++j2)
+        for (int j1 = 0; j1 < v1; ++j1)
+            for (int i = 0; i < nc; ++i) {
+                double sacc = 0.0;
+                for (int j = 0; j < nv; ++j) sacc += a.M[i * nv + j] * buf0[j + nv * (j1 + v1 * j2)];
+                buf1[i + nc * (j1 + v1 * j2)] = sacc;
+            }
+    // dimension 1: (nc, v1, v2) -> (nc, c1n, v2)
+    if (e1) {
+        for (int j2 = 0; j2 < v2; ++j2)
+            for (int i1 = 0; i1 < nc; ++i1)
+                for (int i0 = 0; i0 < nc; ++i0) {
+                    double sacc = 0.0;
+                    for (int j = 0; j < nv; ++j) sacc += a.M[i1 * nv + j] * buf1[i0 + nc * (j + v1 * j2)];
+                    buf0[i0 + nc * (i1 + c1n * j2)] = sacc;
+                }
+    } else {
+        for (int i = 0; i < nc; ++i) buf0[i] = buf1[i];
+    }
+    // dimension 2: (nc, c1n, v2) -> (nc, c1n, c2n), extrema on the fly
+    lo = __builtin_inf(); hi = -__builtin_inf();
+    for (int i2 = 0; i2 < c2n; ++i2)
+        for (int i1 = 0; i1 < c1n; ++i1)
+            for (int i0 = 0; i0 < nc; ++i0) {
+                double sacc = 0.0;
+                if (e2) for (int j = 0; j < nv; ++j) sacc += a.M[i2 * nv + j] * buf0[i0 + nc * (i1 + c1n * j)];
+                else sacc = buf0[i0 + nc * i1];
+                lo = sacc < lo ? sacc : lo; hi = sacc > hi ? sacc : hi;
+            }
+}
+
+// ---- 1. candidate cells: active (all corners in the band, src/meshfield.jl:364-369) and not provably empty.
+// (a) every cell: the cheap bound |p - mid| <= Λ·spread over the stencil values -> list of "maybe" cells (wave-
+//     aggregated append); (b) the maybe cells only (≈6x the final count): the reference's own test on the extrema of
+//     the Bernstein coefficients (proven_empty, src/interpolation.jl:271-274) -> candidate ids.
+__global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* maybe, unsigned* maybe_count) {
     const long long nc = ncells(a);
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (long long)gridDim.x * blockDim.x) {
+    const long long span = (nc + 255) / 256 * 256;      // whole waves reach the ballot
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (long long)gridDim.x * blockDim.x) {
+        bool keep = false;
+        if (c < nc) {
+            int I[3];
+            cell_unlin(a, c, I);
+            const long long qc = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
+            bool act = true;
+            if (a.mask)
+                for (int k = 0; k < (1 << a.ndim); ++k)
+                    act = act && a.mask[qc + (k & 1) + ((k >> 1) & 1) * a.s1 + ((k >> 2) & 1) * a.s2];
+            if (act) {
+                const int nv1 = a.ndim > 1 ? a.nv : 1, nv2 = a.ndim > 2 ? a.nv : 1;
+                const long long q0 = qc + a.off + (a.ndim > 1 ? a.off * a.s1 : 0) + (a.ndim > 2 ? a.off * a.s2 : 0);
+                double lo = __builtin_inf(), hi = -__builtin_inf();
+                for (int j2 = 0; j2 < nv2; ++j2)
+                    for (int j1 = 0; j1 < nv1; ++j1)
+                        for (int j0 = 0; j0 < a.nv; ++j0) {
+                            const double v = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+                            lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+                        }
+                const double mid = 0.5 * (lo + hi), spread = 0.5 * (hi - lo);
+                const bool empty = mid - a.lambda * spread > 0.0 || mid + a.lambda * spread < 0.0;   // p cannot vanish
+                keep = !empty && lo == lo && hi == hi;
+            }
+            cand_id[c] = -1;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (!bal) continue;
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(maybe_count, (unsigned)__popcll(bal));
+        base = __shfl(base, leader, 64);
+        if (keep) maybe[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+    }
+}
+__global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const long long* maybe, unsigned nmaybe, int* cand_id,
+                                                            long long* cand_cell, unsigned* cand_count) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nmaybe; i += gridDim.x * blockDim.x) {
+        const long long c = maybe[i];
         int I[3];
         cell_unlin(a, c, I);
-        const long long qc = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
-        bool act = true;
-        if (a.mask)
-            for (int k = 0; k < (1 << a.ndim); ++k)
-                act = act && a.mask[qc + (k & 1) + ((k >> 1) & 1) * a.s1 + ((k >> 2) & 1) * a.s2];
-        int id = -1;
-        if (act) {
-            const int nv1 = a.ndim > 1 ? a.nv : 1, nv2 = a.ndim > 2 ? a.nv : 1;
-            const long long q0 = qc + a.off + (a.ndim > 1 ? a.off * a.s1 : 0) + (a.ndim > 2 ? a.off * a.s2 : 0);
-            double lo = __builtin_inf(), hi = -__builtin_inf();
-            for (int j2 = 0; j2 < nv2; ++j2)
-                for (int j1 = 0; j1 < nv1; ++j1)
-                    for (int j0 = 0; j0 < a.nv; ++j0) {
-                        const double v = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
-                        lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-                    }
-            const double mid = 0.5 * (lo + hi), spread = 0.5 * (hi - lo);
-            const bool empty = mid - a.lambda * spread > 0.0 || mid + a.lambda * spread < 0.0;   // p cannot vanish
-            if (!empty && lo == lo && hi == hi) {
-                id = (int)atomicAdd(cand_count, 1u);
-                if ((unsigned)id < cand_cap) cand_cell[id] = c;     // pass 2 of the host (pass 1 only counts)
-            }
-        }
-        cand_id[c] = id;
+        const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
+        double clo, chi;
+        bernstein_extrema(a, q0, clo, chi);
+        if (clo * chi > 0.0) continue;
+        const unsigned id = atomicAdd(cand_count, 1u);
+        cand_id[c] = (int)id;
+        cand_cell[id] = c;
     }
 }
 
@@ -738,28 +804,30 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     int S = 1;
     for (int d = 0; d < ndim; ++d) S *= upsample + 1;
     int* cand_id = nullptr;
-    long long* cand_cell = nullptr;
+    long long *cand_cell = nullptr, *maybe = nullptr;
     unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
     long long *node_list = nullptr, *seeds = nullptr;
     unsigned long long* bits = nullptr;
-    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
+    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
                           (void)hipFree(blk); (void)hipFree(node_list); (void)hipFree(seeds); (void)hipFree(bits); };
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
     const unsigned gb = (unsigned)((nc + 255) / 256 > 65535 ? 65535 : (nc + 255) / 256);
-    // two passes: count the candidate cells, then list them (ids are handed out again, consistently with cand_id)
-    unsigned ncand = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
-        hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, cand_cell, pass ? ncand : 0u, counters);
-        if (pass == 0) {
-            RE_HIP(hipMemcpyAsync(&ncand, counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-            RE_HIP(hipStreamSynchronize(stream));
-            RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(ncand ? ncand : 1)));
-        }
+    unsigned nmaybe = 0, ncand = 0;
+    RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
+    RE_HIP(hipMalloc((void**)&maybe, sizeof(long long) * (size_t)nc));
+    hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, maybe, counters);
+    RE_HIP(hipMemcpyAsync(&nmaybe, counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    RE_HIP(hipStreamSynchronize(stream));
+    RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
+    if (nmaybe) {
+        hipLaunchKernelGGL(reinit_cells2_kernel, dim3((nmaybe + 255) / 256), dim3(256), 0, stream, a, maybe, nmaybe, cand_id, cand_cell,
+                           counters + 1);
+        RE_HIP(hipMemcpyAsync(&ncand, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RE_HIP(hipStreamSynchronize(stream));
     }
     RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
     const size_t slots = (size_t)(ncand ? ncand : 1) * S;
