@@ -11,11 +11,15 @@
 //  * sampling (src/sdf.jl:186-221): uniformly spaced start points of every candidate cell are projected onto
 //    the zero set by Newton steps that follow the iterate across cells; converged points that land back in
 //    their own cell are kept.  The reference skips cells it can prove empty from the Bernstein coefficients;
-//    skipping is only an optimisation (a start point of an empty cell never converges back into it), so any
-//    conservative filter yields the same sample set: here |p - c| <= Λ·spread of the stencil values.
-//  * closest point (src/sdf.jl:85-131,223-249): nearest sample (exact: expanding shells of cells, instead of
-//    the reference's KD-tree) seeds a damped Newton–Lagrange solve on the seed cell's patch; up to 4 further
-//    nearest seeds are tried when it fails (the reference tries up to 10).
+//    skipping is only an optimisation (a start point of an empty cell never converges back into it).  Here a
+//    cheap conservative bound (|p - c| <= Λ·spread of the stencil values) runs over all cells and the
+//    reference's Bernstein test over the survivors.
+//  * closest point (src/sdf.jl:85-131,223-249): the nearest sample — exact, like the reference's KD-tree query:
+//    a cheap estimate of the closest point leads to the cells that hold it, and every cell meeting the ball of
+//    that radius around the node is then scanned (16 lanes per node; occupancy bits per cell); nodes without a
+//    usable estimate fall back to expanding shells of cells, then of 8^N-cell blocks — seeds a damped
+//    Newton–Lagrange solve on the seed cell's patch; up to 4 further near seeds are tried when it fails (the
+//    reference tries up to 10).
 // fp64 throughout, -ffp-contract=off.
 #include <cmath>
 #include <vector>
