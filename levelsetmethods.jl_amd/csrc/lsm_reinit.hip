@@ -402,6 +402,7 @@ constexpr int FINE_SHELLS = 6;
 // merge with shuffles.  Nodes the guided search cannot settle (no usable estimate, ball wider than 10 cells) are
 // flagged for the one-lane-per-node kernel below (seeds[0] = -2).
 constexpr int GRP = 16;
+constexpr int QCAP = 96;
 __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
                                                                   const unsigned char* cnt, const unsigned long long* bits,
                                                                   const long long* node_list, long long nlist, long long* seeds) {
@@ -411,6 +412,8 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
     const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
     const int lane = threadIdx.x & 63, gl = lane % GRP, gbase = lane - gl;
     const long long ngroups = (long long)gridDim.x * (blockDim.x / GRP);
+    __shared__ long long qcell[256 / GRP][QCAP];
+    __shared__ unsigned qn[256 / GRP];
     for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / GRP; w < total; w += ngroups) {
         const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
@@ -493,19 +496,50 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             if (gl == 0) seeds[NSEED * w] = -2;
             continue;
         }
-        // every cell that meets the ball of radius R0 around the node: rows (c1, c2) dealt round-robin to the lanes
+        // every occupied cell that meets the ball of radius R0 around the node: the lanes first collect them from the
+        // occupancy rows (c1, c2) into a queue in LDS, then take one cell each — three levels of dependent loads per
+        // node (row word, cell record, samples) instead of a chain per row
         {
+            const int g = threadIdx.x / GRP;
+            if (gl == 0) qn[g] = 0;
+            __builtin_amdgcn_wave_barrier();
             auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
             const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
             const int n1 = a.ndim > 1 ? 2 * k1 + 2 : 1, n2 = a.ndim > 2 ? 2 * k2 + 2 : 1;
             for (int idx = gl; idx < n1 * n2; idx += GRP) {
                 const int c1 = a.ndim > 1 ? I[1] - k1 - 1 + idx % n1 : 0, c2 = a.ndim > 2 ? I[2] - k2 - 1 + idx / n1 : 0;
+                if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) continue;
                 const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0, dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
-                const double lim = bd < bound ? bd : bound;
-                const double rem = lim - dz * dz - dy * dy;
+                const double rem = bound - dz * dz - dy * dy;
                 if (rem < 0.0) continue;
                 const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
-                scan_row(I[0] - k0 - 1, I[0] + k0, c1, c2);
+                int lo = I[0] - k0 - 1, hi = I[0] + k0;
+                lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
+                const long long row = bits_row(a, c1, c2);
+                for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
+                    unsigned long long m = bits[row + w0];
+                    if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
+                    if (w0 == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+                    while (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int c0 = w0 * 64 + b;
+                        const double dx = gap(0, c0) * a.h[0];
+                        if (dx * dx > rem) continue;
+                        const unsigned slot = atomicAdd(&qn[g], 1u);
+                        if (slot < QCAP) qcell[g][slot] = c0 + (long long)nc_[0] * (c1 + (long long)nc_[1] * c2);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned nq = *(volatile unsigned*)&qn[g];
+            if (nq > QCAP) {                       // more occupied cells than the queue holds: the one-lane kernel takes it
+                if (gl == 0) seeds[NSEED * w] = -2;
+                continue;
+            }
+            for (unsigned i = gl; i < nq; i += GRP) {
+                const long long c = *(volatile long long*)&qcell[g][i];
+                scan_cell((int)(c % nc_[0]), (int)((c / nc_[0]) % nc_[1]), (int)(c / ((long long)nc_[0] * nc_[1])));
             }
         }
         // the NSEED nearest of the lanes' bests, nearest first (the first is the exact nearest sample)
