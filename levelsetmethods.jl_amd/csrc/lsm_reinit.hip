@@ -47,28 +47,37 @@ struct ReinitArgs {
 __device__ __constant__ double kBinom[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0},
                                                {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
 
-struct Card { double L[6], dL[6], d2L[6]; };
+// NV = stencil size (2, 4 or 6), a compile-time constant so that the cardinal functions and the contraction live in
+// registers and unroll (the generic-size version needed 256 VGPRs and spilled)
+template <int NV>
+struct Card { double L[NV], dL[NV], d2L[NV]; };
 
 // degree-m Bernstein basis value with out-of-range indices = 0
 __device__ __forceinline__ double bern(int m, int i, const double* tp, const double* sp) {
     return (i < 0 || i > m || m < 0) ? 0.0 : kBinom[m][i] * tp[i] * sp[m - i];
 }
 // cardinal functions of one dimension at local coordinate t, derivatives w.r.t. x (1/h folded in)
-__device__ void cardinal(const ReinitArgs& a, double t, double invh, bool second, Card& o) {
-    const int n = a.order;
-    double tp[6], sp[6];
+template <int NV>
+__device__ __forceinline__ void cardinal(const ReinitArgs& a, double t, double invh, bool second, Card<NV>& o) {
+    const int n = a.order;       // NV - 1 (odd orders) or NV - 2 (even orders: least-squares fit of a larger stencil)
+    double tp[NV], sp[NV];
     tp[0] = sp[0] = 1.0;
-    for (int i = 1; i <= n; ++i) { tp[i] = tp[i - 1] * t; sp[i] = sp[i - 1] * (1.0 - t); }
-    double B[6], dB[6], d2B[6];
-    for (int i = 0; i <= n; ++i) {
-        B[i] = bern(n, i, tp, sp);
-        dB[i] = n * (bern(n - 1, i - 1, tp, sp) - bern(n - 1, i, tp, sp));
-        d2B[i] = second ? n * (n - 1) * (bern(n - 2, i - 2, tp, sp) - 2.0 * bern(n - 2, i - 1, tp, sp) + bern(n - 2, i, tp, sp)) : 0.0;
+#pragma unroll
+    for (int i = 1; i < NV; ++i) { tp[i] = tp[i - 1] * t; sp[i] = sp[i - 1] * (1.0 - t); }
+    double B[NV], dB[NV], d2B[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool in = i <= n;
+        B[i] = in ? bern(n, i, tp, sp) : 0.0;
+        dB[i] = in ? n * (bern(n - 1, i - 1, tp, sp) - bern(n - 1, i, tp, sp)) : 0.0;
+        d2B[i] = in && second ? n * (n - 1) * (bern(n - 2, i - 2, tp, sp) - 2.0 * bern(n - 2, i - 1, tp, sp) + bern(n - 2, i, tp, sp)) : 0.0;
     }
-    for (int j = 0; j < a.nv; ++j) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
         double l = 0.0, dl = 0.0, d2l = 0.0;
-        for (int i = 0; i <= n; ++i) {
-            const double m = a.M[i * a.nv + j];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double m = i <= n ? a.M[i * NV + j] : 0.0;
             l += m * B[i]; dl += m * dB[i]; d2l += m * d2B[i];
         }
         o.L[j] = l; o.dL[j] = dl * invh; o.d2L[j] = d2l * invh * invh;
@@ -76,25 +85,33 @@ __device__ void cardinal(const ReinitArgs& a, double t, double invh, bool second
 }
 
 // value, gradient and (optionally) Hessian {00,11,22,01,02,12} of the patch of cell I at x
+template <int NV>
 __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3], bool second, double& val, double g[3], double H[6]) {
-    Card c[3];
+    Card<NV> c[3];
+#pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (d < a.ndim) {
             const double t = (x[d] - (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d])) / a.h[d];
-            cardinal(a, t, 1.0 / a.h[d], second, c[d]);
+            cardinal<NV>(a, t, 1.0 / a.h[d], second, c[d]);
         } else {
-            c[d].L[0] = 1.0; c[d].dL[0] = 0.0; c[d].d2L[0] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { c[d].L[j] = j == 0 ? 1.0 : 0.0; c[d].dL[j] = 0.0; c[d].d2L[j] = 0.0; }
         }
     }
-    const int nv0 = a.nv, nv1 = a.ndim > 1 ? a.nv : 1, nv2 = a.ndim > 2 ? a.nv : 1;
+    const int nv1 = a.ndim > 1 ? NV : 1, nv2 = a.ndim > 2 ? NV : 1;
     const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
     val = 0.0; g[0] = g[1] = g[2] = 0.0;
     for (int k = 0; k < 6; ++k) H[k] = 0.0;
-    for (int j2 = 0; j2 < nv2; ++j2)
-        for (int j1 = 0; j1 < nv1; ++j1) {
+#pragma unroll
+    for (int j2 = 0; j2 < NV; ++j2) {
+        if (j2 >= nv2) break;
+#pragma unroll
+        for (int j1 = 0; j1 < NV; ++j1) {
+            if (j1 >= nv1) break;
             double s = 0.0, ds = 0.0, d2s = 0.0;
             const long long q = q0 + j1 * a.s1 + j2 * a.s2;
-            for (int j0 = 0; j0 < nv0; ++j0) {
+#pragma unroll
+            for (int j0 = 0; j0 < NV; ++j0) {
                 const double v = ld_val(a.phi, q + j0, a.f32);
                 s += v * c[0].L[j0]; ds += v * c[0].dL[j0]; d2s += v * c[0].d2L[j0];
             }
@@ -107,6 +124,7 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
                 H[3] += ds * D1 * L2; H[4] += ds * L1 * D2; H[5] += s * D1 * D2;
             }
         }
+    }
 }
 
 // compute_index (src/meshes.jl:155-167): cell containing x, clamped to the grid
@@ -229,6 +247,7 @@ __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const 
 }
 
 // ---- 2. interface samples: one thread per (candidate cell, start point)
+template <int NV>
 __global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
                                                             unsigned char* valid) {
     const long long total = (long long)ncand * S;
@@ -249,7 +268,7 @@ __global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const 
             int J[3];
             cell_of(a, x, J);
             double val, g[3], H[6];
-            patch_eval(a, J, x, false, val, g, H);
+            patch_eval<NV>(a, J, x, false, val, g, H);
             if (fabs(val) < a.ftol) { conv = true; break; }
             const double g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
             if (g2 == 0.0 || !(g2 == g2)) break;
@@ -332,10 +351,11 @@ __device__ bool solve_small(int m, double A[4][4], double b[4]) {
 }
 
 // _closest_point (src/sdf.jl:239-272) on the patch of cell I, from x0; returns converged
+template <int NV>
 __device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const double xq[3], const double x0[3], double safeguard, double cp[3]) {
     const int N = a.ndim;
     double val, g[3], H[6];
-    patch_eval(a, I, x0, false, val, g, H);
+    patch_eval<NV>(a, I, x0, false, val, g, H);
     double g2 = 0.0, num = 0.0;
     for (int d = 0; d < N; ++d) { g2 += g[d] * g[d]; num += (xq[d] - x0[d]) * g[d]; }
     double lam = g2 == 0.0 ? 0.0 : num / g2;
@@ -344,7 +364,7 @@ __device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const doub
     cp[0] = x0[0]; cp[1] = x0[1]; cp[2] = x0[2];
     const double reg = 1.4901161193847656e-08;   // sqrt(eps(Float64))
     for (int it = 0; it < a.maxiters; ++it) {
-        patch_eval(a, I, x, true, val, g, H);
+        patch_eval<NV>(a, I, x, true, val, g, H);
         double res[4], rn2 = 0.0;
         for (int d = 0; d < N; ++d) { res[d] = x[d] - xq[d] + lam * g[d]; rn2 += res[d] * res[d]; }
         res[N] = val; rn2 += val * val;
@@ -726,6 +746,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
 }
 
 // (b) closest point from the seeds, signed distance
+template <int NV>
 __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S, const double* pts, const long long* node_list, long long nlist,
                                                             const long long* seeds, void* out, unsigned* nfail, unsigned* nfar) {
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
@@ -750,7 +771,7 @@ __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S,
                 int J[3];
                 cell_of(a, seed, J);
                 double c3[3];
-                conv = closest_on_patch(a, J, xq, seed, safeguard, c3);
+                conv = closest_on_patch<NV>(a, J, xq, seed, safeguard, c3);
                 double d2 = 0.0;
                 for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
                 if (conv || d2 < bestd) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
@@ -885,7 +906,9 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
-        hipLaunchKernelGGL(reinit_sample_kernel, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
+        if (a.nv == 2) hipLaunchKernelGGL(reinit_sample_kernel<2>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
+        else if (a.nv == 4) hipLaunchKernelGGL(reinit_sample_kernel<4>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
+        else hipLaunchKernelGGL(reinit_sample_kernel<6>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
         hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk, bits);
     }
     const long long nodes = (long long)n[0] * n[1] * n[2];
@@ -909,8 +932,12 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
                            cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
         hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
-        hipLaunchKernelGGL(reinit_newton_kernel, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1,
-                           counters + 2);
+        if (a.nv == 2)
+            hipLaunchKernelGGL(reinit_newton_kernel<2>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
+        else if (a.nv == 4)
+            hipLaunchKernelGGL(reinit_newton_kernel<4>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
+        else
+            hipLaunchKernelGGL(reinit_newton_kernel<6>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
     }
     hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
                        out_field, phi);
