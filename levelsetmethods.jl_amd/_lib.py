@@ -129,6 +129,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+        # torch ships its own HIP/HSA runtime libraries and must bring them in first: if libhiplsm.so pulls in
+        # /opt/rocm's copies before torch is imported, the process ends up with two HSA runtimes and the second
+        # one finds no device ("no ROCm-capable device is detected")
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in _SIGS:
             fn = getattr(L, name)   # AttributeError if a declared symbol is not exported

@@ -143,8 +143,13 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
         }
     }
     int dev_count = 0;
-    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0)
-        return fail(nullptr, LSM_ERR_NO_DEVICE, "lsm_create: no HIP device available (this library has no CPU path)");
+    const hipError_t dev_err = hipGetDeviceCount(&dev_count);
+    if (dev_err != hipSuccess || dev_count <= 0) {
+        static char msg[256];
+        snprintf(msg, sizeof msg, "lsm_create: no HIP device available (this library has no CPU path) [hipGetDeviceCount: %s, count %d]",
+                 hipGetErrorString(dev_err), dev_count);
+        return fail(nullptr, LSM_ERR_NO_DEVICE, msg);
+    }
     if (device < 0 || device >= dev_count) return fail(nullptr, LSM_ERR_INVALID, "lsm_create: bad device index");
 
     LsmHandle* h = new LsmHandle();
@@ -395,6 +400,9 @@ static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void
     if (psi == out || psi == out2) return fail(h, LSM_ERR_INVALID, "lsm_stage: out must not alias the stencil input psi");
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const int N = h->grid.ndim;
+    // the kernel addresses a plane (the whole array in 1-D, a row in 2-D) through a 2 GiB buffer descriptor
+    if ((N == 1 ? h->lay.total : h->lay.stride[N - 1]) * 8ll >= (1ll << 31))
+        return fail(h, LSM_ERR_INVALID, "lsm_stage: a plane of the padded array must be smaller than 2 GiB");
     int i = 0;
     bool first = true;
     while (i < nterms) {
@@ -428,13 +436,22 @@ static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void
     flush:
         if (cnt == 0) return fail(h, LSM_ERR_INVALID, "lsm_stage: internal planner error");
         a.nterms = cnt;
+        a.natural = 1;
+        for (int k = 1; k < cnt; ++k)
+            if (a.order[k] <= a.order[k - 1]) a.natural = 0;
         a.psi = (const double*)psi;
         a.out = (double*)out;
         a.out2 = (double*)out2;
         a.cdt = cdt; a.cdt2 = cdt2;
         a.mb = mb; a.me = me;
-        if (first) { a.base_mode = base_mode; a.phin = (const double*)phin; a.out2_accum = 0; }
+        if (first) { a.base_mode = base_mode; a.phin = (const double*)(base_mode == LSM_BASE_PSI ? psi : phin); a.out2_accum = 0; }   // the kernel always loads phin
         else       { a.base_mode = LSM_BASE_OTHER; a.phin = (const double*)out; a.out2_accum = 1; }
+        switch (a.base_mode) {
+        case LSM_BASE_PSI: a.base_a = 0.0; a.base_b = 1.0; break;
+        case LSM_BASE_RK3_S2: a.base_a = 0.75; a.base_b = 0.25; break;
+        case LSM_BASE_RK3_S3: a.base_a = 1.0 / 3; a.base_b = 2.0 / 3; break;
+        default: a.base_a = 1.0; a.base_b = 0.0; break;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->prof) { int r = profile_pair(h, &e0, &e1); if (r) return r; LSM_HIP(h, hipEventRecord(e0, s)); }
         int r;

@@ -49,11 +49,13 @@ struct StageArgs {
     double* out;
     double* out2;
     int base_mode;     // LSM_BASE_*
+    double base_a, base_b;   // FAST build: base = base_a·ϕⁿ + base_b·ψ (set by the launcher from base_mode)
     int out2_accum;    // 0: out2 starts from psi, 1: out2 accumulates onto itself (multi-pass)
     double cdt, cdt2;
     // terms of this pass, in user order: order[k] is a SLOT_*
     int nterms;
     int order[NSLOTS];
+    int natural;       // order[] lists the pass's slots in ascending order (the kernel then needs no look-up)
     int adv_scheme;
     CoeffArgs adv, nm, curv;
     const double* s0;  // Eikonal frozen sign (NULL = current-sign mode)

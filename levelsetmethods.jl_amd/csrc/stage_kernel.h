@@ -14,6 +14,7 @@
 //   * upwind selection never diverges: the biased stencil is fetched through a sign-flipped LDS
 //     stride (x,y) or v_cndmask on the register line (march axis).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include "lsm_internal.h"
 #include "stage_math.h"
@@ -36,17 +37,47 @@ constexpr int halo_of(int ADV, int NM, int CURV, int EIK) {
     return g;
 }
 
-// load/store through a wave-uniform base pointer plus a 32-bit unsigned BYTE offset: this is the
-// shape (sgpr base + zext(vgpr32)) that selects global_load/store's saddr addressing mode.
+// a wave-uniform pointer pinned to SGPRs (the buffer descriptors below must be scalar)
+template <class T>
+LSM_DEV T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// read-only table entry at a wave-uniform index: a scalar load (s_load_dwordx2) instead of a vector load, so that
+// waiting for it does not wait for the plane prefetch in flight (vector loads return in order)
+LSM_DEV double ld_uniform(const double* t, int i) {
+    typedef const __attribute__((address_space(4))) double* cptr;
+    return *((cptr)(unsigned long long)t + i);
+}
+// Field access = wave-uniform base (a plane of the padded array; any 64-bit address) + a 32-bit unsigned BYTE
+// offset inside the plane, as a raw buffer access: the descriptor is built from the base on the scalar unit, the
+// offset goes in as it is — no 64-bit vector address arithmetic (global_load needs one v_lshl_add_u64 per access
+// once LLVM has hoisted the offset's zero-extension out of the plane loop).  The descriptor's range is the 2 GiB
+// above the base (lsm_stage refuses layouts whose planes are larger), so nothing is clamped that the kernel's own
+// index logic allows, and LSM_OOB_OFFSET is out of range under every reading of the range rule: such a load
+// returns 0 without touching memory.
 // ST is the storage type of the field (double, or float for LSM_DTYPE_F32: values widen exactly on load,
 // all arithmetic is fp64, the result is rounded to nearest on store).
+typedef unsigned lsm_v2u __attribute__((ext_vector_type(2)));
+LSM_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+constexpr unsigned LSM_OOB_OFFSET = 0xC0000000u;
 template <class ST>
 LSM_DEV double ldg(const ST* base, unsigned boff) {
-    return (double)*reinterpret_cast<const ST*>(reinterpret_cast<const char*>(base) + boff);
+    if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base), boff, 0, 0));
+    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base), boff, 0, 0));
 }
 template <class ST>
 LSM_DEV void stg(ST* base, unsigned boff, double v) {
-    *reinterpret_cast<ST*>(reinterpret_cast<char*>(base) + boff) = (ST)v;
+    if constexpr (sizeof(ST) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lsm_v2u, v), plane_rsrc(base), boff, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), plane_rsrc(base), boff, 0, 0);
+}
+// byte load with an explicit range: range 0 (no array) returns 0 without touching memory
+LSM_DEV unsigned ldg_u8(const unsigned char* base, unsigned boff, int range) {
+    return __builtin_amdgcn_raw_buffer_load_b8(
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, __builtin_amdgcn_readfirstlane(range), 0x00020000), boff, 0, 0);
 }
 
 // _eval_field (src/levelsetterms.jl:42-43) for the catalogued coefficient kinds (include/lsm.h),
@@ -55,13 +86,15 @@ LSM_DEV void stg(ST* base, unsigned boff, double v) {
 // Operation order is exactly ((T1*T2)*T3)*g and lc + i*h, as in the oracle.
 // SCALED (FAST build, advection velocity only): the values produced are u_d/h_d — the factor 1/h_d and
 // the time factor g(t) are folded into the hoisted part, so the per-node remainder is one multiply.
-template <int NDIM, int NCOMP, bool SCALED = false>
+// KIND >= 0 fixes the coefficient kind at compile time (the "plain" kernel variants), -1 reads it from the arguments
+template <int NDIM, int NCOMP, bool SCALED = false, int KIND = -1>
 LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1, double pre[3]) {
     pre[0] = pre[1] = pre[2] = 0.0;
-    if (c.kind == LSM_COEFF_CONST) {
+    const int kind = KIND >= 0 ? KIND : c.kind;
+    if (kind == LSM_COEFF_CONST) {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) pre[k] = SCALED ? c.v[k] * a.inv_h[k] : c.v[k];
-    } else if (c.kind == LSM_COEFF_ROTATION) {
+    } else if (kind == LSM_COEFF_ROTATION) {
         const double x1 = a.lc[0] + (double)gi0 * a.h[0];
         pre[1] = c.v[0] * (x1 - c.v[1]);
         if (SCALED) pre[1] = pre[1] * a.inv_h[1];
@@ -70,7 +103,7 @@ LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1
             pre[0] = -(c.v[0] * (x2 - c.v[2]));
             if (SCALED) pre[0] = pre[0] * a.inv_h[0];
         }
-    } else if (c.kind == LSM_COEFF_SEPARABLE) {
+    } else if (kind == LSM_COEFF_SEPARABLE) {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) {
             const double* T = c.sep[k];
@@ -80,13 +113,14 @@ LSM_DEV void coeff_prep(const CoeffArgs& c, const StageArgs& a, int gi0, int gi1
         }
     }
 }
-template <int NDIM, int NCOMP, bool SCALED = false>
-LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], int gim, long long plane_off, unsigned ocol,
-                        double out[3]) {
-    if (c.kind == LSM_COEFF_CONST) {
+template <int NDIM, int NCOMP, bool SCALED = false, int KIND = -1>
+LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre[3], const double tz[3], int gim, long long plane_off,
+                        unsigned ocol, double out[3]) {
+    const int kind = KIND >= 0 ? KIND : c.kind;
+    if (kind == LSM_COEFF_CONST) {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) out[k] = pre[k];
-    } else if (c.kind == LSM_COEFF_ROTATION) {
+    } else if (kind == LSM_COEFF_ROTATION) {
         if (NDIM == 2) {
             const double x2 = a.lc[1] + (double)gim * a.h[1];
             out[0] = -(c.v[0] * (x2 - c.v[2]));
@@ -96,20 +130,43 @@ LSM_DEV void coeff_eval(const CoeffArgs& c, const StageArgs& a, const double pre
         }
         if (NCOMP > 1) out[1] = pre[1];
         if (NCOMP > 2) out[2] = 0.0;
-    } else if (c.kind == LSM_COEFF_SEPARABLE) {
+    } else if (kind == LSM_COEFF_SEPARABLE) {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) {
             double p = pre[k];
-            if (NDIM > 1) p = p * c.sep[k][(NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gim];
+            if (NDIM > 1) p = p * tz[k];
             out[k] = SCALED ? p : p * c.tfac;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NCOMP; ++k) {
-            out[k] = ldg(c.f[k] + plane_off, ocol);
+            out[k] = ldg(uniform_ptr(c.f[k] + plane_off), ocol);
             if (SCALED) out[k] = out[k] * a.inv_h[k];
         }
     }
+}
+
+// the march-axis table entries of SEPARABLE coefficients for one plane (wave-uniform: scalar loads, fetched one
+// plane ahead by the march loop)
+struct PlaneTab {
+    double adv[3], nm[3], curv[3];
+};
+template <int NDIM, int NCOMP, int KIND>
+LSM_DEV void plane_tab_one(const CoeffArgs& c, const StageArgs& a, int gim, double tz[3]) {
+    tz[0] = tz[1] = tz[2] = 1.0;
+    if (NDIM > 1 && (KIND >= 0 ? KIND : c.kind) == LSM_COEFF_SEPARABLE) {
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) tz[k] = ld_uniform(c.sep[k], (NDIM == 3 ? a.gn[0] + a.gn[1] : a.gn[0]) + gim);
+    }
+}
+// AK: -1 = everything read from the arguments; >= 0 = a "plain" variant — the advection coefficient is of kind AK, the
+// NormalMotion / curvature coefficients are constants, there is no band mask, no second output, the terms come in
+// slot order.  Plain variants carry none of the other paths' scalars (the general kernel exceeds the SGPR file).
+template <int NDIM, int ADV, int NM, int CURV, int AK>
+LSM_DEV void plane_tab(const StageArgs& a, int gim, PlaneTab& t) {
+    if constexpr (ADV != 0) plane_tab_one<NDIM, NDIM, AK>(a.adv, a, gim, t.adv);
+    if constexpr (NM != 0) plane_tab_one<NDIM, 1, (AK >= 0 ? (int)LSM_COEFF_CONST : -1)>(a.nm, a, gim, t.nm);
+    if constexpr (CURV != 0) plane_tab_one<NDIM, 1, (AK >= 0 ? (int)LSM_COEFF_CONST : -1)>(a.curv, a, gim, t.curv);
 }
 
 // where a node reads/writes its pointwise operands: uniform plane offset + per-thread in-plane offset
@@ -119,6 +176,38 @@ struct NodeIO {
     unsigned ocold;        // the same for the fp64 side arrays (coefficient fields, frozen sign) and, /8, the band mask
     int gim;               // global march index
 };
+
+// the node's pointwise operands, loaded BEFORE the plane's barrier so that their latency hides under the
+// arithmetic (vector loads return in order: a load issued after the barrier would make its consumer wait for the
+// next plane's prefetch as well)
+struct NodeOps {
+    double u[3];     // advection velocity (FAST: u_d/h_d)
+    double vnm;      // NormalMotion speed
+    double bcurv;    // curvature coefficient
+    double s0;       // Eikonal frozen sign
+    double phin;     // ϕⁿ (or the accumulator of a multi-pass stage)
+    double out2;     // previous value of the second output
+};
+template <int NDIM, int ADV, int NM, int CURV, int EIK, class ST, int AK>
+LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pre_adv[3], const double pre_nm[3],
+                           const double pre_curv[3], const PlaneTab& pt, NodeOps& op) {
+    op.u[0] = op.u[1] = op.u[2] = 0.0;
+    op.vnm = op.bcurv = op.s0 = op.phin = op.out2 = 0.0;
+    if constexpr (ADV != 0) coeff_eval<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, pre_adv, pt.adv, io.gim, io.plane_off, io.ocold, op.u);   // FAST: u_d/h_d
+    if constexpr (NM != 0) {
+        double vv[3];
+        coeff_eval<NDIM, 1, false, (AK >= 0 ? (int)LSM_COEFF_CONST : -1)>(a.nm, a, pre_nm, pt.nm, io.gim, io.plane_off, io.ocold, vv);
+        op.vnm = vv[0];
+    }
+    if constexpr (CURV != 0) {
+        double bb[3];
+        coeff_eval<NDIM, 1, false, (AK >= 0 ? (int)LSM_COEFF_CONST : -1)>(a.curv, a, pre_curv, pt.curv, io.gim, io.plane_off, io.ocold, bb);
+        op.bcurv = bb[0];
+    }
+    if constexpr (EIK == 1) op.s0 = ldg(uniform_ptr(a.s0 + io.plane_off), io.ocold);
+    op.phin = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol);   // = ψ when the base is ψ (launcher)
+    if (AK < 0 && a.out2 && a.out2_accum) op.out2 = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.out2) + io.plane_off), io.ocol);
+}
 
 // Everything one node needs: pointers into the LDS ring at the node's own position and the
 // register line along the march axis.
@@ -203,9 +292,8 @@ LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
     return weno5_upwind(q, hs, ihs, 1.0e-99 * a.h2[D]);
 }
 
-template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class ST, class NV>
-LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, const double pre_adv[3], const double pre_nm[3],
-                         const double pre_curv[3], bool active) {
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int G, int W, class ST, bool PLAIN, class NV>
+LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, double& r_out, double& r_out2) {
     const double c = nv.c;
     double Ladv = 0.0, Lnm = 0.0, Lcurv = 0.0, Leik = 0.0;
     double A[3] = {0, 0, 0}, B[3] = {0, 0, 0};   // second-order ENO pairs (NormalMotion, Eikonal)
@@ -218,8 +306,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- AdvectionTerm: Σ_d u_d (u_d>0 ? D⁻|weno5⁻ : D⁺|weno5⁺) — src/levelsetterms.jl:73-82
     if constexpr (ADV != 0) {
-        double u[3];
-        coeff_eval<NDIM, NDIM, ADV_SCALED>(a.adv, a, pre_adv, io.gim, io.plane_off, io.ocold, u);   // FAST: u_d/h_d
+        const double* u = op.u;
         auto one = [&](auto Dc) {
             constexpr int D = decltype(Dc)::value;
             const double v = u[D];
@@ -258,9 +345,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- NormalMotionTerm — src/levelsetterms.jl:156-170
     if constexpr (NM) {
-        double vv[3];
-        coeff_eval<NDIM, 1>(a.nm, a, pre_nm, io.gim, io.plane_off, io.ocold, vv);
-        const double v = vv[0];
+        const double v = op.vnm;
 #if LSM_STRICT
         double gp = 0.0, gm = 0.0;
 #pragma unroll
@@ -271,18 +356,17 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         }
         Lnm = positive(v) * lsm_sqrt(gp) + negative(v) * lsm_sqrt(gm);
 #else
-        const int flip = v > 0 ? 0 : (int)0x80000000;
+        const double sg = v > 0 ? 1.0 : -1.0;
         double g2 = 0.0;
 #pragma unroll
-        for (int d = 0; d < NDIM; ++d) g2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
+        for (int d = 0; d < NDIM; ++d) g2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
         Lnm = v * fast_norm(g2);
 #endif
     }
 
     // ---- CurvatureTerm: b κ |∇ϕ| — src/levelsetterms.jl:111-121, src/levelsetops.jl:197-244
     if constexpr (CURV) {
-        double bb[3];
-        coeff_eval<NDIM, 1>(a.curv, a, pre_curv, io.gim, io.plane_off, io.ocold, bb);
+        const double bb[1] = {op.bcurv};
         double gr[3] = {0, 0, 0}, Hd[3] = {0, 0, 0};
         double H01 = 0, H02 = 0, H12 = 0;
         auto first = [&](auto Dc) {
@@ -344,7 +428,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 
     // ---- EikonalReinitializationTerm: S (|∇ϕ| - 1) — src/levelsetterms.jl:234-265
     if constexpr (EIK != 0) {
-        const double s = EIK == 1 ? ldg(a.s0 + io.plane_off, io.ocold) : c;
+        const double s = EIK == 1 ? op.s0 : c;
 #if LSM_STRICT
         const bool vpos = s > 0;
         double mA = 0.0, mB = 0.0;
@@ -356,10 +440,10 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
         }
         const double n2 = mA + mB;
 #else
-        const int flip = s > 0 ? 0 : (int)0x80000000;
+        const double sg = s > 0 ? 1.0 : -1.0;
         double n2 = 0.0;
 #pragma unroll
-        for (int d = 0; d < NDIM; ++d) n2 += godunov_term(flip, A[d], B[d], a.inv_h2[d]);
+        for (int d = 0; d < NDIM; ++d) n2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
 #endif
 #if LSM_STRICT
         const double nrm = lsm_sqrt(n2);
@@ -382,32 +466,50 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
     }
 
     // ---- stage combination — src/timestepping.jl:129-136,147-163,172-200
-    if (!active) return;
-    // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
-    if (a.mask && !*(reinterpret_cast<const unsigned char*>(a.mask) + io.plane_off + (io.ocold >> 3))) return;
     double base;
-    if (a.base_mode == LSM_BASE_PSI) base = c;
-    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 0.25 * c;
-    else if (a.base_mode == LSM_BASE_RK3_S3)
 #if LSM_STRICT
-        base = (ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 2 * c) / 3;
+    if (a.base_mode == LSM_BASE_PSI) base = c;
+    else if (a.base_mode == LSM_BASE_RK3_S2) base = 0.75 * op.phin + 0.25 * c;
+    else if (a.base_mode == LSM_BASE_RK3_S3) base = (op.phin + 2 * c) / 3;
+    else base = op.phin;
 #else
-        base = (ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol) + 2 * c) * (1.0 / 3);
+    // FAST: the four bases as ONE expression base_a·ϕⁿ + base_b·ψ with (base_a, base_b) = (0,1), (¾,¼), (⅓,⅔), (1,0):
+    // no control flow between the loads issued before the barrier and this first use of ϕⁿ, which therefore stays
+    // BEHIND the arithmetic (the scheduling barrier pins it there) — its latency is hidden, not waited for.
+    __builtin_amdgcn_sched_barrier(0);
+    base = __builtin_fma(a.base_a, op.phin, a.base_b * c);
 #endif
-    else base = ldg(reinterpret_cast<const ST*>(a.phin) + io.plane_off, io.ocol);
-    double b2 = 0.0;
-    if (a.out2) b2 = a.out2_accum ? ldg(reinterpret_cast<const ST*>(a.out2) + io.plane_off, io.ocol) : c;
-    for (int k = 0; k < a.nterms; ++k) {
-        const int o = a.order[k];
-        double L = Ladv;
-        if (NM && o == SLOT_NM) L = Lnm;
-        if (CURV && o == SLOT_CURV) L = Lcurv;
-        if (EIK && o == SLOT_EIK) L = Leik;
-        base -= a.cdt * L;
-        b2 -= a.cdt2 * L;
+    double b2 = !PLAIN && a.out2_accum ? op.out2 : c;
+    const bool has2 = !PLAIN && a.out2 != nullptr;
+    if (PLAIN || a.natural) {
+        // the terms in slot order, each once (the usual case): no look-up of the order
+        auto acc = [&](double L) {
+            base -= a.cdt * L;
+            if (has2) b2 -= a.cdt2 * L;
+        };
+        if constexpr (ADV != 0) acc(Ladv);
+        if constexpr (NM != 0) acc(Lnm);
+        if constexpr (CURV != 0) acc(Lcurv);
+        if constexpr (EIK != 0) acc(Leik);
+    } else {
+        for (int k = 0; k < a.nterms; ++k) {
+            const int o = a.order[k];
+            double L = Ladv;
+            if (NM && o == SLOT_NM) L = Lnm;
+            if (CURV && o == SLOT_CURV) L = Lcurv;
+            if (EIK && o == SLOT_EIK) L = Leik;
+            base -= a.cdt * L;
+            b2 -= a.cdt2 * L;
+        }
     }
-    stg(reinterpret_cast<ST*>(a.out) + io.plane_off, io.ocol, base);
-    if (a.out2) stg(reinterpret_cast<ST*>(a.out2) + io.plane_off, io.ocol, b2);
+    r_out = base;
+    r_out2 = b2;
+}
+template <class ST, bool PLAIN>
+LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_out, double r_out2) {
+    if (!on) return;
+    stg(uniform_ptr(reinterpret_cast<ST*>(a.out) + io.plane_off), io.ocol, r_out);
+    if (!PLAIN && a.out2) stg(uniform_ptr(reinterpret_cast<ST*>(a.out2) + io.plane_off), io.ocol, r_out2);
 }
 
 #ifndef LSM_WAVES_PER_EU
@@ -418,8 +520,10 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeIO& io, con
 #else
 #define LSM_BARRIER() __syncthreads()
 #endif
-template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST>
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK>
 __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const StageArgs a) {
+    constexpr bool PLAIN = AK >= 0;
+    constexpr int CK = PLAIN ? (int)LSM_COEFF_CONST : -1;   // kind of the NormalMotion / curvature coefficients
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
     constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
     constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
@@ -474,7 +578,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
-    auto plane = [&](int p) { return reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm); };
+    auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
 
     // halo elements owned by this thread: LDS offset within a plane, global offset within a plane
     int hl[HPT > 0 ? HPT : 1];
@@ -504,6 +608,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         }
         hl[h] = ly * W + lx;
         hg[h] = (unsigned)sizeof(ST) * ((unsigned)(X + G) + (unsigned)(Y + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
+        if (!hv[h]) hg[h] = LSM_OOB_OFFSET;   // beyond the descriptor's range: the buffer load returns 0 and touches no memory
     }
     const int lpos = (ty + (HAS_Y ? G : 0)) * W + tx + G;
 
@@ -511,22 +616,29 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
     {
         const int gi0 = cx + a.goff[0], gi1 = HAS_Y ? cy + a.goff[1] : 0;
-        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED>(a.adv, a, gi0, gi1, pre_adv);
-        if constexpr (NM != 0) coeff_prep<NDIM, 1>(a.nm, a, gi0, gi1, pre_nm);
-        if constexpr (CURV != 0) coeff_prep<NDIM, 1>(a.curv, a, gi0, gi1, pre_curv);
+        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, gi0, gi1, pre_adv);
+        if constexpr (NM != 0) coeff_prep<NDIM, 1, false, CK>(a.nm, a, gi0, gi1, pre_nm);
+        if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, CK>(a.curv, a, gi0, gi1, pre_curv);
     }
 
     if constexpr (!MARCH) {
         const ST* P = plane(0);
         const double c = ldg(P, ocol);
+        const NodeIO io{corner, ocol, ocold, 0};
+        NodeOps op;
+        PlaneTab pt;
+        plane_tab<NDIM, ADV, NM, CURV, AK>(a, 0, pt);
+        node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
         tile[lpos] = c;
 #pragma unroll
         for (int h = 0; h < HPT; ++h)
             if (hv[h]) tile[hl[h]] = ldg(P, hg[h]);
         __syncthreads();
         NodeView<NDIM, G, W> nv{tile + lpos, nullptr, nullptr, nullptr, c};
-        const NodeIO io{corner, ocol, ocold, 0};
-        node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
+        double r1, r2;
+        node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, PLAIN>(a, nv, op, r1, r2);
+        // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
+        node_store<ST, PLAIN>(a, io, active && (PLAIN || !a.mask || ldg_u8(uniform_ptr(a.mask + corner), ocold >> 3, (int)0x80000000u) != 0), r1, r2);
     } else {
         double zl[2 * G + 1];
 #pragma unroll
@@ -540,34 +652,61 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) tile[slot * HW + hl[h]] = ldg(P, hg[h]);
         }
+        PlaneTab pt;
+        plane_tab<NDIM, ADV, NM, CURV, AK>(a, m0 + a.goff[NDIM - 1], pt);
+        // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices).  The mask byte
+        // of a plane is fetched one plane ahead, unconditionally: without a mask the descriptor's range is 0 and the
+        // load returns 0 without an access (a load inside a branch would cost the loop its exact wait counts).
+        const bool nomask = PLAIN || a.mask == nullptr;
+        const int mrange = nomask ? 0 : (int)0x80000000u;
+        long long po = corner + (long long)m0 * sm;     // plane m of the pointwise operands (ϕⁿ, outputs, mask, side arrays)
+        unsigned mk_next = 0;
+        if constexpr (!PLAIN) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
+        const ST* Pnx = plane(m0 + G);                  // plane m+G of ψ, advanced (and clamped) before each use
+        const ST* Pn = plane(m0 + LEAD);
+        const int plast = nm + G - 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
 #ifdef LSM_UNROLL_M
 #pragma unroll LSM_UNROLL_M
 #endif
         for (int m = m0; m < m1; ++m) {
-            // issue the next plane's global loads early; they land in LDS after this plane's arithmetic
-            const double nxt = ldg(plane(m + 1 + G), ocol);
+            // issue the next plane's loads early; they land in LDS after this plane's arithmetic
+            Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
+            Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
+            const double nxt = ldg(Pnx, ocol);
             double hn[HPT > 0 ? HPT : 1];
-            const ST* Pn = plane(m + 1 + LEAD);
 #pragma unroll
-            for (int h = 0; h < HPT; ++h)
-                if (hv[h]) hn[h] = ldg(Pn, hg[h]);
+            for (int h = 0; h < HPT; ++h) hn[h] = ldg(Pn, hg[h]);   // lanes without a halo element: out-of-range offset, no access
+            const unsigned mk = mk_next;
+            if constexpr (!PLAIN) mk_next = ldg_u8(uniform_ptr(a.mask + (po + sm)), ocold >> 3, mrange);
+            // this plane's pointwise operands (coefficients, ϕⁿ): consumed after the arithmetic
+            const NodeIO io{po, ocol, ocold, m + a.goff[NDIM - 1]};
+            NodeOps op;
+            node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
             LSM_BARRIER();
-            const int rel = m - m0;
-            const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
-            const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
-            const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
-            NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
-            const NodeIO io{corner + (long long)m * sm, ocol, ocold, m + a.goff[NDIM - 1]};
-            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST>(a, nv, io, pre_adv, pre_nm, pre_curv, active);
+            const bool on = active && (nomask || mk != 0);
+            double r1 = 0.0, r2 = 0.0;
+            if (__builtin_amdgcn_ballot_w64(on) != 0) {   // a wave without a node to update skips the arithmetic (band mode)
+                const int rel = m - m0;
+                const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
+                const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
+                const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
+                NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
+                node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, PLAIN>(a, nv, op, r1, r2);
+            }
+            // next plane's table entries: scalar loads, issued behind the LDS reads (they share a counter with them)
+            plane_tab<NDIM, ADV, NM, CURV, AK>(a, (m + 1 < m1 ? m + 1 : m) + a.goff[NDIM - 1], pt);
             // shift the register line, write the next plane to its ring slot
 #pragma unroll
             for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
             zl[2 * G] = nxt;
-            const int wslot = (rel + 1 + 2 * LEAD) % NSLOT;
+            const int wslot = (m - m0 + 1 + 2 * LEAD) % NSLOT;
             tile[wslot * HW + lpos] = zl[G + LEAD];
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];
+            node_store<ST, PLAIN>(a, io, on, r1, r2);
+            po += sm;
         }
     }
 }
@@ -609,8 +748,25 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
-    if (b.f32) hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, float>), grid, block, 0, s, b);
-    else hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, double>), grid, block, 0, s, b);
+    // plain variant (see plane_tab): dense field, one output, terms in slot order, constant speed / curvature
+    // coefficients, and a catalogued advection coefficient
+#if !LSM_STRICT
+    int ak = -1;
+    const bool plain = !b.mask && !b.out2 && b.natural && (!NM || b.nm.kind == LSM_COEFF_CONST) && (!CURV || b.curv.kind == LSM_COEFF_CONST) &&
+                       !getenv("LSM_STAGE_GENERIC");
+    if (plain) ak = ADV ? b.adv.kind : (int)LSM_COEFF_CONST;
+    if (ak == LSM_COEFF_FIELD) ak = -1;
+#endif
+#define LSM_LAUNCH(STT, AKK) hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, STT, AKK>), grid, block, 0, s, b)
+#if LSM_STRICT
+    if (b.f32) LSM_LAUNCH(float, -1); else LSM_LAUNCH(double, -1);
+#else
+    if (ak == LSM_COEFF_CONST) { if (b.f32) LSM_LAUNCH(float, LSM_COEFF_CONST); else LSM_LAUNCH(double, LSM_COEFF_CONST); }
+    else if (ADV && ak == LSM_COEFF_ROTATION) { if (b.f32) LSM_LAUNCH(float, (ADV ? (int)LSM_COEFF_ROTATION : 0)); else LSM_LAUNCH(double, (ADV ? (int)LSM_COEFF_ROTATION : 0)); }
+    else if (ADV && ak == LSM_COEFF_SEPARABLE) { if (b.f32) LSM_LAUNCH(float, (ADV ? (int)LSM_COEFF_SEPARABLE : 0)); else LSM_LAUNCH(double, (ADV ? (int)LSM_COEFF_SEPARABLE : 0)); }
+    else { if (b.f32) LSM_LAUNCH(float, -1); else LSM_LAUNCH(double, -1); }
+#endif
+#undef LSM_LAUNCH
 }
 
 // the instantiated fused combinations (keep in sync with combo_available in lsm_api.hip)

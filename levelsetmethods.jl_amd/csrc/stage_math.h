@@ -122,7 +122,9 @@ LSM_DEV double lsm_sqrt(double x0) {
 // returning h·(reference value), in the second-difference form
 //     Σ ω_k dϕ_k = dϕ₂ + (ω₁/3)(A₁-A₂) + (ω₃/6)(A₂-A₃),   A_k = e_k - 2e_{k+1} + e_{k+2},
 // (algebraically identical to src/derivatives.jl:63-80 because Σω = 1), with the three weights from
-// ONE reciprocal: ω_k ∝ c_k Π_{j≠k} (S_j+ε)².  eps_floor = 1e-99·h².
+// ONE reciprocal: ω_k ∝ c_k Π_{j≠k} (S_j+ε)².  eps_floor = 1e-99·h², raised to 1e-75: the reference's
+// 1e-99 floor only matters for differences below ~1e-49·h; raising it to 1e-75 changes results only for differences
+// below ~3e-35 (by less than their own size) and spares the guard against a vanishing denominator.
 // With PQ, the second-order ENO pair of the same line (eno2_pair below) is returned as well, in the
 // upwind frame of the stencil: P = e3 + ½·minmod(w2, w3), Q = e4 - ½·minmod(w4, w3) — the differences
 // it needs are exactly e3, e4, w2, w3, w4.  In the flipped frame (P, Q) = (-B, -A), which the Godunov
@@ -133,8 +135,10 @@ template <bool PQ>
 LSM_DEV double weno5_undivided_pq(double e1, double e2, double e3, double e4, double e5, double eps_floor, double& P, double& Q) {
     const double w1 = e2 - e1, w2 = e3 - e2, w3 = e4 - e3, w4 = e5 - e4;
     if constexpr (PQ) {
-        P = __builtin_fma(0.5, minmod_fast(w2, w3), e3);
-        Q = __builtin_fma(-0.5, minmod_fast(w4, w3), e4);
+        // minmod(x, w3) = clamp of x to the interval between 0 and w3: the two share max(w3,0), min(w3,0)
+        const double hi = __builtin_fmax(w3, 0.0), lo = __builtin_fmin(w3, 0.0);
+        P = __builtin_fma(0.5, __builtin_fmax(__builtin_fmin(w2, hi), lo), e3);
+        Q = __builtin_fma(-0.5, __builtin_fmax(__builtin_fmin(w4, hi), lo), e4);
     }
     const double A1 = w2 - w1, A2 = w3 - w2, A3 = w4 - w3;
     const double B1 = __builtin_fma(2.0, w2, A1);      // e1 - 4e2 + 3e3
@@ -144,15 +148,16 @@ LSM_DEV double weno5_undivided_pq(double e1, double e2, double e3, double e4, do
                                                    __builtin_fmax(__builtin_fabs(e3), __builtin_fabs(e4))),
                                     __builtin_fabs(e5));
     // S_k + ε scaled by 12/13 (the weights only see ratios): A² + (3/13)·B² + (12/13)·ε — one multiply less per k
-    const double eps = __builtin_fma((12.0 / 13) * 1.0e-6 * m, m, eps_floor);
+    const double eps = __builtin_fma((12.0 / 13) * 1.0e-6 * m, m, __builtin_fmax(eps_floor, 1.0e-75));   // the max is loop-invariant
     const double r1 = __builtin_fma(A1, A1, __builtin_fma((3.0 / 13) * B1, B1, eps));
     const double r2 = __builtin_fma(A2, A2, __builtin_fma((3.0 / 13) * B2, B2, eps));
     const double r3 = __builtin_fma(A3, A3, __builtin_fma((3.0 / 13) * B3, B3, eps));
     const double s1 = r1 * r1, s2 = r2 * r2, s3 = r3 * r3;
     const double W1 = s2 * s3, W2 = s1 * s3, W3 = s1 * s2;   // ∝ α_k / c_k
     const double c1W1 = (0.1 / 3) * W1, c3W3 = (0.3 / 6) * W3;
-    double den = __builtin_fma(3.0, c1W1, __builtin_fma(6.0, c3W3, 0.6 * W2));   // 0.1 W1 + 0.6 W2 + 0.3 W3
-    den = __builtin_fmax(den, 1.0e-300);                      // exactly flat data: 0·(1/tiny) = 0, as the reference
+    // 0.1 W1 + 0.6 W2 + 0.3 W3 > 0: eps_floor >= 1e-75 keeps every r_k >= 1e-75 and the products >= 1e-302
+    // (exactly flat data gives 0·(1/den) = 0, as the reference)
+    const double den = __builtin_fma(3.0, c1W1, __builtin_fma(6.0, c3W3, 0.6 * W2));
     const double rc = fast_rcp(den);
     const double dphi2 = __builtin_fma(-1.0 / 6, e2, __builtin_fma(5.0 / 6, e3, (1.0 / 3) * e4));
     const double X = __builtin_fma(c1W1, A1 - A2, c3W3 * (A2 - A3));
@@ -195,13 +200,11 @@ LSM_DEV void godunov_sel(bool vpos, double A, double B, double& a2, double& b2) 
     b2 = b * b;
 }
 #else
-// flip the operands' sign bit instead of selecting (negative(A)² == positive(-A)²); A,B undivided,
-// returns inv_h2·(a² + b²)
-LSM_DEV double godunov_term(int flip, double A, double B, double inv_h2) {
-    const double As = __hiloint2double(__double2hiint(A) ^ flip, __double2loint(A));
-    const double Bs = __hiloint2double(__double2hiint(B) ^ flip, __double2loint(B));
-    const double a = __builtin_fmax(As, 0.0);
-    const double b = __builtin_fmin(Bs, 0.0);
+// multiply the operands by sg = ±1 instead of selecting (negative(A)² == positive(-A)²; a sign-bit XOR costs the same
+// issue slot and makes the compiler canonicalise the result before the max/min); A,B undivided, returns inv_h2·(a² + b²)
+LSM_DEV double godunov_term(double sg, double A, double B, double inv_h2) {
+    const double a = __builtin_fmax(sg * A, 0.0);
+    const double b = __builtin_fmin(sg * B, 0.0);
     return __builtin_fma(a, a, b * b) * inv_h2;
 }
 #endif
