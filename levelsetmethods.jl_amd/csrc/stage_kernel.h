@@ -246,25 +246,56 @@ struct NodeView {
 LSM_DEV double sel64(int m, double x, double y) {   // m = all-ones ? x : y
     return __hiloint2double((__double2hiint(x) & m) | (__double2hiint(y) & ~m), (__double2loint(x) & m) | (__double2loint(y) & ~m));
 }
+// Almost every wave sees ONE sign of u_d (the sign changes on a few surfaces of the domain): such a wave branches
+// (scalar) to a version with the stencil direction fixed at compile time — LDS reads at immediate offsets from one
+// address register, the march line used in place — and only waves that straddle a sign change run the version that
+// selects per lane (≈9 integer/select instructions per dimension).  All three evaluate the same expression.
+#ifndef LSM_NO_UNIFORM_PATHS
+#define LSM_UNIFORM_PATHS 1
+#else
+#define LSM_UNIFORM_PATHS 0
+#endif
 template <int NDIM, int D, int G, int W, bool PQ, class NV>
 LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, double& P, double& Q) {
-    const int m = ~(__double2hiint(v) >> 31);   // all ones when the sign bit of u_d is clear
-    double q[6];
-    if constexpr (D == 0 || (D == 1 && NDIM == 3)) {
-        constexpr int st = D == 0 ? 1 : W;
-        const int ss = (st & m) | (-st & ~m);
-        q[0] = nv.T0[-3 * ss]; q[1] = nv.T0[-2 * ss]; q[2] = nv.T0[-ss];
-        q[3] = nv.c;
-        q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
+    const double epsf = 1.0e-99 * a.h2[D];
+    auto lds = [&](auto Sc) {            // x / y neighbours, direction Sc::value = ±1 at compile time
+        constexpr int ss = (D == 0 ? 1 : W) * decltype(Sc)::value;
+        const double q0 = nv.T0[-3 * ss], q1 = nv.T0[-2 * ss], q2 = nv.T0[-ss], q4 = nv.T0[ss], q5 = nv.T0[2 * ss];
+        return weno5_undivided_pq<PQ>(q1 - q0, q2 - q1, nv.c - q2, q4 - nv.c, q5 - q4, epsf, P, Q);
+    };
+    auto reg = [&](auto Sc) {            // march-axis neighbours from the register line
+        constexpr int ss = decltype(Sc)::value;
+        return weno5_undivided_pq<PQ>(nv.zl[G - 2 * ss] - nv.zl[G - 3 * ss], nv.zl[G - ss] - nv.zl[G - 2 * ss], nv.c - nv.zl[G - ss],
+                                      nv.zl[G + ss] - nv.c, nv.zl[G + 2 * ss] - nv.zl[G + ss], epsf, P, Q);
+    };
+    constexpr bool IN_LDS = D == 0 || (D == 1 && NDIM == 3);
+    double w;
+    const unsigned long long negs = __builtin_amdgcn_ballot_w64(__double2hiint(v) < 0);
+    if (LSM_UNIFORM_PATHS && negs == 0) {
+        if constexpr (IN_LDS) w = lds(std::integral_constant<int, 1>{});
+        else w = reg(std::integral_constant<int, 1>{});
+    } else if (LSM_UNIFORM_PATHS && negs == __builtin_amdgcn_ballot_w64(true)) {
+        if constexpr (IN_LDS) w = lds(std::integral_constant<int, -1>{});
+        else w = reg(std::integral_constant<int, -1>{});
     } else {
-        q[0] = sel64(m, nv.zl[G - 3], nv.zl[G + 3]);
-        q[1] = sel64(m, nv.zl[G - 2], nv.zl[G + 2]);
-        q[2] = sel64(m, nv.zl[G - 1], nv.zl[G + 1]);
-        q[3] = nv.c;
-        q[4] = sel64(m, nv.zl[G + 1], nv.zl[G - 1]);
-        q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
+        const int m = ~(__double2hiint(v) >> 31);   // all ones when the sign bit of u_d is clear
+        double q[6];
+        if constexpr (IN_LDS) {
+            constexpr int st = D == 0 ? 1 : W;
+            const int ss = (st & m) | (-st & ~m);
+            q[0] = nv.T0[-3 * ss]; q[1] = nv.T0[-2 * ss]; q[2] = nv.T0[-ss];
+            q[3] = nv.c;
+            q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
+        } else {
+            q[0] = sel64(m, nv.zl[G - 3], nv.zl[G + 3]);
+            q[1] = sel64(m, nv.zl[G - 2], nv.zl[G + 2]);
+            q[2] = sel64(m, nv.zl[G - 1], nv.zl[G + 1]);
+            q[3] = nv.c;
+            q[4] = sel64(m, nv.zl[G + 1], nv.zl[G - 1]);
+            q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
+        }
+        w = weno5_undivided_pq<PQ>(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], epsf, P, Q);
     }
-    const double w = weno5_undivided_pq<PQ>(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], 1.0e-99 * a.h2[D], P, Q);
     return __builtin_fabs(v) * w;          // v = u_d/h_d
 }
 #endif
@@ -440,10 +471,21 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
         }
         const double n2 = mA + mB;
 #else
-        const double sg = s > 0 ? 1.0 : -1.0;
         double n2 = 0.0;
+        // the sign of ϕ is the same across most waves (away from the interface): a scalar branch to the version
+        // without the sign factor
+        const unsigned long long poss = __builtin_amdgcn_ballot_w64(s > 0);
+        if (LSM_UNIFORM_PATHS && poss == __builtin_amdgcn_ballot_w64(true)) {
 #pragma unroll
-        for (int d = 0; d < NDIM; ++d) n2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
+            for (int d = 0; d < NDIM; ++d) n2 += godunov_pos(A[d], B[d], a.inv_h2[d]);
+        } else if (LSM_UNIFORM_PATHS && poss == 0) {
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) n2 += godunov_pos(-A[d], -B[d], a.inv_h2[d]);   // min(A,0)² + max(B,0)²: the negations fold into the operands
+        } else {
+            const double sg = s > 0 ? 1.0 : -1.0;
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) n2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
+        }
 #endif
 #if LSM_STRICT
         const double nrm = lsm_sqrt(n2);
@@ -665,6 +707,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         const ST* Pnx = plane(m0 + G);                  // plane m+G of ψ, advanced (and clamped) before each use
         const ST* Pn = plane(m0 + LEAD);
         const int plast = nm + G - 1;
+        const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
 #ifdef LSM_UNROLL_M
 #pragma unroll LSM_UNROLL_M
@@ -686,7 +729,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             LSM_BARRIER();
             const bool on = active && (nomask || mk != 0);
             double r1 = 0.0, r2 = 0.0;
-            if (__builtin_amdgcn_ballot_w64(on) != 0) {   // a wave without a node to update skips the arithmetic (band mode)
+            if (PLAIN ? any_active : __builtin_amdgcn_ballot_w64(on) != 0) {   // a wave without a node to update skips the arithmetic (band mode)
                 const int rel = m - m0;
                 const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
                 const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;

@@ -207,6 +207,12 @@ LSM_DEV double godunov_term(double sg, double A, double B, double inv_h2) {
     const double b = __builtin_fmin(sg * B, 0.0);
     return __builtin_fma(a, a, b * b) * inv_h2;
 }
+// the same for sg = +1: max(A,0)² + min(B,0)²
+LSM_DEV double godunov_pos(double A, double B, double inv_h2) {
+    const double a = __builtin_fmax(A, 0.0);
+    const double b = __builtin_fmin(B, 0.0);
+    return __builtin_fma(a, a, b * b) * inv_h2;
+}
 #endif
 
 }  // namespace LSM_NS
