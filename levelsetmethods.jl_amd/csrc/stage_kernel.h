@@ -60,14 +60,14 @@ LSM_DEV double ld_uniform(const double* t, int i) {
 // ST is the storage type of the field (double, or float for LSM_DTYPE_F32: values widen exactly on load,
 // all arithmetic is fp64, the result is rounded to nearest on store).
 typedef unsigned lsm_v2u __attribute__((ext_vector_type(2)));
-LSM_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+LSM_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, int range = (int)0x80000000u) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, range, 0x00020000);
 }
 constexpr unsigned LSM_OOB_OFFSET = 0xC0000000u;
 template <class ST>
-LSM_DEV double ldg(const ST* base, unsigned boff) {
-    if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base), boff, 0, 0));
-    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base), boff, 0, 0));
+LSM_DEV double ldg(const ST* base, unsigned boff, int range = (int)0x80000000u) {   // range 0: returns 0, no access
+    if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base, range), boff, 0, 0));
+    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base, range), boff, 0, 0));
 }
 template <class ST>
 LSM_DEV void stg(ST* base, unsigned boff, double v) {
@@ -205,7 +205,10 @@ LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pr
         op.bcurv = bb[0];
     }
     if constexpr (EIK == 1) op.s0 = ldg(uniform_ptr(a.s0 + io.plane_off), io.ocold);
-    op.phin = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol);   // = ψ when the base is ψ (launcher)
+    // always issued (a load inside a branch costs the loop its exact wait counts); when the base is ψ the
+    // descriptor's range is 0: the load returns 0 and touches no memory
+    op.phin = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol,
+                  __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u));
     if (AK < 0 && a.out2 && a.out2_accum) op.out2 = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.out2) + io.plane_off), io.ocol);
 }
 
@@ -387,10 +390,19 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
         }
         Lnm = positive(v) * lsm_sqrt(gp) + negative(v) * lsm_sqrt(gm);
 #else
-        const double sg = v > 0 ? 1.0 : -1.0;
         double g2 = 0.0;
+        const unsigned long long vpos = __builtin_amdgcn_ballot_w64(v > 0);   // one sign per wave is the rule (constant speeds)
+        if (LSM_UNIFORM_PATHS && vpos == __builtin_amdgcn_ballot_w64(true)) {
 #pragma unroll
-        for (int d = 0; d < NDIM; ++d) g2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
+            for (int d = 0; d < NDIM; ++d) g2 += godunov_pos(A[d], B[d], a.inv_h2[d]);
+        } else if (LSM_UNIFORM_PATHS && vpos == 0) {
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) g2 += godunov_neg(A[d], B[d], a.inv_h2[d]);
+        } else {
+            const double sg = v > 0 ? 1.0 : -1.0;
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) g2 += godunov_term(sg, A[d], B[d], a.inv_h2[d]);
+        }
         Lnm = v * fast_norm(g2);
 #endif
     }
@@ -480,7 +492,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
             for (int d = 0; d < NDIM; ++d) n2 += godunov_pos(A[d], B[d], a.inv_h2[d]);
         } else if (LSM_UNIFORM_PATHS && poss == 0) {
 #pragma unroll
-            for (int d = 0; d < NDIM; ++d) n2 += godunov_pos(-A[d], -B[d], a.inv_h2[d]);   // min(A,0)² + max(B,0)²: the negations fold into the operands
+            for (int d = 0; d < NDIM; ++d) n2 += godunov_neg(A[d], B[d], a.inv_h2[d]);
         } else {
             const double sg = s > 0 ? 1.0 : -1.0;
 #pragma unroll

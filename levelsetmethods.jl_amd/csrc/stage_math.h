@@ -207,10 +207,19 @@ LSM_DEV double godunov_term(double sg, double A, double B, double inv_h2) {
     const double b = __builtin_fmin(sg * B, 0.0);
     return __builtin_fma(a, a, b * b) * inv_h2;
 }
-// the same for sg = +1: max(A,0)² + min(B,0)²
-LSM_DEV double godunov_pos(double A, double B, double inv_h2) {
-    const double a = __builtin_fmax(A, 0.0);
-    const double b = __builtin_fmin(B, 0.0);
+// the same with the sign fixed.  max/min against 0 through the instruction itself: A and B reach this point from
+// another basic block (the WENO variants), where the compiler no longer knows them to be canonical and would put a
+// v_max_f64 x,x,x in front of every __builtin_fmax/fmin (one issue slot each, six per node).
+LSM_DEV double vmax0(double x) { double r; asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x)); return r; }
+LSM_DEV double vmin0(double x) { double r; asm("v_min_f64 %0, %1, 0" : "=v"(r) : "v"(x)); return r; }
+LSM_DEV double godunov_pos(double A, double B, double inv_h2) {   // max(A,0)² + min(B,0)²
+    const double a = vmax0(A);
+    const double b = vmin0(B);
+    return __builtin_fma(a, a, b * b) * inv_h2;
+}
+LSM_DEV double godunov_neg(double A, double B, double inv_h2) {   // min(A,0)² + max(B,0)²
+    const double a = vmin0(A);
+    const double b = vmax0(B);
     return __builtin_fma(a, a, b * b) * inv_h2;
 }
 #endif
