@@ -197,9 +197,10 @@ def main():
         out["roofline"]["traffic_source"] = "profiles/r1/pmc_per_dispatch.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> B, per 512^3 launch)"
     except Exception:
         pass
-    # the binding resource is the fp64 vector pipe: ~250 fp64 VALU instructions per node-stage, of which 75 are
-    # FMAs: 320 flop (opcode histogram of the loop body, tools/isa_hist.py)
-    flop_per_node_stage = 320.0
+    # the binding resource is the fp64 vector pipe: 239 VALU instructions per node-stage (SQ_INSTS_VALU), ≈225 of
+    # them fp64 arithmetic, 72 of those FMAs: ≈294 flop (per-block opcode counts of the wave-uniform path,
+    # tools/isa_blocks.py)
+    flop_per_node_stage = 294.0
     out["fp64_vector"] = {"achieved_tflops": round(local_cells * 3 * args.steps * flop_per_node_stage / (stage_ms * 1e-3) / 1e12, 2)
                           if n_launch else 0.0, "peak_tflops": FP64_PEAK_TFLOPS,
                           "note": "algorithmic flop estimate from the ISA of the fused stage kernel (DESIGN.md §3.1)"}

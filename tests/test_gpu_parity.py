@@ -170,6 +170,39 @@ def test_separable_and_field_coefficients(hip, orc):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(300,), (270, 40), (70, 21, 45)])
+def test_plain_and_general_kernel_variants_agree(hip, orc, shape, monkeypatch):
+    """FAST mode launches a compile-time 'plain' variant of the stage kernel when the call allows it (dense field, one
+    output, terms in slot order, catalogued coefficients) and the general variant otherwise (LSM_STAGE_GENERIC=1
+    forces it).  Both evaluate the same expressions: results must agree to rounding, and each with the oracle.  The
+    fields change sign of u_d and of ϕ inside waves and keep it across others, so the wave-uniform sign paths and the
+    per-lane path are both exercised."""
+    nd = len(shape)
+    c = hip.Case(shape, "neumann", lc=(0.0,) * nd, hc=(1.0,) * nd, mode="fast")
+    coords = c.grid.coords()
+    s2 = lambda a: np.sin(np.pi * a) * np.sin(np.pi * a)
+    s = lambda a: np.sin(2 * np.pi * a)
+    tables = [[(2 * s2(x) if k == d else (-1) ** d * s(x)) for k, x in enumerate(coords)] for d in range(nd)]
+    phi = _rand_field(shape, 12)
+    cases = [[("adv", ("sep", tables, ("cos", 3.0)), "weno5"), ("eik", None)],
+             [("adv", ("const", (0.7, -0.4, 0.9)[:nd]), "weno5"), ("nm", ("const", (-0.3,)))],
+             [("nm", ("const", (0.2,))), ("curv", ("const", (-0.05,)))],
+             [("adv", ("const", (0.7, -0.4, 0.9)[:nd]), "upwind")]]
+    if nd >= 2:
+        cases.append([("adv", ("rot", 1.3, 0.45, 0.55), "weno5"), ("eik", phi)])
+    for specs in cases:
+        for base_mode in (0, 1, 2, 3):
+            monkeypatch.delenv("LSM_STAGE_GENERIC", raising=False)
+            plain, want, _, _ = _run_stage(c, orc, specs, phi, base_mode, t=0.4)
+            monkeypatch.setenv("LSM_STAGE_GENERIC", "1")
+            general, _, _, _ = _run_stage(c, orc, specs, phi, base_mode, t=0.4)
+            monkeypatch.delenv("LSM_STAGE_GENERIC", raising=False)
+            scale = np.abs(want).max()
+            assert np.abs(plain - want).max() <= TOL_STAGE * scale, (specs[0][:1], base_mode, np.abs(plain - want).max())
+            assert np.abs(general - want).max() <= TOL_STAGE * scale, (specs[0][:1], base_mode, np.abs(general - want).max())
+            assert np.abs(plain - general).max() <= 4e-16 * scale, (specs[0][:1], base_mode, np.abs(plain - general).max())
+
+
 @pytest.mark.parametrize("shape", [(50,), (40, 30), (20, 18, 16)])
 def test_cfl_bitwise(hip, orc, shape):
     from lsm_amd import _lib as L
