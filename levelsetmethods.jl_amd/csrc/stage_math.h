@@ -159,7 +159,7 @@ LSM_DEV double weno5_undivided_pq(double e1, double e2, double e3, double e4, do
     // (exactly flat data gives 0·(1/den) = 0, as the reference)
     const double den = __builtin_fma(3.0, c1W1, __builtin_fma(6.0, c3W3, 0.6 * W2));
     const double rc = fast_rcp(den);
-    const double dphi2 = __builtin_fma(-1.0 / 6, e2, __builtin_fma(5.0 / 6, e3, (1.0 / 3) * e4));
+    const double dphi2 = __builtin_fma(1.0 / 3, w3, __builtin_fma(1.0 / 6, w2, e3));   // (-e2 + 5 e3 + 2 e4)/6 = e3 + w3/3 + w2/6
     const double X = __builtin_fma(c1W1, A1 - A2, c3W3 * (A2 - A3));
     return __builtin_fma(rc, X, dphi2);
 }
