@@ -187,12 +187,17 @@ struct NodeOps {
     double s0;       // Eikonal frozen sign
     double phin;     // ϕⁿ (or the accumulator of a multi-pass stage)
     double out2;     // previous value of the second output
+    // plain variants with a catalogued advection coefficient: the lanes with the sign bit of u_d set, known without a
+    // per-plane compare — sign(pre_d·table entry) = sign(pre_d) xor sign(entry), pre_d fixed along the march axis
+    bool have_negs;
+    unsigned long long negs[3];
 };
 template <int NDIM, int ADV, int NM, int CURV, int EIK, class ST, int AK>
 LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pre_adv[3], const double pre_nm[3],
                            const double pre_curv[3], const PlaneTab& pt, NodeOps& op) {
     op.u[0] = op.u[1] = op.u[2] = 0.0;
     op.vnm = op.bcurv = op.s0 = op.phin = op.out2 = 0.0;
+    op.have_negs = false;
     if constexpr (ADV != 0) coeff_eval<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, pre_adv, pt.adv, io.gim, io.plane_off, io.ocold, op.u);   // FAST: u_d/h_d
     if constexpr (NM != 0) {
         double vv[3];
@@ -259,7 +264,7 @@ LSM_DEV double sel64(int m, double x, double y) {   // m = all-ones ? x : y
 #define LSM_UNIFORM_PATHS 0
 #endif
 template <int NDIM, int D, int G, int W, bool PQ, class NV>
-LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, double& P, double& Q) {
+LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, bool have_negs, unsigned long long negs_known, double& P, double& Q) {
     const double epsf = 1.0e-99 * a.h2[D];
     auto lds = [&](auto Sc) {            // x / y neighbours, direction Sc::value = ±1 at compile time
         constexpr int ss = (D == 0 ? 1 : W) * decltype(Sc)::value;
@@ -273,7 +278,7 @@ LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, double& P, 
     };
     constexpr bool IN_LDS = D == 0 || (D == 1 && NDIM == 3);
     double w;
-    const unsigned long long negs = __builtin_amdgcn_ballot_w64(__double2hiint(v) < 0);
+    const unsigned long long negs = have_negs ? negs_known : __builtin_amdgcn_ballot_w64(__double2hiint(v) < 0);
     if (LSM_UNIFORM_PATHS && negs == 0) {
         if constexpr (IN_LDS) w = lds(std::integral_constant<int, 1>{});
         else w = reg(std::integral_constant<int, 1>{});
@@ -349,7 +354,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
 #if LSM_STRICT
                 der = weno_dim<NDIM, D, G, W>(nv, a, v);
 #else
-                return weno_term<NDIM, D, G, W, ENO_FROM_WENO>(nv, a, v, A[D], B[D]);
+                return weno_term<NDIM, D, G, W, ENO_FROM_WENO>(nv, a, v, op.have_negs, op.negs[D], A[D], B[D]);
 #endif
             } else {
 #if LSM_STRICT
@@ -720,6 +725,14 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         const ST* Pn = plane(m0 + LEAD);
         const int plast = nm + G - 1;
         const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
+        // sign bits of the march-invariant parts of u_d (plain variants; see NodeOps::negs)
+        constexpr bool SIGNS_KNOWN = PLAIN && ADV == 2 && AK != LSM_COEFF_FIELD && !LSM_STRICT;
+        unsigned long long neg_pre[3] = {0, 0, 0};
+        const unsigned long long all_lanes = __builtin_amdgcn_ballot_w64(true);
+        if constexpr (SIGNS_KNOWN) {
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) neg_pre[d] = __builtin_amdgcn_ballot_w64(__double2hiint(pre_adv[d]) < 0);
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
 #ifdef LSM_UNROLL_M
 #pragma unroll LSM_UNROLL_M
@@ -738,6 +751,17 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             const NodeIO io{po, ocol, ocold, m + a.goff[NDIM - 1]};
             NodeOps op;
             node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
+            if constexpr (SIGNS_KNOWN) {
+                op.have_negs = true;
+#pragma unroll
+                for (int d = 0; d < NDIM; ++d) {
+                    // CONST, ROTATION (3-D): u_d = pre_d; ROTATION (2-D) dimension 0 is recomputed per plane (not known
+                    // here); SEPARABLE: u_d = pre_d · entry of the march-axis table (wave-uniform)
+                    if (AK == LSM_COEFF_SEPARABLE) op.negs[d] = neg_pre[d] ^ (__double2hiint(pt.adv[d]) < 0 ? all_lanes : 0ull);
+                    else op.negs[d] = neg_pre[d];
+                }
+                if (AK == LSM_COEFF_ROTATION) op.have_negs = NDIM == 3;
+            }
             LSM_BARRIER();
             const bool on = active && (nomask || mk != 0);
             double r1 = 0.0, r2 = 0.0;
