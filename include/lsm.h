@@ -216,6 +216,18 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
                              void* work2, void* work3, int nb_iters, double cfl, double interface_band,
                              double min_norm);
 
+/* ---- curvature(ϕ, I), gradient(ϕ, I), normal(ϕ, I) (src/levelsetops.jl:197-226) at every node of the local slab,
+ *      written to fp64 side arrays in the padded layout (out0 for the curvature, out0..out[ndim-1] for the vectors).
+ *      phi's ghost layers are refilled on entry (centred differences reach one layer, corners included).
+ *      The result is multiplied by `scale`.  band_width >= 0 evaluates only the nodes with |ϕ| <= band_width; the
+ *      others get `fill`, and frozen_out (may be NULL; fp64 side array) := 1.0 on the evaluated nodes, 0.0 elsewhere —
+ *      the seed-and-freeze loop of the reference's speed update functions (test/test-velocityextension.jl:118-131:
+ *      v[I] = -curvature(ϕ, I) where |ϕ[I]| <= 1.5Δ, frozen there) in one launch, ready for
+ *      lsm_extend_along_normals.  band_width < 0: every node.  Asynchronous on `stream` (NULL = the handle's). */
+enum { LSM_GEOM_CURVATURE = 0, LSM_GEOM_GRADIENT = 1, LSM_GEOM_NORMAL = 2 };
+int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_width, double fill, void* out0,
+                 void* out1, void* out2, void* frozen_out, void* stream);
+
 /* ---- NarrowBandMeshField (src/meshfield.jl:314-588) on the device.
  *      The band is a byte mask (1 = active node) over the same padded index space as the values
  *      (allocate LsmLayout.total bytes; ghost entries stay 0).  Values stay in the dense padded array.

@@ -235,6 +235,26 @@ function LSM.extend_along_normals!(F::ROCMeshField, ϕ::ROCMeshField; nb_iters =
     return F
 end
 
+# curvature / gradient / normal of ϕ at every node (src/levelsetops.jl:197-226) into Float64 device arrays in ϕ's padded
+# layout; `band`: only |ϕ[I]| <= band is evaluated (else `fill`) and `frozen` marks those nodes with 1.0 — the seed loop of
+# the reference's speed update functions (test/test-velocityextension.jl:118-131) without a host pass.
+function curvature_field!(out::ROCVector{Float64}, ϕ::ROCMeshField; scale = 1.0, band = -1.0, fill = 0.0, frozen = nothing)
+    _check(ϕ.handle, ccall((:lsm_geometry, libhiplsm), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, 0, pointer(ϕ.buf), scale, band, fill, pointer(out), C_NULL, C_NULL, frozen === nothing ? C_NULL : pointer(frozen), C_NULL),
+        "lsm_geometry")
+    return out
+end
+function _vector_field!(what::Integer, outs::NTuple{N, ROCVector{Float64}}, ϕ::ROCMeshField; scale = 1.0) where {N}
+    o = ntuple(d -> d <= N ? pointer(outs[d]) : C_NULL, 3)
+    _check(ϕ.handle, ccall((:lsm_geometry, libhiplsm), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, what, pointer(ϕ.buf), scale, -1.0, 0.0, o[1], o[2], o[3], C_NULL, C_NULL), "lsm_geometry")
+    return outs
+end
+gradient_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(1, outs, ϕ; kw...)
+normal_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(2, outs, ϕ; kw...)
+
 # reinitialize!(ϕ; ...) (src/reinitializer.jl:12-42)
 function LSM.reinitialize!(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
     xt, ft = something(xtol, sqrt(eps(Float64))), something(ftol, sqrt(eps(Float64)))

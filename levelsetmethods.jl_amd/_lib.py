@@ -24,6 +24,7 @@ BASE_PSI, BASE_RK3_S2, BASE_RK3_S3, BASE_OTHER = 0, 1, 2, 3
 MODE_FAST, MODE_STRICT = 0, 1
 DTYPE_F64 = 0
 DTYPE_F32 = 1
+GEOM_CURVATURE, GEOM_GRADIENT, GEOM_NORMAL = 0, 1, 2
 
 
 class LsmGrid(C.Structure):
@@ -86,6 +87,8 @@ _SIGS = [
                                   C.c_double, StageHook, C.c_void_p]),
     ("lsm_eikonal_sign", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("lsm_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
     ("lsm_extend_along_normals", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_double, C.c_double, C.c_double]),
     ("lsm_band_tile_count", C.c_int, [_H, C.c_int, C.POINTER(C.c_int64)]),

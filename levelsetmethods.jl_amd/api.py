@@ -1152,7 +1152,7 @@ def extend_along_normals_(F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_
     b = phi.backend
     fz = None
     if frozen is not None:
-        if isinstance(frozen, ROCMeshField):
+        if isinstance(frozen, (ROCMeshField, SideField)):
             fz = frozen.buf if str(frozen.buf.dtype) == "torch.float64" else frozen.buf.double()   # side arrays are float64
         else:
             a = np.asarray(frozen.vals if isinstance(frozen, MeshField) else frozen)
@@ -1163,6 +1163,65 @@ def extend_along_normals_(F, phi, nb_iters=50, cfl=0.45, frozen=None, interface_
     b.extend_along_normals(F.buf, phi.buf, fz, int(nb_iters), float(cfl), float(interface_band), float(min_norm))
     F.ghosts_dirty = True
     return F
+
+
+class SideField:
+    """A float64 device array in the padded layout of a backend (coefficient fields, frozen masks, the outputs of
+    curvature_field / gradient_field / normal_field)."""
+
+    def __init__(self, backend, mesh, buf=None):
+        self.backend, self.mesh = backend, mesh
+        self.buf = backend.alloc_side() if buf is None else buf
+
+    def values(self):
+        return self.backend.download_side(self.buf)
+
+
+def _geometry(phi, what, ncomp, scale, band, fill, out, frozen_out):
+    if not isinstance(phi, ROCMeshField):
+        raise ValueError("ϕ must be a device field (ROCMeshField)")
+    if isinstance(phi, ROCNarrowBandMeshField):
+        raise ValueError("curvature/gradient/normal fields are built for dense device fields (a band state answers ϕ[I] "
+                         "away from the band by extrapolation; prepare its halo and use the term kernels instead)")
+    b = phi.backend
+    outs = out if out is not None else [SideField(b, phi.mesh) for _ in range(ncomp)]
+    if len(outs) != ncomp:
+        raise ValueError(f"expected {ncomp} output field(s)")
+    b.geometry(what, phi.buf, [o.buf if isinstance(o, SideField) else o for o in outs], scale=scale,
+               band_width=-1.0 if band is None else float(band), fill=fill,
+               frozen_out=None if frozen_out is None else (frozen_out.buf if isinstance(frozen_out, SideField) else frozen_out))
+    phi.ghosts_dirty = False
+    return outs
+
+
+def curvature_field(phi, scale=1.0, band=None, fill=0.0, out=None, frozen_out=None):
+    """scale·curvature(ϕ, I) (src/levelsetops.jl:197-205) at every node, on the device.  `band`: only nodes with
+    |ϕ[I]| <= band are evaluated (the others get `fill`) and `frozen_out` (a SideField) marks them with 1.0 — the
+    seed-and-freeze loop of the reference's speed update functions (test/test-velocityextension.jl:118-131)."""
+    return _geometry(phi, L.GEOM_CURVATURE, 1, scale, band, fill, None if out is None else [out], frozen_out)[0]
+
+
+def gradient_field(phi, scale=1.0):
+    """gradient(ϕ, I) (src/levelsetops.jl:212-215) at every node: one SideField per dimension."""
+    return _geometry(phi, L.GEOM_GRADIENT, phi.mesh.ndim, scale, None, 0.0, None, None)
+
+
+def normal_field(phi, scale=1.0):
+    """normal(ϕ, I) = ∇ϕ/‖∇ϕ‖ (src/levelsetops.jl:222-226) at every node: one SideField per dimension."""
+    return _geometry(phi, L.GEOM_NORMAL, phi.mesh.ndim, scale, None, 0.0, None, None)
+
+
+def curvature(phi, I):
+    """curvature(ϕ, I) — scalar convenience (slow: evaluates the field); 0-based I."""
+    return float(curvature_field(phi).values()[tuple(I)])
+
+
+def gradient(phi, I):
+    return np.array([float(g.values()[tuple(I)]) for g in gradient_field(phi)])
+
+
+def normal(phi, I):
+    return np.array([float(g.values()[tuple(I)]) for g in normal_field(phi)])
 
 
 def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):

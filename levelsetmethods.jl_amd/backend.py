@@ -149,6 +149,12 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_extrema(self.h, self.ptr(t), C.byref(lo), C.byref(hi)), "lsm_extrema")
         return lo.value, hi.value
 
+    def geometry(self, what, phi, outs, scale=1.0, band_width=-1.0, fill=0.0, frozen_out=None):
+        """curvature / gradient / normal of phi at every node into fp64 side arrays (lsm_geometry)."""
+        o = [self.ptr(t) for t in outs] + [None] * (3 - len(outs))
+        L.check(self.h, self.lib.lsm_geometry(self.h, int(what), self.ptr(phi), float(scale), float(band_width), float(fill), o[0], o[1], o[2],
+                                              self.ptr(frozen_out), None), "lsm_geometry")
+
     def extend_along_normals(self, F, phi, frozen, nb_iters, cfl, interface_band, min_norm):
         work = [self.alloc()] + [self.alloc_side() for _ in range(self.ndim)]   # F staging + the normal components
         w = [self.ptr(x) for x in work] + [None] * (4 - len(work))

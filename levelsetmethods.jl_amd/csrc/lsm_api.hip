@@ -706,6 +706,23 @@ static int measure(LsmHandle* h, int mode, void* phi, double* out) {
 int lsm_volume(LsmHandle* h, const void* phi, double* out) { return measure(h, 0, (void*)phi, out); }
 int lsm_perimeter(LsmHandle* h, void* phi, double* out) { return measure(h, 1, phi, out); }
 
+// curvature / gradient / normal fields (src/levelsetops.jl:197-226)
+int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_width, double fill, void* out0, void* out1, void* out2,
+                 void* frozen_out, void* stream) {
+    if (!h || !phi || !out0) return h ? fail(h, LSM_ERR_INVALID, "lsm_geometry: null argument") : LSM_ERR_INVALID;
+    if (what < LSM_GEOM_CURVATURE || what > LSM_GEOM_NORMAL) return fail(h, LSM_ERR_INVALID, "lsm_geometry: bad selector");
+    const int N = h->grid.ndim;
+    if (what != LSM_GEOM_CURVATURE && ((N > 1 && !out1) || (N > 2 && !out2)))
+        return fail(h, LSM_ERR_INVALID, "lsm_geometry: one output array per dimension is required");
+    if (phi == out0 || phi == out1 || phi == out2 || phi == frozen_out) return fail(h, LSM_ERR_INVALID, "lsm_geometry: outputs must not alias phi");
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, stream));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    launch_geometry(what, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, scale, band_width, fill, phi, is_f32(h),
+                    (double*)out0, (double*)out1, (double*)out2, (double*)frozen_out, s);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
 // extend_along_normals! (src/velocityextension.jl:20-67): nb_iters first-order upwind pseudo-time
 // sweeps F <- F - τ Σ_d a_d (a_d>0 ? D⁻F : D⁺F) with a = sign-weighted unit normal of ϕ, frozen nodes
 // held fixed.  Each sweep is the fused stage kernel with an Upwind advection term whose velocity is

@@ -603,6 +603,70 @@ void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2,
 }
 
 // ---------------------------------------------------------------------------------------------
+// curvature / gradient / normal at every node (src/levelsetops.jl:197-226), the reference's operation order
+// (this file is built with -ffp-contract=off): D⁰, D2⁰, D2 of src/derivatives.jl:129-149; gᵀHg in the order of
+// LinearAlgebra.dot(x, ::Symmetric, y) as in the CurvatureTerm of the stage kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) geometry_kernel(int what, int ndim, int n0, int n1, int n2, long long s1, long long s2, long long origin,
+                                                       double h0, double h1, double h2, double scale, double band_width, double fill,
+                                                       const void* phip, int f32, double* o0, double* o1, double* o2, double* frozen) {
+    auto phi = [&](long long i) { return ld_val(phip, i, f32); };
+    const long long total = (long long)n0 * n1 * n2;
+    const double hh[3] = {h0, h1, h2};
+    const long long st[3] = {1, s1, s2};
+    double* out[3] = {o0, o1, o2};
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
+        const long long q = origin + i0 + i1 * s1 + i2 * s2;
+        const double c = phi(q);
+        const bool on = band_width < 0.0 || __builtin_fabs(c) <= band_width;
+        if (frozen) frozen[q] = on ? 1.0 : 0.0;
+        if (!on) {
+            if (what == LSM_GEOM_CURVATURE) o0[q] = fill;
+            else for (int d = 0; d < ndim; ++d) out[d][q] = fill;
+            continue;
+        }
+        double g[3] = {0, 0, 0};
+        for (int d = 0; d < ndim; ++d) g[d] = (phi(q + st[d]) - phi(q - st[d])) / (2 * hh[d]);
+        double nrmsq = g[0] * g[0];
+        for (int d = 1; d < ndim; ++d) nrmsq = nrmsq + g[d] * g[d];
+        if (what != LSM_GEOM_CURVATURE) {
+            const double nrm = __builtin_sqrt(nrmsq);
+            for (int d = 0; d < ndim; ++d) out[d][q] = scale * (what == LSM_GEOM_GRADIENT ? g[d] : g[d] / nrm);
+            continue;
+        }
+        double kappa = 0.0;
+        if (!(nrmsq < 2.220446049250313e-16)) {
+            double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int a = 0; a < ndim; ++a) {
+                H[a][a] = (phi(q + st[a]) - 2 * c + phi(q - st[a])) / (hh[a] * hh[a]);
+                for (int b = a + 1; b < ndim; ++b)
+                    H[a][b] = ((phi(q + st[a] + st[b]) - phi(q + st[a] - st[b])) / (2 * hh[b]) -
+                               (phi(q - st[a] + st[b]) - phi(q - st[a] - st[b])) / (2 * hh[b])) / (2 * hh[a]);
+            }
+            double lap = H[0][0];
+            for (int d = 1; d < ndim; ++d) lap = lap + H[d][d];
+            double r = 0.0;
+            for (int j = 0; j < ndim; ++j) {
+                r += g[j] * (H[j][j] * g[j]);
+                for (int i = 0; i < j; ++i) r += g[i] * (H[i][j] * g[j]) + g[j] * (H[i][j] * g[i]);
+            }
+            kappa = (lap * nrmsq - r) / pow(nrmsq, 1.5);
+        }
+        o0[q] = scale * kappa;
+    }
+}
+void launch_geometry(int what, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double scale,
+                     double band_width, double fill, const void* phi, int f32, double* o0, double* o1, double* o2, double* frozen,
+                     hipStream_t s) {
+    const long long total = (long long)n[0] * n[1] * n[2];
+    long long b = (total + 255) / 256;
+    const int nb = (int)(b > 8192 ? 8192 : b);
+    hipLaunchKernelGGL(geometry_kernel, dim3(nb), dim3(256), 0, s, what, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2], scale,
+                       band_width, fill, phi, f32, o0, o1, o2, frozen);
+}
+
+// ---------------------------------------------------------------------------------------------
 // EikonalReinitializationTerm(ϕ₀): S₀ = v / sqrt(v² + Δx²) on the interior (src/levelsetterms.jl:217-221)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eikonal_sign_kernel(int n0, int n1, int n2, long long s1, long long s2,

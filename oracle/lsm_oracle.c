@@ -474,6 +474,25 @@ double orc_measure(int mode, const LsmGrid* g, const LsmBc bc[3][2], const doubl
     return vol * pairwise(mode, &f, 0, g->n[0] * g->n[1] * g->n[2], min_meshsize(g));
 }
 
+/* ------------------------------------------------------------------ curvature / gradient / normal at every node
+ * src/levelsetops.jl:197-226 (what: 0 curvature -> out0; 1 gradient, 2 normal -> out0..out[N-1]); dense arrays. */
+void orc_geometry(int what, const LsmGrid* g, const LsmBc bc[3][2], const double* v, double* out0, double* out1, double* out2) {
+    F f; make_field(&f, g, bc, 1, v);
+    int N = g->ndim;
+    double* out[3] = {out0, out1, out2};
+    for (int64_t i2 = 0; i2 < g->n[2]; ++i2)
+        for (int64_t i1 = 0; i1 < g->n[1]; ++i1)
+            for (int64_t i0 = 0; i0 < g->n[0]; ++i0) {
+                const int64_t I[3] = {i0, i1, i2};
+                const int64_t q = i0 + g->n[0] * (i1 + g->n[1] * i2);
+                if (what == 0) { out0[q] = curvature(&f, I); continue; }
+                double gr[3] = {0, 0, 0}, s = 0.0;
+                for (int d = 0; d < N; ++d) { gr[d] = D0(&f, I, d); s = d == 0 ? gr[d] * gr[d] : s + gr[d] * gr[d]; }
+                const double nrm = sqrt(s);                       /* norm(::SVector) */
+                for (int d = 0; d < N; ++d) out[d][q] = what == 1 ? gr[d] : gr[d] / nrm;
+            }
+}
+
 /* ------------------------------------------------------------------ extend_along_normals!
  * src/velocityextension.jl:20-67 (sweeps), :78-94 (frozen mask), :96-116 (signed normal components).
  * frozen: NULL (band rule) or a dense 0/1 double array.  F is updated in place. */

@@ -106,6 +106,8 @@ def lib():
         L.orc_extend_along_normals.argtypes = [C.POINTER(LsmGrid), BcArray, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.orc_measure.restype = C.c_double
         L.orc_measure.argtypes = [C.c_int, C.POINTER(LsmGrid), BcArray, dp]
+        L.orc_geometry.restype = None
+        L.orc_geometry.argtypes = [C.c_int, C.POINTER(LsmGrid), BcArray, dp, dp, dp, dp]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -329,6 +331,16 @@ def volume(grid, v):
 def perimeter(grid, v, bc=None):
     """perimeter(ϕ) — src/levelsetops.jl:139-149 (LinearExtrapolationBC when the field has none)."""
     return lib().orc_measure(1, C.byref(grid.c), bc if bc is not None else make_bc("linear", grid.ndim), _dp(v))
+
+
+def geometry(grid, bc, v, what):
+    """what = 'curvature' | 'gradient' | 'normal' at every node — src/levelsetops.jl:197-226.
+    Returns one dense array (curvature) or a list of ndim arrays."""
+    k = {"curvature": 0, "gradient": 1, "normal": 2}[what]
+    outs = [np.zeros(grid.n, dtype=np.float64, order="F") for _ in range(1 if k == 0 else grid.ndim)]
+    ptr = [_dp(o) for o in outs] + [None] * (3 - len(outs))
+    lib().orc_geometry(k, C.byref(grid.c), bc, _dp(np.asfortranarray(v)), ptr[0], ptr[1], ptr[2])
+    return outs[0] if k == 0 else outs
 
 
 def compute_cfl(grid, bc, v, terms, t=0.0):
