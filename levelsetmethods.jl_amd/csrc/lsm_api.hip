@@ -1086,7 +1086,7 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
     for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
     long long counts[3] = {0, 0, 0};
     const char* err = nullptr;
-    const int r = reinit_run(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, lc, h->h, order, upsample, maxiters, xtol, ftol,
+    const int r = reinit_run(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->lay.total, lc, h->h, order, upsample, maxiters, xtol, ftol,
                              phi, is_f32(h), (const unsigned char*)mask, work, h->stream, counts, &err);
     if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_reinitialize");
     if (r) return fail(h, LSM_ERR_HIP, err ? err : "lsm_reinitialize");

@@ -154,9 +154,9 @@ void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned lo
 void stage_tile_shape(int ndim, int* tx, int* ty);
 
 // reinitialize! (lsm_reinit.hip)
-int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
-               int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask, void* out_field,
-               hipStream_t stream, long long out_counts[3], const char** err);
+int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
+               const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
+               void* out_field, hipStream_t stream, long long out_counts[3], const char** err);
 
 // compile-time description of one instantiated fused kernel
 struct Combo {

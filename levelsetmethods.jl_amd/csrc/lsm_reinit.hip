@@ -192,17 +192,29 @@ __device__ void bernstein_extrema(const ReinitArgs& a, long long q0, double& lo,
 // (a) every cell: the cheap bound |p - mid| <= Λ·spread over the stencil values -> list of "maybe" cells (wave-
 //     aggregated append); (b) the maybe cells only (≈6x the final count): the reference's own test on the extrema of
 //     the Bernstein coefficients (proven_empty, src/interpolation.jl:271-274) -> candidate ids.
-__global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* maybe, unsigned* maybe_count) {
-    const long long nc = ncells(a);
+// node_list != NULL (band fields): only the cells whose lowest corner is a listed (active) node are looked at, and
+// cand_id has been set to -1 by the caller.
+__global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* maybe, unsigned* maybe_count,
+                                                           const long long* node_list, long long nlist) {
+    const long long nc = node_list ? nlist : ncells(a);
     const long long span = (nc + 255) / 256 * 256;      // whole waves reach the ballot
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (long long)gridDim.x * blockDim.x) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < span; w += (long long)gridDim.x * blockDim.x) {
         bool keep = false;
-        if (c < nc) {
+        long long c = w;
+        if (w < nc) {
             int I[3];
-            cell_unlin(a, c, I);
+            bool has_cell = true;
+            if (node_list) {
+                const long long t = node_list[w];
+                I[0] = (int)(t % a.n[0]); I[1] = (int)((t / a.n[0]) % a.n[1]); I[2] = (int)(t / ((long long)a.n[0] * a.n[1]));
+                for (int d = 0; d < a.ndim; ++d) has_cell = has_cell && I[d] < a.n[d] - 1;
+                c = has_cell ? cell_lin(a, I) : 0;
+            } else {
+                cell_unlin(a, c, I);
+            }
             const long long qc = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
-            bool act = true;
-            if (a.mask)
+            bool act = has_cell;
+            if (a.mask && act)
                 for (int k = 0; k < (1 << a.ndim); ++k)
                     act = act && a.mask[qc + (k & 1) + ((k >> 1) & 1) * a.s1 + ((k >> 2) & 1) * a.s2];
             if (act) {
@@ -219,7 +231,7 @@ __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* ca
                 const bool empty = mid - a.lambda * spread > 0.0 || mid + a.lambda * spread < 0.0;   // p cannot vanish
                 keep = !empty && lo == lo && hi == hi;
             }
-            cand_id[c] = -1;
+            if (!node_list) cand_id[c] = -1;
         }
         const unsigned long long bal = __ballot(keep);
         if (!bal) continue;
@@ -412,6 +424,53 @@ __global__ void __launch_bounds__(256) reinit_nodes_kernel(ReinitArgs a, long lo
         if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(bal));
         base = __shfl(base, leader, 64);
         if (on && list) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;   // list == NULL: count only
+    }
+}
+
+// The same list for a band, built from a linear scan of the mask bytes, 16 per load: the band is ~1 % of a 3-D grid and
+// the node-indexed scan above spends its time on the other 99 % (one byte load and a 64-bit division per node).  One
+// global atomic per workgroup (a global atomic per wave serialises: ~10 ns each).  Mask bytes outside the grid are 0.
+__global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, long long total, long long* list, unsigned* count) {
+    __shared__ unsigned blk_n, blk_base;
+    const uint4* m4 = reinterpret_cast<const uint4*>(a.mask);        // hipMalloc'ed: 256-byte aligned
+    const long long nvec = (total + 15) / 16;
+    const long long span = (nvec + 255) / 256 * 256;
+    const long long G = LSM_GHOST;
+    const long long corner = a.origin - G - (a.ndim > 1 ? G * a.s1 : 0) - (a.ndim > 2 ? G * a.s2 : 0);
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < span; v += (long long)gridDim.x * blockDim.x) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (v < nvec) {
+            if (16 * v + 16 <= total) { const uint4 x = m4[v]; w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; }
+            else for (long long b = 16 * v; b < total; ++b) w[(b - 16 * v) / 4] |= (unsigned)a.mask[b] << (8 * ((b - 16 * v) % 4));
+        }
+        unsigned n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            n += ((w[k] & 0xffu) != 0) + ((w[k] & 0xff00u) != 0) + ((w[k] & 0xff0000u) != 0) + ((w[k] & 0xff000000u) != 0);
+        if (!__syncthreads_or(n != 0)) continue;          // also the barrier that separates two rounds of the counters
+        if (threadIdx.x == 0) blk_n = 0;
+        __syncthreads();
+        unsigned mine = 0;
+        if (n) mine = atomicAdd(&blk_n, n);
+        __syncthreads();
+        if (threadIdx.x == 0) blk_base = atomicAdd(count, blk_n);
+        __syncthreads();
+        if (n && list) {                                   // list == NULL: count only
+            unsigned at = blk_base + mine;
+            for (int k = 0; k < 16; ++k) {
+                if (!((w[k >> 2] >> (8 * (k & 3))) & 0xffu)) continue;
+                const long long qq = 16 * v + k - corner;   // offset from the lowest ghost corner of the padded array
+                long long p0 = qq, p1 = 0, p2 = 0;
+                if (a.ndim > 2) { p2 = qq / a.s2; p0 = qq - p2 * a.s2; }
+                if (a.ndim > 1) { p1 = p0 / a.s1; p0 = p0 - p1 * a.s1; }
+                long long i0 = p0 - G, i1 = a.ndim > 1 ? p1 - G : 0, i2 = a.ndim > 2 ? p2 - G : 0;
+                // the ghost entries of a band mask are 0 (include/lsm.h); should one not be, it lands on the nearest node
+                i0 = i0 < 0 ? 0 : (i0 > a.n[0] - 1 ? a.n[0] - 1 : i0);
+                i1 = i1 < 0 ? 0 : (i1 > a.n[1] - 1 ? a.n[1] - 1 : i1);
+                i2 = i2 < 0 ? 0 : (i2 > a.n[2] - 1 ? a.n[2] - 1 : i2);
+                list[at++] = i0 + (long long)a.n[0] * (i1 + (long long)a.n[1] * i2);
+            }
+        }
     }
 }
 
@@ -788,9 +847,10 @@ __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S,
 }
 
 // copy the new values of the active nodes back (the evaluation phase never writes ϕ: src/reinitializer.jl:21-24)
-__global__ void __launch_bounds__(256) reinit_commit_kernel(ReinitArgs a, const void* src, void* dst) {
-    const long long total = (long long)a.n[0] * a.n[1] * a.n[2];
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) reinit_commit_kernel(ReinitArgs a, const void* src, void* dst, const long long* node_list, long long nlist) {
+    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long t = node_list ? node_list[w] : w;
         const long long q = a.origin + (t % a.n[0]) + ((t / a.n[0]) % a.n[1]) * a.s1 + (t / ((long long)a.n[0] * a.n[1])) * a.s2;
         if (a.mask && !a.mask[q]) continue;
         st_val(dst, q, a.f32, ld_val(src, q, a.f32));
@@ -846,9 +906,9 @@ static bool interp_matrix(int order, int ndim, double M[36], int* nv_out, double
 }
 
 // returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
-int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
-               int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask, void* out_field,
-               hipStream_t stream, long long out_counts[3], const char** err) {
+int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
+               const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
+               void* out_field, hipStream_t stream, long long out_counts[3], const char** err) {
     ReinitArgs a;
     a.ndim = ndim;
     for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.goff[d] = goff[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
@@ -874,11 +934,29 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
     RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
     RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
-    const unsigned gb = (unsigned)((nc + 255) / 256 > 65535 ? 65535 : (nc + 255) / 256);
     unsigned nmaybe = 0, ncand = 0;
     RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
-    RE_HIP(hipMalloc((void**)&maybe, sizeof(long long) * (size_t)nc));
-    hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, maybe, counters);
+    // band fields: the compact list of the active nodes first — candidate cells, the distance computation and the
+    // commit all run over it (the band is ~1 % of a 3-D grid)
+    const long long nodes = (long long)n[0] * n[1] * n[2];
+    long long nwork = nodes;
+    if (mask) {
+        unsigned nact = 0;
+        const long long nvec = (total + 15) / 16;
+        const unsigned gl = (unsigned)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, (long long*)nullptr, counters + 3);
+        RE_HIP(hipMemcpyAsync(&nact, counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RE_HIP(hipStreamSynchronize(stream));
+        RE_HIP(hipMalloc((void**)&node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
+        RE_HIP(hipMemsetAsync(counters + 3, 0, sizeof(unsigned), stream));
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, node_list, counters + 3);
+        nwork = nact;
+        RE_HIP(hipMemsetAsync(cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
+    }
+    const long long ncell_work = mask ? nwork : nc;
+    const unsigned gb = (unsigned)((ncell_work + 255) / 256 > 65535 ? 65535 : (ncell_work + 255) / 256);
+    RE_HIP(hipMalloc((void**)&maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
+    if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, maybe, counters, node_list, nwork);
     RE_HIP(hipMemcpyAsync(&nmaybe, counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     RE_HIP(hipStreamSynchronize(stream));
     RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
@@ -888,7 +966,7 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         RE_HIP(hipMemcpyAsync(&ncand, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
     }
-    RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
+    RE_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(unsigned), stream));
     const size_t slots = (size_t)(ncand ? ncand : 1) * S;
     RE_HIP(hipMalloc((void**)&pts, sizeof(double) * 3 * slots));
     RE_HIP(hipMalloc((void**)&valid, slots));
@@ -911,19 +989,6 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         else hipLaunchKernelGGL(reinit_sample_kernel<6>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
         hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk, bits);
     }
-    const long long nodes = (long long)n[0] * n[1] * n[2];
-    long long nwork = nodes;
-    if (mask) {
-        unsigned nact = 0;
-        const unsigned gl = (unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256);
-        hipLaunchKernelGGL(reinit_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, (long long*)nullptr, counters + 3);
-        RE_HIP(hipMemcpyAsync(&nact, counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        RE_HIP(hipStreamSynchronize(stream));
-        RE_HIP(hipMalloc((void**)&node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
-        RE_HIP(hipMemsetAsync(counters + 3, 0, sizeof(unsigned), stream));
-        hipLaunchKernelGGL(reinit_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, node_list, counters + 3);
-        nwork = nact;
-    }
     if (nwork) {
         RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
@@ -939,8 +1004,9 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         else
             hipLaunchKernelGGL(reinit_newton_kernel<6>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
     }
-    hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nodes + 255) / 256 > 65535 ? 65535 : (nodes + 255) / 256)), dim3(256), 0, stream, a,
-                       out_field, phi);
+    if (nwork)
+        hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nwork + 255) / 256 > 65535 ? 65535 : (nwork + 255) / 256)), dim3(256), 0, stream, a,
+                           out_field, phi, node_list, nwork);
     unsigned cn[4] = {0, 0, 0, 0};
     RE_HIP(hipMemcpyAsync(cn, counters, sizeof(cn), hipMemcpyDeviceToHost, stream));
     RE_HIP(hipStreamSynchronize(stream));
