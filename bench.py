@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="cells per side of the per-GPU 512³-equivalent workload")
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--cpu-sample", type=int, default=256)
     args = ap.parse_args()
 
     import torch

@@ -480,8 +480,14 @@ constexpr int FINE_SHELLS = 6;
 // (row word -> cell id -> sample count -> samples); sixteen lanes share the rows of the ball, keep one best each and
 // merge with shuffles.  Nodes the guided search cannot settle (no usable estimate, ball wider than 10 cells) are
 // flagged for the one-lane-per-node kernel below (seeds[0] = -2).
-constexpr int GRP = 16;
-constexpr int QCAP = 96;
+#ifndef LSM_REINIT_GRP
+#define LSM_REINIT_GRP 16
+#endif
+#ifndef LSM_REINIT_QCAP
+#define LSM_REINIT_QCAP 96
+#endif
+constexpr int GRP = LSM_REINIT_GRP;
+constexpr int QCAP = LSM_REINIT_QCAP;
 __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
                                                                   const unsigned char* cnt, const unsigned long long* bits,
                                                                   const long long* node_list, long long nlist, long long* seeds) {
