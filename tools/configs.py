@@ -107,6 +107,32 @@ def upwind(n=512, steps=10):
     return res
 
 
+def terms(n=512, steps=8):
+    """Every single term and the fused pairs on a 512^3 sphere, ForwardEuler (one stage per step: read ψ, write): the
+    stage kernel's duration and algorithmic GB/s (16 B per node) — which members of the family are HBM-bound."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    ic = lsm.LazyMeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, grid)
+    cases = {
+        "upwind adv (const)": (lsm.AdvectionTerm((1.0, 0.5, -0.25), lsm.Upwind()),),
+        "WENO5 adv (const)": (lsm.AdvectionTerm((1.0, 0.5, -0.25), lsm.WENO5()),),
+        "WENO5 adv (rotation)": (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()),),
+        "NormalMotion (const)": (lsm.NormalMotionTerm(0.1),),
+        "Curvature (const)": (lsm.CurvatureTerm(-0.1),),
+        "Eikonal (current sign)": (lsm.EikonalReinitializationTerm(),),
+        "NormalMotion + Curvature": (lsm.NormalMotionTerm(0.1), lsm.CurvatureTerm(-0.1)),
+        "WENO5 adv (rotation) + Curvature": (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.01)),
+        "WENO5 adv (vortex) + Eikonal": (lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+    }
+    res = {"config": f"3D {n}^3 single stages (ForwardEuler)"}
+    for name, tm in cases.items():
+        eq = lsm.LevelSetEquation(terms=tm, ic=ic, bc=lsm.NeumannBC(), integrator=lsm.ForwardEuler())
+        ms, kms, nl = timed(eq, steps)
+        res[name] = {"stage_ms": round(kms, 4), "GBs_algorithmic": round(n ** 3 * 16 / kms / 1e6, 1), "frac_of_8TBs": round(n ** 3 * 16 / kms / 1e6 / 8000, 3)}
+        del eq
+        torch.cuda.empty_cache()
+    return res
+
+
 def calib(n=512):
     """Known-traffic kernels for the FETCH_SIZE/WRITE_SIZE calibration (run under rocprofv3 --pmc):
     extrema reads n^3*8 B with 8-byte-per-lane loads; eikonal_sign reads and writes n^3*8 B."""
@@ -133,6 +159,8 @@ if __name__ == "__main__":
         out.append(config5())
     if mode in ("all", "upwind"):
         out.append(upwind())
+    if mode == "terms":
+        out.append(terms())
     if mode == "calib":
         out.append(calib())
     print(json.dumps(out, indent=1))
