@@ -205,6 +205,16 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax);
  *      Synchronous. */
 int lsm_volume(LsmHandle* h, const void* phi, double* out);
 int lsm_perimeter(LsmHandle* h, void* phi, double* out);
+/* ---- the same measures of a NarrowBandMeshField (src/levelsetops.jl:34-116,150-166), from the band alone.
+ *      lsm_band_volume: prod(h)·(Σ_band H(-ϕ) + the number of off-band nodes inside): per grid line along dimension 1 the
+ *      tails and the gaps between consecutive band nodes count when their end nodes are negative; a line without a band
+ *      node takes the sign of the band node nearest (in index space) to its point n₁÷2, as the reference's KD-tree query
+ *      does.  0 for an empty band.
+ *      lsm_band_perimeter: the dense sum over the band nodes (the delta's support lies inside the band); phi must be a
+ *      prepared stage input (lsm_band_prepare: the off-band neighbours of band nodes hold the extrapolated values).
+ *      Single device; synchronous. */
+int lsm_band_volume(LsmHandle* h, const void* phi, const void* mask, double* out);
+int lsm_band_perimeter(LsmHandle* h, const void* phi, const void* mask, double* out);
 
 /* ---- extend_along_normals!(F, ϕ; nb_iters, cfl, frozen, interface_band, min_norm)
  *      (src/velocityextension.jl:20-67): extends the speed F off the interface of ϕ by nb_iters

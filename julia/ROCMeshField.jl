@@ -221,6 +221,19 @@ function LSM.perimeter(ϕ::ROCMeshField)
     return out[]
 end
 
+# volume / perimeter of a band field (src/levelsetops.jl:34-116,150-166); `mask` is the band's byte mask, ϕ prepared
+# (lsm_band_prepare) for the perimeter's centred gradient
+function band_volume(ϕ::ROCMeshField, mask::ROCVector{UInt8})
+    out = Ref{Float64}()
+    _check(ϕ.handle, ccall((:lsm_band_volume, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ϕ.handle, pointer(ϕ.buf), pointer(mask), out), "lsm_band_volume")
+    return out[]
+end
+function band_perimeter(ϕ::ROCMeshField, mask::ROCVector{UInt8})
+    out = Ref{Float64}()
+    _check(ϕ.handle, ccall((:lsm_band_perimeter, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), ϕ.handle, pointer(ϕ.buf), pointer(mask), out), "lsm_band_perimeter")
+    return out[]
+end
+
 # extend_along_normals!(F, ϕ; ...) (src/velocityextension.jl:20-116); frozen = nothing -> band rule
 function LSM.extend_along_normals!(F::ROCMeshField, ϕ::ROCMeshField; nb_iters = 50, cfl = 0.45, frozen = nothing,
                                    interface_band = 1.5, min_norm = 1.0e-14)

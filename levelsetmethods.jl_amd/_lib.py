@@ -110,6 +110,8 @@ _SIGS = [
                                        C.POINTER(C.c_double)]),
     ("lsm_volume", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double)]),
     ("lsm_perimeter", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double)]),
+    ("lsm_band_volume", C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    ("lsm_band_perimeter", C.c_int, [_H, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     ("lsm_profile_enable", C.c_int, [_H, C.c_int]),
     ("lsm_profile_read", C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 ]

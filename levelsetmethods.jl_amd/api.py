@@ -1112,22 +1112,29 @@ def _sum_over_ranks(ls, x):
     return float(t.item())
 
 
-def _dense_only(ls, what):
-    # the reference sums over every node through getindex, which throws away from the band (src/meshfield.jl:499-500)
-    if getattr(ls, "band", False):
-        raise ValueError(f"{what} needs values on the whole grid: not defined for a NarrowBandMeshField state")
+def _band_single_device(ls, what):
+    if ls.comm is not None and ls.world > 1:
+        raise ValueError(f"{what} of a slab-decomposed NarrowBandMeshField is not built (the band-free grid lines are "
+                         "classified by the nearest band node of the whole band)")
 
 
 def volume(ls):
     """volume(eq) — measure of {ϕ ≤ 0} with the smoothed Heaviside (src/levelsetops.jl:27-33,
-    src/levelsetequation.jl:165); the standard posthook diagnostic (docs/src/levelset-equation.md:142-149)."""
-    _dense_only(ls, "volume")
+    src/levelsetequation.jl:165); the standard posthook diagnostic (docs/src/levelset-equation.md:142-149).
+    NarrowBandMeshField states: from the band alone (src/levelsetops.jl:34-116)."""
+    if getattr(ls, "band", False):
+        _band_single_device(ls, "volume")
+        return ls.backend.band_volume(ls.state.buf, ls.state.mask)
     return _sum_over_ranks(ls, ls.backend.volume_local(ls.state.buf))
 
 
 def perimeter(ls):
-    """perimeter(eq) — measure of {ϕ = 0} with the smoothed Dirac delta (src/levelsetops.jl:139-149)."""
-    _dense_only(ls, "perimeter")
+    """perimeter(eq) — measure of {ϕ = 0} with the smoothed Dirac delta (src/levelsetops.jl:139-149); for a
+    NarrowBandMeshField state the sum over the active nodes (:150-166)."""
+    if getattr(ls, "band", False):
+        _band_single_device(ls, "perimeter")
+        ls.state.prepare(ls.state.buf)      # ϕ[I] off the band (extrapolation) and outside the grid (BCs) for the centred gradient
+        return ls.backend.band_perimeter(ls.state.buf, ls.state.mask)
     if ls.comm is not None and ls.world > 1:
         ls._halo(ls.state.buf)          # slab interfaces: the centred gradient needs the neighbours' planes
     return _sum_over_ranks(ls, ls.backend.perimeter_local(ls.state.buf))

@@ -246,6 +246,16 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_perimeter(self.h, self.ptr(t), C.byref(out)), "lsm_perimeter")
         return out.value
 
+    def band_volume(self, t, mask):
+        out = C.c_double()
+        L.check(self.h, self.lib.lsm_band_volume(self.h, self.ptr(t), self.ptr(mask), C.byref(out)), "lsm_band_volume")
+        return out.value
+
+    def band_perimeter(self, t, mask):
+        out = C.c_double()
+        L.check(self.h, self.lib.lsm_band_perimeter(self.h, self.ptr(t), self.ptr(mask), C.byref(out)), "lsm_band_perimeter")
+        return out.value
+
     def reinitialize(self, phi, mask, order, upsample, maxiters, xtol, ftol):
         work = self.alloc()
         nc, nfail, nfar = C.c_int64(), C.c_int64(), C.c_int64()

@@ -706,6 +706,37 @@ static int measure(LsmHandle* h, int mode, void* phi, double* out) {
 int lsm_volume(LsmHandle* h, const void* phi, double* out) { return measure(h, 0, (void*)phi, out); }
 int lsm_perimeter(LsmHandle* h, void* phi, double* out) { return measure(h, 1, phi, out); }
 
+// volume / perimeter of a NarrowBandMeshField (src/levelsetops.jl:34-116,150-166)
+int lsm_band_volume(LsmHandle* h, const void* phi, const void* mask, double* out) {
+    if (!h || !phi || !mask || !out) return h ? fail(h, LSM_ERR_INVALID, "lsm_band_volume: null argument") : LSM_ERR_INVALID;
+    LSM_TRY(check_single_device(h));
+    const int N = h->grid.ndim;
+    double scale = 1.0;
+    for (int d = 0; d < N; ++d) scale = d == 0 ? h->h[0] : scale * h->h[d];
+    if (launch_band_volume(N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->dxmin, scale, phi, is_f32(h),
+                           (const unsigned char*)mask, h->d_result, h->stream))
+        return fail(h, LSM_ERR_HIP, "lsm_band_volume: device error");
+    LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0];
+    return LSM_OK;
+}
+int lsm_band_perimeter(LsmHandle* h, const void* phi, const void* mask, double* out) {
+    if (!h || !phi || !mask || !out) return h ? fail(h, LSM_ERR_INVALID, "lsm_band_perimeter: null argument") : LSM_ERR_INVALID;
+    LSM_TRY(check_single_device(h));
+    const int N = h->grid.ndim;
+    int nb = cfl_blocks(N, h->nloc);
+    if (nb > MAXB) nb = MAXB;
+    double scale = 1.0;
+    for (int d = 0; d < N; ++d) scale = d == 0 ? h->h[0] : scale * h->h[d];
+    launch_measure(1, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, h->dxmin, scale, phi, is_f32(h), h->d_partial, nb,
+                   h->d_result, h->stream, (const unsigned char*)mask);
+    LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    *out = h->h_result[0];
+    return LSM_OK;
+}
+
 // curvature / gradient / normal fields (src/levelsetops.jl:197-226)
 int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_width, double fill, void* out0, void* out1, void* out2,
                  void* frozen_out, void* stream) {

@@ -511,13 +511,14 @@ __device__ __forceinline__ double smooth_delta(double x, double alpha) {       /
 // mode 0: volume, 1: perimeter
 __global__ void __launch_bounds__(256) measure_kernel(int mode, int ndim, int n0, int n1, int n2, long long s1, long long s2,
                                                       long long origin, double h0, double h1, double h2, double dmin,
-                                                      const void* vp, int f32, double* partial) {
+                                                      const void* vp, int f32, double* partial, const unsigned char* mask) {
     auto v = [&](long long i) { return ld_val(vp, i, f32); };
     const long long total = (long long)n0 * n1 * n2;
     double acc = 0.0;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
         const long long q = origin + i0 + i1 * s1 + i2 * s2;
+        if (mask && !mask[q]) continue;      // NarrowBandMeshField: the sum runs over the active nodes (src/levelsetops.jl:157-166)
         const double c = v(q);
         if (mode == 0) {
             acc += smooth_heaviside(-c, dmin);
@@ -550,10 +551,132 @@ __global__ void __launch_bounds__(256) measure_final_kernel(const double* partia
     if (threadIdx.x == 0) out[0] = scale * ((ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
 }
 void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
-                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s) {
+                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s,
+                    const unsigned char* mask) {
     hipLaunchKernelGGL(measure_kernel, dim3(nblocks), dim3(256), 0, s, mode, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2],
-                       dmin, v, f32, partial);
+                       dmin, v, f32, partial, mask);
     hipLaunchKernelGGL(measure_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, scale, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// volume(nb::NarrowBandMeshField) (src/levelsetops.jl:34-116): Σ_band H(-ϕ) + the number of off-band nodes inside.
+// (1) one wave per grid line along dimension 1: 64 mask bytes per step, band / negative-band bit masks by ballot; the
+//     off-band interior of the line = the tail before the first band node if that node is negative, the tail after the
+//     last one likewise, and every gap whose two end nodes are both negative (_count_offband_interior, :67-91); also
+//     the line's Σ H(-ϕ), and the band node nearest to x0 = n1÷2 (the reference's query point) with its sign.
+// (2) a line without a band node carries no crossing and takes the sign of the nearest band node of the whole band
+//     (_count_bandfree_interior, :96-113, a KD-tree there).  Its squared index distance to a band line t' is
+//     |t - t'|² + (nearest band node of t' to x0)², a separable min-plus problem: one pass along the second dimension,
+//     one along the third, exact in integers.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) band_lines_kernel(int ndim, int n0, int n1, int n2, long long s1, long long s2, long long origin, double dmin,
+                                                         const void* vp, int f32, const unsigned char* mask, int x0, long long* line_count,
+                                                         double* line_hsum, int* line_near, int* line_neg) {
+    const int lane = threadIdx.x & 63;
+    const long long nlines = (long long)n1 * n2;
+    for (long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < nlines; t += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const int i1 = (int)(t % n1), i2 = (int)(t / n1);
+        const long long row = origin + i1 * s1 + i2 * s2;
+        long long count = 0;
+        double hs = 0.0;
+        int prev = -1, prev_neg = 0;          // last band node seen so far on the line and whether its value is negative
+        int best = 0x7fffffff, best_neg = 0;  // distance of the band node nearest to x0, and its sign
+        for (int b = 0; b < n0; b += 64) {
+            const int i0 = b + lane;
+            const bool on = i0 < n0 && mask[row + i0] != 0;
+            const double v = on ? ld_val(vp, row + i0, f32) : 0.0;
+            if (on) hs += smooth_heaviside(-v, dmin);
+            unsigned long long bm = __ballot(on), ng = __ballot(on && v < 0.0);
+            while (bm) {                       // wave-uniform walk over the band nodes of this chunk
+                const int k = __ffsll((long long)bm) - 1;
+                bm &= bm - 1;
+                const int x = b + k, neg = (int)((ng >> k) & 1ull);
+                if (prev < 0) { if (neg) count += x; }                       // tail before the first band node (x nodes: 0..x-1)
+                else if (x - prev - 1 > 0 && neg && prev_neg) count += x - prev - 1;
+                const int d = x > x0 ? x - x0 : x0 - x;
+                if (d < best) { best = d; best_neg = neg; }
+                prev = x; prev_neg = neg;
+            }
+        }
+        if (prev >= 0 && prev_neg) count += n0 - 1 - prev;                   // tail after the last band node
+        hs = wave_sum(hs);
+        if (lane == 0) {
+            line_count[t] = count;
+            line_hsum[t] = hs;
+            line_near[t] = prev >= 0 ? best : -1;
+            line_neg[t] = best_neg;
+        }
+    }
+}
+// pass along dimension `dim` (1 or 2) of the line lattice: g'(t) = min_{t'} (Δ_dim² + g(t')) with the sign carried along
+__global__ void __launch_bounds__(256) band_lines_minplus_kernel(int dim, int n1, int n2, const long long* gin, const int* negin, long long* gout,
+                                                                 int* negout) {
+    const long long nlines = (long long)n1 * n2;
+    const long long INF = 0x3fffffffffffffffll;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nlines; t += (long long)gridDim.x * blockDim.x) {
+        const int i1 = (int)(t % n1), i2 = (int)(t / n1);
+        const int len = dim == 1 ? n1 : n2, me = dim == 1 ? i1 : i2;
+        const long long base = dim == 1 ? (long long)i2 * n1 : i1, step = dim == 1 ? 1 : n1;
+        long long best = INF;
+        int bneg = 0;
+        for (int k = 0; k < len; ++k) {
+            const long long g = gin[base + k * step];
+            if (g >= INF) continue;
+            const long long d = (long long)(k - me) * (k - me) + g;
+            if (d < best) { best = d; bneg = negin[base + k * step]; }
+        }
+        gout[t] = best;
+        negout[t] = bneg;
+    }
+}
+__global__ void __launch_bounds__(256) band_lines_init_kernel(long long nlines, const int* line_near, long long* g) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nlines; t += (long long)gridDim.x * blockDim.x)
+        g[t] = line_near[t] < 0 ? 0x3fffffffffffffffll : (long long)line_near[t] * line_near[t];
+}
+// Σ over the lines: H sums + counted interior nodes + n0 for every band-free line whose nearest band node is negative
+__global__ void __launch_bounds__(256) band_lines_final_kernel(long long nlines, int n0, const long long* line_count, const double* line_hsum,
+                                                               const int* line_near, const long long* g, const int* gneg, double scale, double* out) {
+    double acc = 0.0;
+    bool any = false;
+    for (long long t = threadIdx.x; t < nlines; t += blockDim.x) {
+        if (line_near[t] >= 0) { acc += line_hsum[t] + (double)line_count[t]; any = true; }
+        else if (g[t] < 0x3fffffffffffffffll && gneg[t]) acc += (double)n0;
+    }
+    acc = wave_sum(acc);
+    __shared__ double ssum[4];
+    __shared__ int sany;
+    if (threadIdx.x == 0) sany = 0;
+    __syncthreads();
+    if (any) sany = 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) ssum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sany ? scale * ((ssum[0] + ssum[1]) + (ssum[2] + ssum[3])) : 0.0;   // empty band: 0 (:54)
+}
+int launch_band_volume(int ndim, const int n[3], long long s1, long long s2, long long origin, double dmin, double scale, const void* v, int f32,
+                       const unsigned char* mask, double* out, hipStream_t s) {
+    const int n0 = n[0], n1 = ndim > 1 ? n[1] : 1, n2 = ndim > 2 ? n[2] : 1;
+    const long long nlines = (long long)n1 * n2;
+    long long *cnt = nullptr, *g0 = nullptr, *g1 = nullptr;
+    double* hsum = nullptr;
+    int *near = nullptr, *neg0 = nullptr, *neg1 = nullptr;
+    auto cleanup = [&]() { (void)hipFree(cnt); (void)hipFree(g0); (void)hipFree(g1); (void)hipFree(hsum); (void)hipFree(near); (void)hipFree(neg0); (void)hipFree(neg1); };
+    if (hipMalloc((void**)&cnt, 8 * nlines) != hipSuccess || hipMalloc((void**)&g0, 8 * nlines) != hipSuccess ||
+        hipMalloc((void**)&g1, 8 * nlines) != hipSuccess || hipMalloc((void**)&hsum, 8 * nlines) != hipSuccess ||
+        hipMalloc((void**)&near, 4 * nlines) != hipSuccess || hipMalloc((void**)&neg0, 4 * nlines) != hipSuccess ||
+        hipMalloc((void**)&neg1, 4 * nlines) != hipSuccess) { cleanup(); return 1; }
+    const int x0 = n0 / 2 - 1;                                   // the reference's 1-based n1 ÷ 2
+    long long wb = (nlines * 64 + 255) / 256;
+    hipLaunchKernelGGL(band_lines_kernel, dim3((unsigned)(wb > 65535 ? 65535 : wb)), dim3(256), 0, s, ndim, n0, n1, n2, s1, s2, origin, dmin, v, f32,
+                       mask, x0, cnt, hsum, near, neg0);
+    const unsigned lb = (unsigned)((nlines + 255) / 256 > 4096 ? 4096 : (nlines + 255) / 256);
+    hipLaunchKernelGGL(band_lines_init_kernel, dim3(lb), dim3(256), 0, s, nlines, near, g0);
+    hipLaunchKernelGGL(band_lines_minplus_kernel, dim3(lb), dim3(256), 0, s, 1, n1, n2, g0, neg0, g1, neg1);
+    hipLaunchKernelGGL(band_lines_minplus_kernel, dim3(lb), dim3(256), 0, s, 2, n1, n2, g1, neg1, g0, neg0);
+    hipLaunchKernelGGL(band_lines_final_kernel, dim3(1), dim3(256), 0, s, nlines, n0, cnt, hsum, near, g0, neg0, scale, out);
+    const bool ok = hipStreamSynchronize(s) == hipSuccess;
+    cleanup();
+    return ok ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------

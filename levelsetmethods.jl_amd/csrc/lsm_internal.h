@@ -182,7 +182,10 @@ void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, do
 void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const void* v, int f32,
                     double* partial_min, double* partial_max, int nblocks, double* out2, hipStream_t s);
 void launch_measure(int mode, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3],
-                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s);
+                    double dmin, double scale, const void* v, int f32, double* partial, int nblocks, double* out, hipStream_t s,
+                    const unsigned char* mask = nullptr);
+int launch_band_volume(int ndim, const int n[3], long long s1, long long s2, long long origin, double dmin, double scale, const void* v, int f32,
+                       const unsigned char* mask, double* out, hipStream_t s);
 void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double delta,
                            double band_width, double min_norm2, const void* phi, int f32, const double* frozen, double* c0, double* c1,
                            double* c2, hipStream_t s);

@@ -398,3 +398,88 @@ def test_field_without_interface(lsm):
             lsm.reinitialize_(dense)
         assert any("no interface sample" in str(x.message) for x in w)
         assert np.array_equal(dense.current_state().values(), phi.vals)
+
+
+
+def _band_volume_ref(vals_on_band, n, h, dmin):
+    """volume(nb) restated literally (src/levelsetops.jl:49-113): dict of band values (0-based indices), scanlines along
+    dimension 1, band-free lines by the nearest band node (exact KD-tree query from the line's point n1÷2)."""
+    from scipy.spatial import cKDTree
+    d = vals_on_band
+    if not d:
+        return 0.0
+    N = len(n)
+
+    def heaviside(x, a):
+        return 1.0 if x > a else (0.0 if x < -a else 0.5 * (1.0 + x / a + np.sin(np.pi * x / a) / np.pi))
+    interface = sum(heaviside(-v, dmin) for v in d.values())
+    ks = sorted(d.keys(), key=lambda I: (tuple(I[1:][::-1]), I[0]))     # by line, then along dimension 1 (any line order will do)
+    count, lines = 0, set()
+    i, M = 0, len(ks)
+    while i < M:
+        j = i
+        while j + 1 < M and ks[j + 1][1:] == ks[i][1:]:
+            j += 1
+        lines.add(ks[i][1:])
+        first, last = ks[i], ks[j]
+        if d[first] < 0:
+            count += first[0]                    # 1-based first[1] - 1
+        if d[last] < 0:
+            count += n[0] - 1 - last[0]          # n1 - last[1]
+        for t in range(i, j):
+            gap = ks[t + 1][0] - ks[t][0] - 1
+            if gap > 0 and d[ks[t]] < 0 and d[ks[t + 1]] < 0:
+                count += gap
+        i = j + 1
+    transverse = list(np.ndindex(*n[1:])) if N > 1 else [()]
+    if len(lines) != len(transverse):
+        pts = np.array([[I[k] + 1 for k in range(N)] for I in d.keys()], dtype=float)     # 1-based, as the reference
+        neg = [v < 0 for v in d.values()]
+        tree = cKDTree(pts)
+        for t in transverse:
+            if t in lines:
+                continue
+            _, idx = tree.query(np.array([n[0] // 2] + [c + 1 for c in t], dtype=float))
+            if neg[idx]:
+                count += n[0]
+    return float(np.prod(h)) * (interface + count)
+
+
+def test_reference_band_volume_and_perimeter(lsm, orc):
+    """test/test-narrow-band.jl:207-241: the band-only measures reproduce the full-grid ones (compact, two components,
+    clipped by the boundary, slab spanning the domain; 3-D sphere; empty band), and equal the literal restatement of
+    the reference's scanline count."""
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (100, 100))
+    cases = (lambda x: np.hypot(x[0], x[1]) - 0.5,
+             lambda x: np.minimum(np.hypot(x[0] - 0.4, x[1]) - 0.25, np.hypot(x[0] + 0.4, x[1]) - 0.2),
+             lambda x: np.hypot(x[0] - 0.7, x[1]) - 0.6,
+             lambda x: x[1] + 0 * x[0])
+    for f in cases:
+        phi = lsm.MeshField(f, grid)
+        dense = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=phi, bc=lsm.LinearExtrapolationBC())
+        band = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.LinearExtrapolationBC())
+        vb, vd = lsm.volume(band), lsm.volume(dense)
+        assert vb == pytest.approx(vd, rel=1e-7)                      # the reference's ≈ (rtol √eps)
+        m = band.current_state().active_mask()
+        vals = band.current_state().values()
+        ref = _band_volume_ref({tuple(int(i) for i in I): float(vals[tuple(I)]) for I in np.argwhere(m)}, grid.n, grid.meshsize(), min(grid.meshsize()))
+        assert vb == pytest.approx(ref, rel=1e-12)
+    phi = lsm.MeshField(cases[0], grid)
+    dense = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=phi, bc=lsm.LinearExtrapolationBC())
+    band = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.LinearExtrapolationBC())
+    assert lsm.perimeter(band) == pytest.approx(lsm.perimeter(dense), rel=1e-7)
+    assert lsm.perimeter(band) == pytest.approx(2 * np.pi * 0.5, rel=1e-2)
+    g3 = lsm.CartesianGrid((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), (40, 40, 40))
+    p3 = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, g3)
+    d3 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=p3, bc=lsm.LinearExtrapolationBC())
+    b3 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(p3, nlayers=3), bc=lsm.LinearExtrapolationBC())
+    assert lsm.volume(b3) == pytest.approx(lsm.volume(d3), rel=1e-7)
+    m = b3.current_state().active_mask()
+    vals = b3.current_state().values()
+    ref = _band_volume_ref({tuple(int(i) for i in I): float(vals[tuple(I)]) for I in np.argwhere(m)}, g3.n, g3.meshsize(), min(g3.meshsize()))
+    assert lsm.volume(b3) == pytest.approx(ref, rel=1e-12)
+    assert lsm.perimeter(b3) == pytest.approx(lsm.perimeter(d3), rel=1e-7)
+    # an empty band (no interface captured) measures zero
+    flat = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(lambda x: 1.0 + 0 * x[0], grid), nlayers=3),
+                                bc=lsm.LinearExtrapolationBC())
+    assert flat.current_state().active_count() == 0 and lsm.volume(flat) == 0.0
