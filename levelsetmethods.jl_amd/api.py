@@ -223,6 +223,43 @@ class MeshField:
             acc += 1.0 * self._getindexbc(I[:d] + (b + sgn * k,) + I[d + 1:], dim - 1)
         return acc
 
+    # ---- set operations on level sets (src/levelsetops.jl:246-325): union = min, intersection = max,
+    #      complement = negation, difference = max(ϕ₁, -ϕ₂); the in-place forms return self, as the reference's `!` forms
+    def _other(self, o):
+        if not isinstance(o, MeshField) or o.mesh.n != self.mesh.n:
+            raise ValueError("set operations need two MeshFields on the same grid")
+        return o.vals
+
+    def union_(self, o):
+        np.minimum(self.vals, self._other(o), out=self.vals)
+        return self
+
+    def intersect_(self, o):
+        np.maximum(self.vals, self._other(o), out=self.vals)
+        return self
+
+    def complement_(self):
+        np.negative(self.vals, out=self.vals)
+        return self
+
+    def setdiff_(self, o):
+        np.maximum(self.vals, -self._other(o), out=self.vals)
+        return self
+
+    def union(self, o):
+        return self.copy().union_(o)
+
+    def intersect(self, o):
+        return self.copy().intersect_(o)
+
+    def complement(self):
+        return self.copy().complement_()
+
+    def setdiff(self, o):
+        return self.copy().setdiff_(o)
+
+    __or__, __and__, __sub__, __neg__ = union, intersect, setdiff, complement     # ϕ₁ ∪ ϕ₂, ϕ₁ ∩ ϕ₂, setdiff, complement
+
     def __repr__(self):
         s = f"MeshField on {self.mesh!r}"
         if self.vals.ndim == self.mesh.ndim:

@@ -140,3 +140,23 @@ def test_terms_and_equation_argument_checks(lsm):
     assert repr(lsm.ForwardEuler(cfl=0.25)).endswith("cfl: 0.25")
     assert repr(lsm.AdvectionTerm((1.0, 0.0))) == "𝐮 ⋅ ∇ ϕ" and repr(lsm.CurvatureTerm(1.0)) == "b κ|∇ϕ|"
     assert repr(lsm.EikonalReinitializationTerm()) == "sign(ϕ) (|∇ϕ| - 1)"
+
+
+
+def test_set_operations_on_level_sets():
+    """src/levelsetops.jl:246-325 and docs/src/example-zalesak.md:21-26: union = min, intersection = max, complement = -ϕ,
+    setdiff = max(ϕ₁, -ϕ₂); the in-place forms mutate and return their first argument."""
+    import lsm_amd as lsm
+    grid = lsm.CartesianGrid((-1.5, -1.5), (1.5, 1.5), (61, 61))
+    disk = lsm.MeshField(lambda x: np.hypot(x[0] + 0.75, x[1]) - 0.5, grid)
+    rec = lsm.MeshField(lambda x: np.maximum(np.abs(x[0] + 0.75) - 0.1, np.abs(x[1] + 0.25) - 0.5), grid)
+    zal = disk.setdiff(rec)
+    assert np.array_equal(zal.vals, np.maximum(disk.vals, -rec.vals)) and zal is not disk
+    assert np.array_equal(disk.union(rec).vals, np.minimum(disk.vals, rec.vals))
+    assert np.array_equal((disk & rec).vals, np.maximum(disk.vals, rec.vals))
+    assert np.array_equal((-disk).vals, -disk.vals) and np.array_equal((disk - rec).vals, zal.vals)
+    keep = disk.vals.copy()
+    assert disk.union_(rec) is disk and np.array_equal(disk.vals, np.minimum(keep, rec.vals))
+    assert disk.vals.flags.f_contiguous
+    with pytest.raises(ValueError):
+        disk.union(lsm.MeshField(lambda x: x[0], lsm.CartesianGrid((-1, -1), (1, 1), (11, 11))))
