@@ -238,6 +238,15 @@ enum { LSM_GEOM_CURVATURE = 0, LSM_GEOM_GRADIENT = 1, LSM_GEOM_NORMAL = 2 };
 int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_width, double fill, void* out0,
                  void* out1, void* out2, void* frozen_out, void* stream);
 
+/* ---- InterpolatedField(ϕ, order)(x) (src/interpolation.jl:117-151,228-260): value, gradient and Hessian of the piecewise
+ *      polynomial interpolant of ϕ (Bernstein patch of the cell that holds x, odd orders interpolate, even orders fit
+ *      a stencil one node larger; the interpolant `reinitialize!` measures distances to) at `npoints` points.
+ *      points: npoints x ndim doubles on the device (point-major); values: npoints; gradients: npoints x ndim or NULL;
+ *      hessians: npoints x ndim x ndim (row-major) or NULL.  order in 1..5.  phi's ghost layers are refilled on entry
+ *      (dense fields; single device).  Asynchronous on `stream` (NULL = the handle's). */
+int lsm_interpolate(LsmHandle* h, void* phi, int order, int64_t npoints, const void* points, void* values, void* gradients,
+                    void* hessians, void* stream);
+
 /* ---- NarrowBandMeshField (src/meshfield.jl:314-588) on the device.
  *      The band is a byte mask (1 = active node) over the same padded index space as the values
  *      (allocate LsmLayout.total bytes; ghost entries stay 0).  Values stay in the dense padded array.

@@ -268,6 +268,16 @@ end
 gradient_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(1, outs, ϕ; kw...)
 normal_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(2, outs, ϕ; kw...)
 
+# InterpolatedField(ϕ, order) evaluated at points (src/interpolation.jl:117-151,228-260): `pts` is an ndim x npts device matrix
+# (column = point); returns values, and fills `grad` (ndim x npts) / `hess` (ndim x ndim x npts) when given
+function interpolate!(val::ROCVector{Float64}, ϕ::ROCMeshField, order::Integer, pts::ROCMatrix{Float64}; grad = nothing, hess = nothing)
+    _check(ϕ.handle, ccall((:lsm_interpolate, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, pointer(ϕ.buf), order, size(pts, 2), pointer(pts), pointer(val), grad === nothing ? C_NULL : pointer(grad),
+        hess === nothing ? C_NULL : pointer(hess), C_NULL), "lsm_interpolate")
+    return val
+end
+
 # reinitialize!(ϕ; ...) (src/reinitializer.jl:12-42)
 function LSM.reinitialize!(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
     xt, ft = something(xtol, sqrt(eps(Float64))), something(ftol, sqrt(eps(Float64)))

@@ -1268,6 +1268,46 @@ def normal(phi, I):
     return np.array([float(g.values()[tuple(I)]) for g in normal_field(phi)])
 
 
+class InterpolatedField:
+    """InterpolatedField(ϕ, order) (src/interpolation.jl:117-151): the piecewise polynomial interpolant of a dense device
+    field, evaluated on the device.  `itp(x)` for one point or an (npts, ndim) array; `gradient`, `hessian`,
+    `value_and_gradient`, `value_gradient_hessian` as in the reference (:228-260)."""
+
+    def __init__(self, phi, order=3):
+        if not isinstance(phi, ROCMeshField) or isinstance(phi, ROCNarrowBandMeshField):
+            raise ValueError("InterpolatedField wraps a dense device field (ROCMeshField)")
+        if not 1 <= int(order) <= 5:
+            raise ValueError("interpolation order must be in 1..5")
+        self.phi, self.order = phi, int(order)
+
+    def _eval(self, x, grad, hess):
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        pts = x[None, :] if single else x
+        if pts.ndim != 2 or pts.shape[1] != self.phi.mesh.ndim:
+            raise ValueError(f"points must have {self.phi.mesh.ndim} coordinates")
+        v, g, H = self.phi.backend.interpolate(self.phi.buf, self.order, pts, grad, hess)
+        self.phi.ghosts_dirty = False
+        if single:
+            return float(v[0]), (g[0] if grad else None), (H[0] if hess else None)
+        return v, g, H
+
+    def __call__(self, x):
+        return self._eval(x, False, False)[0]
+
+    def gradient(self, x):
+        return self._eval(x, True, False)[1]
+
+    def hessian(self, x):
+        return self._eval(x, False, True)[2]
+
+    def value_and_gradient(self, x):
+        return self._eval(x, True, False)[:2]
+
+    def value_gradient_hessian(self, x):
+        return self._eval(x, True, True)
+
+
 def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
     """reinitialize!(ϕ; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
     (src/reinitializer.jl:12-42): overwrite every active node of ϕ with its signed distance to the interface,

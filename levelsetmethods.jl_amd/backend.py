@@ -155,6 +155,19 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_geometry(self.h, int(what), self.ptr(phi), float(scale), float(band_width), float(fill), o[0], o[1], o[2],
                                               self.ptr(frozen_out), None), "lsm_geometry")
 
+    def interpolate(self, phi, order, pts, want_grad, want_hess):
+        """InterpolatedField evaluation at host points (npts x ndim): returns (values, gradients or None, hessians or None)."""
+        t = self.torch
+        p = t.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(self.device)
+        n, N = int(p.shape[0]), self.ndim
+        val = t.empty(n, dtype=t.float64, device=self.device)
+        grad = t.empty((n, N), dtype=t.float64, device=self.device) if want_grad else None
+        hess = t.empty((n, N, N), dtype=t.float64, device=self.device) if want_hess else None
+        L.check(self.h, self.lib.lsm_interpolate(self.h, self.ptr(phi), int(order), n, self.ptr(p), self.ptr(val), self.ptr(grad), self.ptr(hess), None),
+                "lsm_interpolate")
+        self.sync()
+        return val.cpu().numpy(), (grad.cpu().numpy() if want_grad else None), (hess.cpu().numpy() if want_hess else None)
+
     def extend_along_normals(self, F, phi, frozen, nb_iters, cfl, interface_band, min_norm):
         work = [self.alloc()] + [self.alloc_side() for _ in range(self.ndim)]   # F staging + the normal components
         w = [self.ptr(x) for x in work] + [None] * (4 - len(work))

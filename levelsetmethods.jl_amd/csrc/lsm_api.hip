@@ -1127,6 +1127,24 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
     return LSM_OK;
 }
 
+// InterpolatedField(ϕ, order) evaluated at points — src/interpolation.jl:117-151,228-260
+int lsm_interpolate(LsmHandle* h, void* phi, int order, int64_t npoints, const void* points, void* values, void* gradients, void* hessians,
+                    void* stream) {
+    if (!h || !phi || (npoints > 0 && (!points || !values))) return h ? fail(h, LSM_ERR_INVALID, "lsm_interpolate: null argument") : LSM_ERR_INVALID;
+    if (npoints < 0) return fail(h, LSM_ERR_INVALID, "lsm_interpolate: negative point count");
+    LSM_TRY(check_single_device(h));
+    LSM_TRY(lsm_fill_ghosts(h, phi, 7, stream));
+    const int N = h->grid.ndim;
+    double lc[3] = {0, 0, 0};
+    for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
+    const char* err = nullptr;
+    const int r = interp_run(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, lc, h->h, order, phi, is_f32(h), npoints,
+                             (const double*)points, (double*)values, (double*)gradients, (double*)hessians, stream ? (hipStream_t)stream : h->stream, &err);
+    if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_interpolate");
+    if (r) return fail(h, LSM_ERR_HIP, "lsm_interpolate: launch failed");
+    return LSM_OK;
+}
+
 int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;

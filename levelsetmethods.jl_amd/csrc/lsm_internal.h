@@ -158,6 +158,9 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
                const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
                void* out_field, hipStream_t stream, long long out_counts[3], const char** err);
 
+int interp_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
+               const void* phi, int f32, long long npts, const double* pts, double* val, double* grad, double* hess, hipStream_t stream, const char** err);
+
 // compile-time description of one instantiated fused kernel
 struct Combo {
     int adv;   // 0 none, 1 upwind, 2 weno5

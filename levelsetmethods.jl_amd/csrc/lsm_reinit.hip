@@ -911,6 +911,51 @@ static bool interp_matrix(int order, int ndim, double M[36], int* nv_out, double
     return true;
 }
 
+// ---- InterpolatedField(ϕ, order)(x): value, gradient and Hessian of the piecewise interpolant at arbitrary points
+// (src/interpolation.jl:117-151,228-260): the patch of the cell that holds x (compute_index, clamped to the grid).
+// pts: npts x ndim doubles (point-major); val: npts; grad: npts x ndim; hess: npts x ndim x ndim (row-major, symmetric);
+// grad / hess may be NULL.
+template <int NV>
+__global__ void __launch_bounds__(128) interp_points_kernel(ReinitArgs a, long long npts, const double* pts, double* val, double* grad, double* hess) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npts; p += (long long)gridDim.x * blockDim.x) {
+        double x[3] = {0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) x[d] = pts[p * a.ndim + d];
+        int I[3];
+        cell_of(a, x, I);
+        double v, g[3], H[6];
+        patch_eval<NV>(a, I, x, hess != nullptr, v, g, H);
+        val[p] = v;
+        if (grad) for (int d = 0; d < a.ndim; ++d) grad[p * a.ndim + d] = g[d];
+        if (hess) {
+            const int N = a.ndim;
+            const double full[3][3] = {{H[0], H[3], H[4]}, {H[3], H[1], H[5]}, {H[4], H[5], H[2]}};
+            for (int r = 0; r < N; ++r)
+                for (int c = 0; c < N; ++c) hess[(p * N + r) * N + c] = full[r][c];
+        }
+    }
+}
+static bool interp_matrix(int order, int ndim, double M[36], int* nv_out, double* lambda);
+int interp_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
+               const void* phi, int f32, long long npts, const double* pts, double* val, double* grad, double* hess, hipStream_t stream, const char** err) {
+    ReinitArgs a;
+    a.ndim = ndim;
+    for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.goff[d] = goff[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
+    a.s1 = s1; a.s2 = s2; a.origin = origin;
+    a.order = order; a.upsample = 1; a.maxiters = 1; a.xtol = a.ftol = 0.0;
+    a.phi = phi; a.f32 = f32; a.mask = nullptr;
+    if (!interp_matrix(order, ndim, a.M, &a.nv, &a.lambda)) { *err = "InterpolatedField: order must be in 1..5"; return 1; }
+    a.off = -((a.nv - 1) - 1) / 2;
+    if (a.nv + a.off - 1 > LSM_GHOST + 1 || -a.off > LSM_GHOST) { *err = "InterpolatedField: stencil exceeds the ghost layers"; return 1; }
+    for (int d = 0; d < ndim; ++d)
+        if (n[d] < 2) { *err = "InterpolatedField: at least two nodes per dimension"; return 1; }
+    if (npts <= 0) return 0;
+    const unsigned gb = (unsigned)((npts + 127) / 128 > 65535 ? 65535 : (npts + 127) / 128);
+    if (a.nv == 2) hipLaunchKernelGGL(interp_points_kernel<2>, dim3(gb), dim3(128), 0, stream, a, npts, pts, val, grad, hess);
+    else if (a.nv == 4) hipLaunchKernelGGL(interp_points_kernel<4>, dim3(gb), dim3(128), 0, stream, a, npts, pts, val, grad, hess);
+    else hipLaunchKernelGGL(interp_points_kernel<6>, dim3(gb), dim3(128), 0, stream, a, npts, pts, val, grad, hess);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 // returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
 int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
                const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,

@@ -215,3 +215,65 @@ def test_crystal_normal_extension_signs():
                               integrator=lsm.ForwardEuler(cfl=0.3))
     lsm.integrate_(eq, 2.5e-3, 2.5e-3)
     assert radius_cv(eq.current_state().values()) < cv0
+
+
+@pytest.mark.gpu
+def test_interpolated_field_on_device_reference_tests(orc):
+    """test/test-interpolation.jl:36-80,107-137 through the host API on the device: cubic patches reproduce quadratics
+    with gradient and Hessian (2-D, 3-D), the least-squares order 2 does too; argument checks."""
+    import lsm_amd as lsm
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (21, 21))
+    f = lambda x: x[0] ** 2 + 2 * x[1] ** 2 - 0.5
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(f, grid), bc=lsm.ExtrapolationBC(2))
+    x = np.array([0.15, -0.25])
+    for order in (3, 2):
+        itp = lsm.InterpolatedField(eq.current_state(), order)
+        assert abs(itp(x) - f(x)) < 1e-12
+        assert np.abs(itp.gradient(x) - np.array([2 * x[0], 4 * x[1]])).max() < 1e-12
+    itp = lsm.InterpolatedField(eq.current_state(), 3)
+    assert np.abs(itp.hessian(x) - np.array([[2.0, 0.0], [0.0, 4.0]])).max() < 1e-10
+    v, g = itp.value_and_gradient(x)
+    assert abs(v - f(x)) < 1e-12 and np.abs(g - np.array([0.3, -1.0])).max() < 1e-12
+    v, g, H = itp.value_gradient_hessian(x)
+    assert abs(v - f(x)) < 1e-12 and np.abs(H - np.array([[2.0, 0.0], [0.0, 4.0]])).max() < 1e-10
+    g3 = lsm.CartesianGrid((-1.0,) * 3, (1.0,) * 3, (11, 11, 11))
+    f3 = lambda x: x[0] ** 2 + x[1] ** 2 + x[2] ** 2 - 0.5
+    e3 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(f3, g3), bc=lsm.ExtrapolationBC(2))
+    x3 = np.array([0.1, -0.2, 0.3])
+    it3 = lsm.InterpolatedField(e3.current_state(), 3)
+    assert abs(it3(x3) - f3(x3)) < 1e-12 and np.abs(it3.gradient(x3) - 2 * x3).max() < 1e-12
+    with pytest.raises(ValueError):
+        lsm.InterpolatedField(e3.current_state(), 6)
+    with pytest.raises(ValueError):
+        it3(np.array([0.1, 0.2]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndim,order", [(1, 1), (2, 2), (2, 3), (3, 3), (2, 5), (3, 4)])
+def test_interpolated_field_matches_the_restatement(orc, ndim, order):
+    """Device patch evaluation (the one reinitialize! uses) against tests/_reinit_ref.py at random points, incl. points in
+    boundary cells (stencils reach the ghost layers) and outside the grid (clamped cell): value, gradient, Hessian."""
+    import lsm_amd as lsm
+    from _reinit_ref import ReinitRef
+    n = (17, 15, 13)[:ndim]
+    lc, hc = (-1.0, -0.8, -0.6)[:ndim], (1.0, 1.2, 0.9)[:ndim]
+    og = orc.Grid(lc, hc, n)
+    X = np.meshgrid(*og.coords(), indexing="ij")
+    vals = np.asfortranarray(np.sqrt(sum((x - 0.1 * (d + 1)) ** 2 for d, x in enumerate(X)) + 0.05) - 0.5 + 0.1 * np.sin(2 * X[0]))
+    bcs = ("extrapolation", 2)
+    obc = orc.make_bc(bcs, ndim)
+    ref = ReinitRef(lambda J: orc.get(og, obc, vals, J), n, lc, hc, order=order, cells=[])
+    lg = lsm.CartesianGrid(lc, hc, n)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(vals, lg), bc=lsm.ExtrapolationBC(2))
+    itp = lsm.InterpolatedField(eq.current_state(), order)
+    rng = np.random.default_rng(5)
+    pts = np.array(lc) + rng.random((60, ndim)) * (np.array(hc) - np.array(lc))
+    pts[:5] = np.array(lc) + 1e-3                      # first cell
+    pts[5:10] = np.array(hc) - 1e-3                    # last cell
+    pts[10:12] = np.array(hc) + 0.05                   # outside: the clamped cell's patch, extrapolated
+    v, g, H = itp.value_gradient_hessian(pts)
+    for k, x in enumerate(pts):
+        rv, rg, rH = ref.vgh(ref.cell_of(x), x)
+        assert abs(v[k] - rv) <= 1e-12 * max(1.0, abs(rv)), (k, v[k], rv)
+        assert np.abs(g[k] - rg).max() <= 1e-11 * max(1.0, np.abs(rg).max())
+        assert np.abs(H[k] - rH).max() <= 1e-9 * max(1.0, np.abs(rH).max())
