@@ -8,11 +8,19 @@
 //     neighbours.  Each ψ value is fetched from HBM/L2 once per tile (+halo), every neighbour
 //     read is an LDS ds_read_b64 or a register.
 //   * the LDS planes form a ring of 2·LEAD+2 slots (LEAD = 1 when the curvature term needs the
-//     edge-diagonal neighbours of planes m±1): ONE s_barrier per plane, the next plane's global
-//     loads are issued before the barrier and written to LDS after the compute (issue-early /
-//     write-late), so their latency hides under ≈340 fp64 VALU slots of WENO arithmetic.
-//   * upwind selection never diverges: the biased stencil is fetched through a sign-flipped LDS
-//     stride (x,y) or v_cndmask on the register line (march axis).
+//     edge-diagonal neighbours of planes m±1): ONE s_barrier per plane.
+//   * every global load of a plane — the next plane's centre and halo values, this plane's ϕⁿ, coefficient
+//     fields, frozen sign, the band mask byte of the next plane — is issued BEFORE the plane's barrier and
+//     consumed behind its arithmetic; the store is the last instruction of the iteration.  Vector loads return in
+//     order, so the memory instructions of the loop are kept free of control flow (zero-range descriptors and
+//     out-of-range offsets instead of branches): the compiler's wait counts are exact and nothing is waited for
+//     that has not had a plane's arithmetic (≈230 vector instructions for WENO5 + Eikonal) to arrive.
+//   * field accesses are raw buffer loads/stores (scalar plane descriptor + 32-bit lane offset), march-axis
+//     table entries scalar loads; "plain" variants (template parameter AK) fix what the general kernel reads from
+//     its arguments, which keeps the scalar state inside the SGPR file and the kernel at 5 waves per SIMD.
+//   * upwind selection never diverges: waves with one sign of u_d (almost all) take a scalar branch to a version
+//     with the stencil direction fixed at compile time; the others select per lane (sign-flipped LDS stride in
+//     x,y; v_cndmask on the register line along the march axis).
 #pragma once
 #include <cstdlib>
 #include <type_traits>

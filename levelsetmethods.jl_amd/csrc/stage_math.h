@@ -7,13 +7,14 @@
 //          src/levelsetterms.jl:73-265, src/levelsetops.jl:197-244): true IEEE divisions, no
 //          contraction.  Used to prove indexing / ghost / stage logic bit for bit against the oracle.
 //  FAST    same mathematics reorganised for the fp64 vector pipe, which — not HBM — bounds this
-//          kernel (≈340 fp64 VALU slots per node-stage against 24 bytes):
+//          kernel (≈230 vector instructions per node-stage of WENO5 advection + Eikonal against 24 bytes):
 //            * differences stay undivided (Δ, not Δ/h); WENO5 is homogeneous of degree one, so the
-//              1/h is applied once per dimension and the ε floor becomes 1e-99·h²;
+//              1/h is applied once per dimension and the ε floor becomes 1e-99·h² (raised to 1e-75, see below);
 //            * the three WENO weights use ONE reciprocal: Σ_k c_k Π_{j≠k}(S_j+ε)² d_k / Σ_k c_k Π_{j≠k}(S_j+ε)²
 //              instead of 6 divisions (src/derivatives.jl:73-78);
 //            * divisions/sqrt are v_rcp_f64 / v_rsq_f64 seeds + Newton/Goldschmidt FMA steps (≤2 ulp);
-//            * minmod by sign bits, upwind selection by operand flips.
+//            * the two minmods of an ENO pair as clamps sharing max(w₃,0), min(w₃,0); Godunov sums without selects;
+//              the ENO pair of a WENO5 line from that line's own differences.
 //          Valid for neighbour differences in ~[1e-35, 1e+35] (beyond that the weight products
 //          leave the fp64 range; exactly flat data is handled); within 1e-13·max|ϕ| per stage.
 #pragma once
