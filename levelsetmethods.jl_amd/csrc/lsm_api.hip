@@ -746,6 +746,7 @@ int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_wi
     if (what != LSM_GEOM_CURVATURE && ((N > 1 && !out1) || (N > 2 && !out2)))
         return fail(h, LSM_ERR_INVALID, "lsm_geometry: one output array per dimension is required");
     if (phi == out0 || phi == out1 || phi == out2 || phi == frozen_out) return fail(h, LSM_ERR_INVALID, "lsm_geometry: outputs must not alias phi");
+    LSM_TRY(check_single_device(h));     // the planes of a slab interface would have to be exchanged first
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, stream));
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     launch_geometry(what, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, scale, band_width, fill, phi, is_f32(h),
