@@ -610,7 +610,8 @@ static int check_single_device(LsmHandle* h) {
     const int N = h->grid.ndim;
     if (h->bc[N - 1][0].kind == LSM_BC_NONE || h->bc[N - 1][1].kind == LSM_BC_NONE)
         return fail(h, LSM_ERR_INVALID,
-                    "lsm_advance_*: this handle is a slab of a multi-GPU grid; drive it with lsm_stage + lsm_fill_ghosts + halo exchange");
+                    "this entry point works on a whole grid: the handle is a slab of a multi-GPU grid (drive a slab with lsm_stage + "
+                    "lsm_fill_ghosts + halo exchange)");
     return LSM_OK;
 }
 static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, const void* field, double t) {
