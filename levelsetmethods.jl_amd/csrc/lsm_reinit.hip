@@ -591,13 +591,17 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
             const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
             const int n1 = a.ndim > 1 ? 2 * k1 + 2 : 1, n2 = a.ndim > 2 ? 2 * k2 + 2 : 1;
+            const float inv_n1 = 1.0f / (float)n1, inv_h0 = (float)(1.0 / a.h[0]);
             for (int idx = gl; idx < n1 * n2; idx += GRP) {
-                const int c1 = a.ndim > 1 ? I[1] - k1 - 1 + idx % n1 : 0, c2 = a.ndim > 2 ? I[2] - k2 - 1 + idx / n1 : 0;
+                const int q2 = (int)(((float)idx + 0.5f) * inv_n1), q1 = idx - q2 * n1;     // idx / n1, idx % n1 (small integers: exact)
+                const int c1 = a.ndim > 1 ? I[1] - k1 - 1 + q1 : 0, c2 = a.ndim > 2 ? I[2] - k2 - 1 + q2 : 0;
                 if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) continue;
                 const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0, dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
                 const double rem = bound - dz * dz - dy * dy;
                 if (rem < 0.0) continue;
-                const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
+                // the x-range of the row that can meet the ball, rounded outwards (single precision is enough: every
+                // cell of the range is tested against `rem` exactly below)
+                const int k0 = (int)(__fsqrt_rn((float)rem) * inv_h0 * 1.0001f) + 1;
                 int lo = I[0] - k0 - 1, hi = I[0] + k0;
                 lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
                 const long long row = bits_row(a, c1, c2);
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                         const double dx = gap(0, c0) * a.h[0];
                         if (dx * dx > rem) continue;
                         const unsigned slot = atomicAdd(&qn[g], 1u);
-                        if (slot < QCAP) qcell[g][slot] = c0 + (long long)nc_[0] * (c1 + (long long)nc_[1] * c2);
+                        if (slot < QCAP) qcell[g][slot] = (long long)c0 | ((long long)c1 << 21) | ((long long)c2 << 42);   // 21 bits per index
                     }
                 }
             }
@@ -624,7 +628,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             }
             for (unsigned i = gl; i < nq; i += GRP) {
                 const long long c = *(volatile long long*)&qcell[g][i];
-                scan_cell((int)(c % nc_[0]), (int)((c / nc_[0]) % nc_[1]), (int)(c / ((long long)nc_[0] * nc_[1])));
+                scan_cell((int)(c & 0x1fffff), (int)((c >> 21) & 0x1fffff), (int)((c >> 42) & 0x1fffff));
             }
         }
         // the NSEED nearest of the lanes' bests, nearest first (the first is the exact nearest sample)
