@@ -237,6 +237,11 @@ int lsm_extend_along_normals(LsmHandle* h, void* F, void* phi, const void* froze
 enum { LSM_GEOM_CURVATURE = 0, LSM_GEOM_GRADIENT = 1, LSM_GEOM_NORMAL = 2 };
 int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_width, double fill, void* out0,
                  void* out1, void* out2, void* frozen_out, void* stream);
+/*      The same at the active nodes of a NarrowBandMeshField (the reference's queries work on both field types,
+ *      docs/src/geometry-queries.md): phi must be a prepared stage input (lsm_band_prepare: off-band neighbours hold the
+ *      extrapolated values, out-of-grid ones the boundary values); nodes off the band get `fill` (frozen_out 0). */
+int lsm_band_geometry(LsmHandle* h, int what, const void* phi, const void* mask, double scale, double band_width, double fill,
+                      void* out0, void* out1, void* out2, void* frozen_out, void* stream);
 
 /* ---- InterpolatedField(ϕ, order)(x) (src/interpolation.jl:117-151,228-260): value, gradient and Hessian of the piecewise
  *      polynomial interpolant of ϕ (Bernstein patch of the cell that holds x, odd orders interpolate, even orders fit

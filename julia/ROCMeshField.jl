@@ -265,6 +265,14 @@ function _vector_field!(what::Integer, outs::NTuple{N, ROCVector{Float64}}, ϕ::
         ϕ.handle, what, pointer(ϕ.buf), scale, -1.0, 0.0, o[1], o[2], o[3], C_NULL, C_NULL), "lsm_geometry")
     return outs
 end
+# band fields: the same over the active nodes of a prepared band (`mask` = the band's byte mask)
+function band_curvature_field!(out::ROCVector{Float64}, ϕ::ROCMeshField, mask::ROCVector{UInt8}; scale = 1.0, band = -1.0, fill = 0.0, frozen = nothing)
+    _check(ϕ.handle, ccall((:lsm_band_geometry, libhiplsm), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.handle, 0, pointer(ϕ.buf), pointer(mask), scale, band, fill, pointer(out), C_NULL, C_NULL, frozen === nothing ? C_NULL : pointer(frozen), C_NULL),
+        "lsm_band_geometry")
+    return out
+end
 gradient_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(1, outs, ϕ; kw...)
 normal_field!(outs, ϕ::ROCMeshField; kw...) = _vector_field!(2, outs, ϕ; kw...)
 

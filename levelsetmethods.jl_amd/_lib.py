@@ -89,6 +89,8 @@ _SIGS = [
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("lsm_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    ("lsm_band_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_interpolate", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extend_along_normals", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_double, C.c_double, C.c_double]),

@@ -1224,16 +1224,17 @@ class SideField:
 def _geometry(phi, what, ncomp, scale, band, fill, out, frozen_out):
     if not isinstance(phi, ROCMeshField):
         raise ValueError("ϕ must be a device field (ROCMeshField)")
-    if isinstance(phi, ROCNarrowBandMeshField):
-        raise ValueError("curvature/gradient/normal fields are built for dense device fields (a band state answers ϕ[I] "
-                         "away from the band by extrapolation; prepare its halo and use the term kernels instead)")
     b = phi.backend
+    mask = None
+    if isinstance(phi, ROCNarrowBandMeshField):     # the queries work on both field types (docs/src/geometry-queries.md)
+        phi.prepare(phi.buf)                        # ϕ[I] off the band (extrapolation) and outside the grid (BCs)
+        mask = phi.mask
     outs = out if out is not None else [SideField(b, phi.mesh) for _ in range(ncomp)]
     if len(outs) != ncomp:
         raise ValueError(f"expected {ncomp} output field(s)")
     b.geometry(what, phi.buf, [o.buf if isinstance(o, SideField) else o for o in outs], scale=scale,
                band_width=-1.0 if band is None else float(band), fill=fill,
-               frozen_out=None if frozen_out is None else (frozen_out.buf if isinstance(frozen_out, SideField) else frozen_out))
+               frozen_out=None if frozen_out is None else (frozen_out.buf if isinstance(frozen_out, SideField) else frozen_out), mask=mask)
     phi.ghosts_dirty = False
     return outs
 

@@ -149,11 +149,16 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_extrema(self.h, self.ptr(t), C.byref(lo), C.byref(hi)), "lsm_extrema")
         return lo.value, hi.value
 
-    def geometry(self, what, phi, outs, scale=1.0, band_width=-1.0, fill=0.0, frozen_out=None):
-        """curvature / gradient / normal of phi at every node into fp64 side arrays (lsm_geometry)."""
+    def geometry(self, what, phi, outs, scale=1.0, band_width=-1.0, fill=0.0, frozen_out=None, mask=None):
+        """curvature / gradient / normal of phi at every node (mask: at the band nodes of a prepared band field) into
+        fp64 side arrays (lsm_geometry / lsm_band_geometry)."""
         o = [self.ptr(t) for t in outs] + [None] * (3 - len(outs))
-        L.check(self.h, self.lib.lsm_geometry(self.h, int(what), self.ptr(phi), float(scale), float(band_width), float(fill), o[0], o[1], o[2],
-                                              self.ptr(frozen_out), None), "lsm_geometry")
+        if mask is None:
+            L.check(self.h, self.lib.lsm_geometry(self.h, int(what), self.ptr(phi), float(scale), float(band_width), float(fill), o[0], o[1], o[2],
+                                                  self.ptr(frozen_out), None), "lsm_geometry")
+        else:
+            L.check(self.h, self.lib.lsm_band_geometry(self.h, int(what), self.ptr(phi), self.ptr(mask), float(scale), float(band_width), float(fill),
+                                                       o[0], o[1], o[2], self.ptr(frozen_out), None), "lsm_band_geometry")
 
     def interpolate(self, phi, order, pts, want_grad, want_hess):
         """InterpolatedField evaluation at host points (npts x ndim): returns (values, gradients or None, hessians or None)."""

@@ -756,6 +756,23 @@ int lsm_geometry(LsmHandle* h, int what, void* phi, double scale, double band_wi
     return LSM_OK;
 }
 
+// the same at the active nodes of a NarrowBandMeshField; phi must be a prepared stage input (lsm_band_prepare)
+int lsm_band_geometry(LsmHandle* h, int what, const void* phi, const void* mask, double scale, double band_width, double fill, void* out0,
+                      void* out1, void* out2, void* frozen_out, void* stream) {
+    if (!h || !phi || !mask || !out0) return h ? fail(h, LSM_ERR_INVALID, "lsm_band_geometry: null argument") : LSM_ERR_INVALID;
+    if (what < LSM_GEOM_CURVATURE || what > LSM_GEOM_NORMAL) return fail(h, LSM_ERR_INVALID, "lsm_band_geometry: bad selector");
+    const int N = h->grid.ndim;
+    if (what != LSM_GEOM_CURVATURE && ((N > 1 && !out1) || (N > 2 && !out2)))
+        return fail(h, LSM_ERR_INVALID, "lsm_band_geometry: one output array per dimension is required");
+    if (phi == out0 || phi == out1 || phi == out2 || phi == frozen_out) return fail(h, LSM_ERR_INVALID, "lsm_band_geometry: outputs must not alias phi");
+    LSM_TRY(check_single_device(h));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    launch_geometry(what, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, scale, band_width, fill, phi, is_f32(h),
+                    (double*)out0, (double*)out1, (double*)out2, (double*)frozen_out, s, (const unsigned char*)mask);
+    LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
 // extend_along_normals! (src/velocityextension.jl:20-67): nb_iters first-order upwind pseudo-time
 // sweeps F <- F - τ Σ_d a_d (a_d>0 ? D⁻F : D⁺F) with a = sign-weighted unit normal of ϕ, frozen nodes
 // held fixed.  Each sweep is the fused stage kernel with an Upwind advection term whose velocity is

@@ -732,7 +732,8 @@ void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2,
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) geometry_kernel(int what, int ndim, int n0, int n1, int n2, long long s1, long long s2, long long origin,
                                                        double h0, double h1, double h2, double scale, double band_width, double fill,
-                                                       const void* phip, int f32, double* o0, double* o1, double* o2, double* frozen) {
+                                                       const void* phip, int f32, double* o0, double* o1, double* o2, double* frozen,
+                                                       const unsigned char* mask) {
     auto phi = [&](long long i) { return ld_val(phip, i, f32); };
     const long long total = (long long)n0 * n1 * n2;
     const double hh[3] = {h0, h1, h2};
@@ -742,7 +743,7 @@ __global__ void __launch_bounds__(256) geometry_kernel(int what, int ndim, int n
         const int i0 = (int)(t % n0), i1 = (int)((t / n0) % n1), i2 = (int)(t / ((long long)n0 * n1));
         const long long q = origin + i0 + i1 * s1 + i2 * s2;
         const double c = phi(q);
-        const bool on = band_width < 0.0 || __builtin_fabs(c) <= band_width;
+        const bool on = (band_width < 0.0 || __builtin_fabs(c) <= band_width) && (!mask || mask[q]);   // band fields: active nodes only
         if (frozen) frozen[q] = on ? 1.0 : 0.0;
         if (!on) {
             if (what == LSM_GEOM_CURVATURE) o0[q] = fill;
@@ -781,12 +782,12 @@ __global__ void __launch_bounds__(256) geometry_kernel(int what, int ndim, int n
 }
 void launch_geometry(int what, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double scale,
                      double band_width, double fill, const void* phi, int f32, double* o0, double* o1, double* o2, double* frozen,
-                     hipStream_t s) {
+                     hipStream_t s, const unsigned char* mask) {
     const long long total = (long long)n[0] * n[1] * n[2];
     long long b = (total + 255) / 256;
     const int nb = (int)(b > 8192 ? 8192 : b);
     hipLaunchKernelGGL(geometry_kernel, dim3(nb), dim3(256), 0, s, what, ndim, n[0], n[1], n[2], s1, s2, origin, h[0], h[1], h[2], scale,
-                       band_width, fill, phi, f32, o0, o1, o2, frozen);
+                       band_width, fill, phi, f32, o0, o1, o2, frozen, mask);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -194,7 +194,7 @@ void launch_signed_normals(int ndim, const int n[3], long long s1, long long s2,
                            double* c2, hipStream_t s);
 void launch_geometry(int what, int ndim, const int n[3], long long s1, long long s2, long long origin, const double h[3], double scale,
                      double band_width, double fill, const void* phi, int f32, double* o0, double* o1, double* o2, double* frozen,
-                     hipStream_t s);
+                     hipStream_t s, const unsigned char* mask = nullptr);
 void launch_eikonal_sign(int ndim, const int n[3], long long s1, long long s2, long long origin, double dxmin,
                          const void* phi0, int f32, double* s0, hipStream_t s);
 

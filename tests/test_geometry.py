@@ -277,3 +277,41 @@ def test_interpolated_field_matches_the_restatement(orc, ndim, order):
         assert abs(v[k] - rv) <= 1e-12 * max(1.0, abs(rv)), (k, v[k], rv)
         assert np.abs(g[k] - rg).max() <= 1e-11 * max(1.0, np.abs(rg).max())
         assert np.abs(H[k] - rH).max() <= 1e-9 * max(1.0, np.abs(rH).max())
+
+
+@pytest.mark.gpu
+def test_geometry_queries_on_a_band_field(orc):
+    """docs/src/geometry-queries.md: curvature / gradient / normal work on a NarrowBandMeshField as on a MeshField.  At
+    the band nodes whose whole stencil lies in the band they equal the dense values; elsewhere on the band they use the
+    band's extrapolated neighbours (checked against the dict-based restatement of ϕ[I]); off the band: fill."""
+    import lsm_amd as lsm
+    from _nb_ref import NBRef
+    n = (41, 37)
+    og = orc.Grid((-1.0, -1.0), (1.0, 1.0), n)
+    X = np.meshgrid(*og.coords(), indexing="ij")
+    vals = np.asfortranarray(np.hypot(X[0] - 0.1, X[1] + 0.05) - 0.55)
+    lg = lsm.CartesianGrid(og.lc, og.hc, n)
+    bc = lsm.LinearExtrapolationBC()
+    dense = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(vals, lg), bc=bc).current_state()
+    band = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(vals, lg), nlayers=3), bc=bc).current_state()
+    m = band.active_mask()
+    kd, kb = lsm.curvature_field(dense).values(), lsm.curvature_field(band, fill=-7.0).values()
+    assert np.array_equal(kb[~m], np.full((~m).sum(), -7.0))
+    inner = m.copy()                                             # band nodes whose 3x3 neighbourhood lies in the band
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            inner &= np.roll(np.roll(m, di, 0), dj, 1)
+    inner[[0, -1], :] = False
+    inner[:, [0, -1]] = False
+    assert inner.sum() > 100 and np.array_equal(kb[inner], kd[inner])
+    # the band's edge nodes: the centred differences read extrapolated values, as the reference's nb[I] does
+    ref = NBRef(vals, 3)
+    h = og.meshsize()
+    gb = [g.values() for g in lsm.gradient_field(band)]
+    edge = [tuple(int(i) for i in I) for I in np.argwhere(m & ~inner) if 0 < I[0] < n[0] - 1 and 0 < I[1] < n[1] - 1][:40]
+    assert len(edge) == 40
+    for I in edge:
+        for d in range(2):
+            e = tuple(1 if k == d else 0 for k in range(2))
+            want = (ref.get((I[0] + e[0], I[1] + e[1])) - ref.get((I[0] - e[0], I[1] - e[1]))) / (2 * h[d])
+            assert gb[d][I] == want, (I, d, gb[d][I], want)
