@@ -416,6 +416,15 @@ class ROCNarrowBandMeshField(ROCMeshField):
     def active_nodeindices(self):
         return [tuple(int(i) for i in I) for I in np.argwhere(self.active_mask())]
 
+    def active_cellindices(self):
+        """Cells whose 2^N corners are all band nodes (src/meshfield.jl:364-369), by their lower corner (0-based)."""
+        m = self.active_mask()
+        N = m.ndim
+        ok = np.ones(tuple(k - 1 for k in m.shape), dtype=bool)
+        for off in np.ndindex(*(2,) * N):
+            ok &= m[tuple(slice(o, m.shape[d] - 1 + o) for d, o in enumerate(off))]
+        return [tuple(int(i) for i in I) for I in np.argwhere(ok)]
+
     def values(self):
         """Host copy: stored values on the band, NaN elsewhere."""
         v = self.backend.download(self.buf)

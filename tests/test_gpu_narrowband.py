@@ -483,3 +483,14 @@ def test_reference_band_volume_and_perimeter(lsm, orc):
     flat = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(lambda x: 1.0 + 0 * x[0], grid), nlayers=3),
                                 bc=lsm.LinearExtrapolationBC())
     assert flat.current_state().active_count() == 0 and lsm.volume(flat) == 0.0
+
+
+def test_active_cellindices(lsm):
+    """src/meshfield.jl:364-369: a cell is active when all its corners are band nodes."""
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (31, 29))
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - 0.5, grid), nlayers=2),
+                              bc=lsm.NeumannBC())
+    st = eq.current_state()
+    nodes = set(st.active_nodeindices())
+    want = {I for I in nodes if I[0] < 30 and I[1] < 28 and all((I[0] + a, I[1] + b) in nodes for a in (0, 1) for b in (0, 1))}
+    assert set(st.active_cellindices()) == want and len(want) > 50
