@@ -829,9 +829,15 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     StageArgs b = a;
     b.nb[0] = (a.n[0] + T::TX - 1) / T::TX;
     b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
-    const int mc = a.mc > 0 ? a.mc : T::MC;
-    b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
     if (NDIM >= 2 && a.me <= a.mb) return;
+    int mc = a.mc > 0 ? a.mc : T::MC;
+    // small grids: a workgroup marching 64 planes leaves most of the 256 CUs idle (48^3 = 12 workgroups, a serial walk
+    // of 48 planes each).  Shorter chunks — down to 8 planes — until there are ~8 workgroups per CU; each chunk pays its
+    // 2G+1 planes of prologue, which is why large grids keep the long march.
+    if (a.mc <= 0 && NDIM == 3 && !a.mask)
+        while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
+    b.mc = mc;
+    b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
