@@ -582,6 +582,8 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #ifndef LSM_WAVES_PER_EU
 #define LSM_WAVES_PER_EU 1
 #endif
+// build switches of the A/B experiments recorded in DESIGN.md §3.1 (tools/variants.sh): occupancy hint, and a
+// timing-only build without the per-plane barrier (its results are wrong)
 #ifdef LSM_EXP_NOBARRIER
 #define LSM_BARRIER() do {} while (0)
 #else
@@ -742,9 +744,6 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             for (int d = 0; d < NDIM; ++d) neg_pre[d] = __builtin_amdgcn_ballot_w64(__double2hiint(pre_adv[d]) < 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
-#ifdef LSM_UNROLL_M
-#pragma unroll LSM_UNROLL_M
-#endif
         for (int m = m0; m < m1; ++m) {
             // issue the next plane's loads early; they land in LDS after this plane's arithmetic
             Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
