@@ -161,7 +161,9 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream);
 /* ---- one loop body of _advance! (src/timestepping.jl:128-137,143-164,170-202), all terms fused:
  *      out[I]  = (base - cdt*L_1(psi)[I]) - cdt*L_2(psi)[I] ...
  *      out2[I] = (psi[I] - cdt2*L_1) - cdt2*L_2 ...   (RK2's corr accumulator; NULL to skip)
- *      psi needs valid ghosts; out/out2 ghosts are NOT filled. out may alias phin (pointwise). */
+ *      psi needs valid ghosts; out/out2 ghosts are NOT filled. out may alias phin (pointwise).
+ *      One padded plane of the field (the whole array in 1-D, a row in 2-D) must be smaller than 2 GiB: the kernel
+ *      addresses a plane through a buffer descriptor (LSM_ERR_INVALID otherwise). */
 int lsm_stage(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin,
               void* out, void* out2, int base_mode, double cdt, double cdt2, double t_stage, void* stream);
 
