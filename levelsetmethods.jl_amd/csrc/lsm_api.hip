@@ -75,6 +75,13 @@ struct LsmHandle {
     struct CflCand { LsmTerm key; long long* d_cand; unsigned count; };
     std::vector<CflCand> cfl_cand;                       // SEPARABLE × g(t): the arg-max candidates are time-independent
     unsigned* d_cand_count;
+    // Δt of a ϕ-independent term (constant / catalogued analytic coefficient) is reduced on a stream of its own, with
+    // its own scratch: the host gets it without waiting for the stages queued on the main stream, and can queue the
+    // next step behind them
+    hipStream_t cfl_stream;
+    double *c_partial, *c_result, *ch_result;
+    int* c_flag;
+    std::vector<const void*> cfl_seen;   // coefficient tables known to have landed
     bool prof;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used;
@@ -216,6 +223,12 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->own_stream = true;
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_partial, sizeof(double) * 2 * MAXB);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_flag, sizeof(int));
+    h->cfl_stream = nullptr; h->c_partial = h->c_result = h->ch_result = nullptr; h->c_flag = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cfl_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->c_partial, sizeof(double) * 2 * MAXB);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->c_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->c_result, sizeof(double) * 2);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->ch_result, sizeof(double) * 2, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_w, sizeof(h->w));
     if (e == hipSuccess) e = hipMemcpy(h->d_w, h->w, sizeof(h->w), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 2);
@@ -239,6 +252,9 @@ void lsm_destroy(LsmHandle* h) {
     if (h->d_cand_count) (void)hipFree(h->d_cand_count);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_flag);
+    if (h->cfl_stream) (void)hipStreamDestroy(h->cfl_stream);
+    (void)hipFree(h->c_partial); (void)hipFree(h->c_flag); (void)hipFree(h->c_result);
+    if (h->ch_result) (void)hipHostFree(h->ch_result);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
     if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); }
@@ -530,8 +546,30 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
             a.term_kind = tm.kind;
             fill_coeff(tm.coeff, t, a.coeff);
-            a.partial = h->d_partial;
-            a.nanflag = h->d_flag;
+            // ϕ-independent coefficient, dense field: the reduction runs on the handle's CFL stream with its own scratch and
+            // does not queue behind the stages on the main stream (LSM_CFL_MAIN_STREAM=1 is the A/B switch).  A table is
+            // waited for once, the first time it is seen (its upload was ordered on the main stream).
+            static const bool main_env = getenv("LSM_CFL_MAIN_STREAM") != nullptr;
+            const bool side = !main_env && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD;
+            if (side && tm.coeff.kind == LSM_COEFF_SEPARABLE)
+                for (int c = 0; c < 3; ++c) {
+                    const void* tp = tm.coeff.sep[c];
+                    if (!tp) continue;
+                    bool seen = false;
+                    for (const void* q : h->cfl_seen) seen = seen || q == tp;
+                    if (!seen) {
+                        LSM_HIP(h, hipStreamSynchronize(h->stream));
+                        if (h->cfl_seen.size() > 64) h->cfl_seen.clear();
+                        h->cfl_seen.push_back(tp);
+                    }
+                }
+            hipStream_t cs = side ? h->cfl_stream : h->stream;
+            double* const dpart = side ? h->c_partial : h->d_partial;
+            int* const dflag = side ? h->c_flag : h->d_flag;
+            double* const dres = side ? h->c_result : h->d_result;
+            double* const hres = side ? h->ch_result : h->h_result;
+            a.partial = dpart;
+            a.nanflag = dflag;
             a.mask = h->band_mask;
             if (h->band_mask && h->band_tiles && N > 1) {
                 const BandArgs ba = band_args(h, h->band_mc, nullptr);
@@ -540,7 +578,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             }
             int nb = cfl_blocks(N, h->nloc);
             if (nb > MAXB) nb = MAXB;
-            LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+            LSM_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), cs));
             static const bool single_env = getenv("LSM_CFL_SINGLE_PASS") != nullptr;   // A/B switch
             // (on a band the exact divisions run on the few band nodes only: one pass)
             const bool two_pass = !single_env && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
@@ -558,6 +596,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
                     long long* buf = nullptr;
                     LSM_HIP(h, hipMalloc((void**)&buf, cap * sizeof(long long)));
                     CflArgs b = a;
+                    b.partial = h->d_partial; b.nanflag = h->d_flag;      // one-off search on the main stream, synchronised
                     b.coeff.tfac = 1.0;
                     b.cand = buf; b.cand_count = h->d_cand_count; b.cand_cap = cap;
                     LSM_HIP(h, hipMemsetAsync(h->d_cand_count, 0, sizeof(unsigned), h->stream));
@@ -582,19 +621,19 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             if (cand) {
                 CflArgs b = a;
                 b.cand = cand->d_cand;
-                launch_cfl_candidates(N, b, cand->count, h->stream);
+                launch_cfl_candidates(N, b, cand->count, cs);
                 nb = 1;
             } else if (two_pass) {
-                launch_cfl(N, a, nb, 0, nullptr, h->stream);
-                launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 0, h->stream);
-                launch_cfl(N, a, nb, 1, h->d_result + 1, h->stream);
+                launch_cfl(N, a, nb, 0, nullptr, cs);
+                launch_cfl_final(dpart, nb, dflag, dres, tm.kind, h->dxmin, 0, cs);
+                launch_cfl(N, a, nb, 1, dres + 1, cs);
             } else {
-                launch_cfl(N, a, nb, 1, nullptr, h->stream);
+                launch_cfl(N, a, nb, 1, nullptr, cs);
             }
-            launch_cfl_final(h->d_partial, nb, h->d_flag, h->d_result, tm.kind, h->dxmin, 1, h->stream);
-            LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            LSM_HIP(h, hipStreamSynchronize(h->stream));
-            dt = h->h_result[0];
+            launch_cfl_final(dpart, nb, dflag, dres, tm.kind, h->dxmin, 1, cs);
+            LSM_HIP(h, hipMemcpyAsync(hres, dres, sizeof(double), hipMemcpyDeviceToHost, cs));
+            LSM_HIP(h, hipStreamSynchronize(cs));
+            dt = hres[0];
             if (cacheable) {
                 if (h->cfl_cache.size() > 16) h->cfl_cache.clear();
                 h->cfl_cache.emplace_back(tm, dt);
