@@ -188,6 +188,66 @@ __device__ void bernstein_extrema(const ReinitArgs& a, long long q0, double& lo,
             }
 }
 
+// The same with the stencil size, the coefficient count and the dimension fixed at compile time (orders 1–3): the NV^N
+// stencil values stay in registers (128 VGPRs for 4³) and every loop unrolls — the general version above keeps two
+// 216-value arrays per lane in scratch memory.  For each index i_last of the last dimension the stencil is contracted
+// along that dimension first (one NV^(N-1) slab), then along the others, and the extrema are taken on the fly.
+template <int NV, int NC, int NDIM>
+__device__ void bernstein_extrema_reg(const ReinitArgs& a, long long q0, double& lo, double& hi) {
+    constexpr int V1 = NDIM > 1 ? NV : 1, V2 = NDIM > 2 ? NV : 1;
+    constexpr int C0 = NC, C1 = NDIM > 1 ? NC : 1, CL = NDIM > 2 ? NC : 1;
+    double v[NV * V1 * V2];
+#pragma unroll
+    for (int j2 = 0; j2 < V2; ++j2)
+#pragma unroll
+        for (int j1 = 0; j1 < V1; ++j1)
+#pragma unroll
+            for (int j0 = 0; j0 < NV; ++j0) v[j0 + NV * (j1 + V1 * j2)] = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+    double m[NC * NV];
+#pragma unroll
+    for (int k = 0; k < NC * NV; ++k) m[k] = a.M[k];
+    lo = __builtin_inf(); hi = -__builtin_inf();
+#pragma unroll
+    for (int i2 = 0; i2 < CL; ++i2) {
+        double t[NV * V1];                       // contracted along dimension 2 (3-D) — or the stencil itself
+#pragma unroll
+        for (int k = 0; k < NV * V1; ++k) {
+            if constexpr (NDIM > 2) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc += m[i2 * NV + j] * v[k + NV * V1 * j];
+                t[k] = acc;
+            } else {
+                t[k] = v[k];
+            }
+        }
+        double u[C0 * V1];                       // along dimension 0
+#pragma unroll
+        for (int j1 = 0; j1 < V1; ++j1)
+#pragma unroll
+            for (int i0 = 0; i0 < C0; ++i0) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc += m[i0 * NV + j] * t[j + NV * j1];
+                u[i0 + C0 * j1] = acc;
+            }
+#pragma unroll
+        for (int i1 = 0; i1 < C1; ++i1)          // along dimension 1, extrema on the fly
+#pragma unroll
+            for (int i0 = 0; i0 < C0; ++i0) {
+                double acc;
+                if constexpr (NDIM > 1) {
+                    acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) acc += m[i1 * NV + j] * u[i0 + C0 * j];
+                } else {
+                    acc = u[i0];
+                }
+                lo = acc < lo ? acc : lo; hi = acc > hi ? acc : hi;
+            }
+    }
+}
+
 // ---- 1. candidate cells: active (all corners in the band, src/meshfield.jl:364-369) and not provably empty.
 // (a) every cell: the cheap bound |p - mid| <= Λ·spread over the stencil values -> list of "maybe" cells (wave-
 //     aggregated append); (b) the maybe cells only (≈6x the final count): the reference's own test on the extrema of
@@ -242,6 +302,7 @@ __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* ca
         if (keep) maybe[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
     }
 }
+template <int NV, int NC, int NDIM>   // NV = 0: the general version
 __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const long long* maybe, unsigned nmaybe, int* cand_id,
                                                             long long* cand_cell, unsigned* cand_count) {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nmaybe; i += gridDim.x * blockDim.x) {
@@ -250,7 +311,8 @@ __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const 
         cell_unlin(a, c, I);
         const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
         double clo, chi;
-        bernstein_extrema(a, q0, clo, chi);
+        if constexpr (NV == 0) bernstein_extrema(a, q0, clo, chi);
+        else bernstein_extrema_reg<NV, NC, NDIM>(a, q0, clo, chi);
         if (clo * chi > 0.0) continue;
         const unsigned id = atomicAdd(cand_count, 1u);
         cand_id[c] = (int)id;
@@ -1016,8 +1078,17 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     RE_HIP(hipStreamSynchronize(stream));
     RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
     if (nmaybe) {
-        hipLaunchKernelGGL(reinit_cells2_kernel, dim3((nmaybe + 255) / 256), dim3(256), 0, stream, a, maybe, nmaybe, cand_id, cand_cell,
-                           counters + 1);
+        const dim3 g2((nmaybe + 255) / 256), b2(256);
+#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, maybe, nmaybe, cand_id, cand_cell, counters + 1)
+        const int ncf = order + 1;
+        if (a.nv == 4 && ncf == 4 && ndim == 3) LSM_CELLS2(4, 4, 3);
+        else if (a.nv == 4 && ncf == 4 && ndim == 2) LSM_CELLS2(4, 4, 2);
+        else if (a.nv == 4 && ncf == 3 && ndim == 3) LSM_CELLS2(4, 3, 3);
+        else if (a.nv == 4 && ncf == 3 && ndim == 2) LSM_CELLS2(4, 3, 2);
+        else if (a.nv == 2 && ncf == 2 && ndim == 3) LSM_CELLS2(2, 2, 3);
+        else if (a.nv == 2 && ncf == 2 && ndim == 2) LSM_CELLS2(2, 2, 2);
+        else LSM_CELLS2(0, 0, 0);
+#undef LSM_CELLS2
         RE_HIP(hipMemcpyAsync(&ncand, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
     }
