@@ -550,13 +550,14 @@ constexpr int FINE_SHELLS = 6;
 #endif
 constexpr int GRP = LSM_REINIT_GRP;
 constexpr int QCAP = LSM_REINIT_QCAP;
+template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
                                                                   const unsigned char* cnt, const unsigned long long* bits,
                                                                   const long long* node_list, long long nlist, long long* seeds) {
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0];
-    for (int d = 1; d < a.ndim; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
-    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
+    for (int d = 1; d < ND; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
+    const int nc_[3] = {a.n[0] - 1, ND > 1 ? a.n[1] - 1 : 1, ND > 2 ? a.n[2] - 1 : 1};
     const int lane = threadIdx.x & 63, gl = lane % GRP, gbase = lane - gl;
     const long long ngroups = (long long)gridDim.x * (blockDim.x / GRP);
     __shared__ long long qcell[256 / GRP][QCAP];
@@ -565,14 +566,14 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
         const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         double xq[3] = {0, 0, 0};
-        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
+        for (int d = 0; d < ND; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
         double bd = __builtin_inf();        // this lane's nearest sample so far
         long long bslot = -1;
         double bound = __builtin_inf();     // the group's (pruning only)
         auto scan_cell = [&](int c0, int c1, int c2) {
             const int c[3] = {c0, c1, c2};
             double bx = 0.0;                 // squared distance from the node to the cell
-            for (int d = 0; d < a.ndim; ++d) {
+            for (int d = 0; d < ND; ++d) {
                 const int gap = I[d] < c[d] ? c[d] - I[d] : (I[d] > c[d] + 1 ? I[d] - (c[d] + 1) : 0);
                 bx += (double)gap * a.h[d] * ((double)gap * a.h[d]);
             }
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             for (int k = 0; k < m; ++k) {
                 const long long slot = (long long)id * S + k;
                 double d2 = 0.0;
-                for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                for (int d = 0; d < ND; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
                 if (d2 < bd) { bd = d2; bslot = slot; }
             }
         };
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
         for (int it = 0; it < 5 && have; ++it) {
             int J[3] = {0, 0, 0};
             long long qj = a.origin;
-            for (int d = 0; d < a.ndim; ++d) {
+            for (int d = 0; d < ND; ++d) {
                 int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
                 j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
                 J[d] = j;
@@ -621,21 +622,21 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             if (a.mask && !a.mask[qj]) break;
             const double vj = ld_val(a.phi, qj, a.f32);
             double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
-            for (int d = 0; d < a.ndim; ++d) {
+            for (int d = 0; d < ND; ++d) {
                 const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
                 g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
                 g2 += g[d] * g[d];
                 val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
             }
             if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
-            for (int d = 0; d < a.ndim; ++d) xe[d] -= val * g[d] / g2;
+            for (int d = 0; d < ND; ++d) xe[d] -= val * g[d] / g2;
             if (val * val < 0.0625 * hmin * hmin * g2) break;
         }
         if (have) {     // the rows around the estimate's cell, one per lane
             int E[3];
             cell_of(a, xe, E);
-            const int r1 = a.ndim > 1 ? 3 : 1, r2 = a.ndim > 2 ? 3 : 1;
-            if (gl < r1 * r2) scan_row(E[0] - 1, E[0] + 1, E[1] + (a.ndim > 1 ? gl % 3 - 1 : 0), E[2] + (a.ndim > 2 ? gl / 3 - 1 : 0));
+            const int r1 = ND > 1 ? 3 : 1, r2 = ND > 2 ? 3 : 1;
+            if (gl < r1 * r2) scan_row(E[0] - 1, E[0] + 1, E[1] + (ND > 1 ? gl % 3 - 1 : 0), E[2] + (ND > 2 ? gl / 3 - 1 : 0));
         }
         bound = group_min(bd);
         const double R0 = sqrt(bound);
@@ -651,14 +652,14 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             if (gl == 0) qn[g] = 0;
             __builtin_amdgcn_wave_barrier();
             auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
-            const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
-            const int n1 = a.ndim > 1 ? 2 * k1 + 2 : 1, n2 = a.ndim > 2 ? 2 * k2 + 2 : 1;
+            const int k2 = ND > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = ND > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
+            const int n1 = ND > 1 ? 2 * k1 + 2 : 1, n2 = ND > 2 ? 2 * k2 + 2 : 1;
             const float inv_n1 = 1.0f / (float)n1, inv_h0 = (float)(1.0 / a.h[0]);
             for (int idx = gl; idx < n1 * n2; idx += GRP) {
                 const int q2 = (int)(((float)idx + 0.5f) * inv_n1), q1 = idx - q2 * n1;     // idx / n1, idx % n1 (small integers: exact)
-                const int c1 = a.ndim > 1 ? I[1] - k1 - 1 + q1 : 0, c2 = a.ndim > 2 ? I[2] - k2 - 1 + q2 : 0;
+                const int c1 = ND > 1 ? I[1] - k1 - 1 + q1 : 0, c2 = ND > 2 ? I[2] - k2 - 1 + q2 : 0;
                 if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) continue;
-                const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0, dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
+                const double dz = ND > 2 ? gap(2, c2) * a.h[2] : 0.0, dy = ND > 1 ? gap(1, c1) * a.h[1] : 0.0;
                 const double rem = bound - dz * dz - dy * dy;
                 if (rem < 0.0) continue;
                 // the x-range of the row that can meet the ball, rounded outwards (single precision is enough: every
@@ -1119,8 +1120,10 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
         const long long grp_blocks = (nwork * GRP + 255) / 256;
-        hipLaunchKernelGGL(reinit_search_group_kernel, dim3((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks)), dim3(256), 0, stream, a,
-                           cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
+        const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
+        if (ndim == 3) hipLaunchKernelGGL(reinit_search_group_kernel<3>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
+        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_group_kernel<2>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
+        else hipLaunchKernelGGL(reinit_search_group_kernel<1>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
         hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         if (a.nv == 2)
