@@ -712,23 +712,24 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
 }
 
 // (a) nearest samples of every active node -> seeds[NSEED * w .. ]   (latency-bound: keep it light on registers)
+template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
                                                             const unsigned char* blk, const unsigned long long* bits,
                                                             const long long* node_list, long long nlist, long long* seeds) {
     // one lane per node, for the nodes the group kernel flagged (seeds[0] == -2)
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
-    for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
-    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};      // cells per dimension
+    for (int d = 1; d < ND; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
+    const int nc_[3] = {a.n[0] - 1, ND > 1 ? a.n[1] - 1 : 1, ND > 2 ? a.n[2] - 1 : 1};      // cells per dimension
     const int nb_[3] = {(nc_[0] + RB - 1) / RB, (nc_[1] + RB - 1) / RB, (nc_[2] + RB - 1) / RB};  // blocks per dimension
     int rmax = 1;
-    for (int d = 0; d < a.ndim; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
+    for (int d = 0; d < ND; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
         if (seeds[NSEED * w] != -2) continue;
         const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         double xq[3] = {0, 0, 0};
-        for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
+        for (int d = 0; d < ND; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
         // the NSEED nearest samples, nearest first
         double bd[NSEED];
         long long bslot[NSEED];
@@ -737,7 +738,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         auto box_d2 = [&](int c0, int c1, int c2, int w) {
             const int c[3] = {c0, c1, c2};
             double d2 = 0.0;
-            for (int d = 0; d < a.ndim; ++d) {
+            for (int d = 0; d < ND; ++d) {
                 const int gap = I[d] < c[d] ? c[d] - I[d] : (I[d] > c[d] + w ? I[d] - (c[d] + w) : 0);
                 const double e = (double)gap * a.h[d];
                 d2 += e * e;
@@ -754,7 +755,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
             for (int k = 0; k < m; ++k) {
                 const long long slot = (long long)id * S + k;
                 double d2 = 0.0;
-                for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                for (int d = 0; d < ND; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
                 if (d2 < bd[NSEED - 1]) {                 // sorted insertion, once per sample
                     bool dup = false;
                     for (int p = 0; p < NSEED; ++p) dup = dup || bslot[p] == slot;
@@ -794,7 +795,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
             for (int it = 0; it < 5 && have; ++it) {
                 int J[3] = {0, 0, 0};
                 long long qj = a.origin;
-                for (int d = 0; d < a.ndim; ++d) {
+                for (int d = 0; d < ND; ++d) {
                     int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
                     j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
                     J[d] = j;
@@ -803,33 +804,33 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                 if (a.mask && !a.mask[qj]) break;              // left the band: keep the last iterate
                 const double vj = ld_val(a.phi, qj, a.f32);
                 double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
-                for (int d = 0; d < a.ndim; ++d) {
+                for (int d = 0; d < ND; ++d) {
                     const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
                     g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
                     g2 += g[d] * g[d];
                     val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
                 }
                 if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
-                for (int d = 0; d < a.ndim; ++d) xe[d] -= val * g[d] / g2;
+                for (int d = 0; d < ND; ++d) xe[d] -= val * g[d] / g2;
                 if (val * val < 0.0625 * hmin * hmin * g2) break;   // within a quarter cell of the model's zero
             }
             if (have) {
                 int E[3];
                 cell_of(a, xe, E);
-                for (int c2 = E[2] - (a.ndim > 2 ? 1 : 0); c2 <= E[2] + (a.ndim > 2 ? 1 : 0); ++c2)
-                    for (int c1 = E[1] - (a.ndim > 1 ? 1 : 0); c1 <= E[1] + (a.ndim > 1 ? 1 : 0); ++c1)
+                for (int c2 = E[2] - (ND > 2 ? 1 : 0); c2 <= E[2] + (ND > 2 ? 1 : 0); ++c2)
+                    for (int c1 = E[1] - (ND > 1 ? 1 : 0); c1 <= E[1] + (ND > 1 ? 1 : 0); ++c1)
                         scan_row(E[0] - 1, E[0] + 1, c1, c2);
             }
             const double R0 = bslot[0] >= 0 ? sqrt(bd[0]) : __builtin_inf();
             if (R0 <= 10.0 * hmin) {
                 // gap (in cells) between the node and cell c of dimension d
                 auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
-                const int k2 = a.ndim > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = a.ndim > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
-                for (int c2 = I[2] - k2 - (a.ndim > 2 ? 1 : 0); c2 <= I[2] + k2; ++c2) {
-                    const double dz = a.ndim > 2 ? gap(2, c2) * a.h[2] : 0.0;
+                const int k2 = ND > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = ND > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
+                for (int c2 = I[2] - k2 - (ND > 2 ? 1 : 0); c2 <= I[2] + k2; ++c2) {
+                    const double dz = ND > 2 ? gap(2, c2) * a.h[2] : 0.0;
                     if (dz * dz > bd[0]) continue;
-                    for (int c1 = I[1] - k1 - (a.ndim > 1 ? 1 : 0); c1 <= I[1] + k1; ++c1) {
-                        const double dy = a.ndim > 1 ? gap(1, c1) * a.h[1] : 0.0;
+                    for (int c1 = I[1] - k1 - (ND > 1 ? 1 : 0); c1 <= I[1] + k1; ++c1) {
+                        const double dy = ND > 1 ? gap(1, c1) * a.h[1] : 0.0;
                         const double rem = bd[0] - dz * dz - dy * dy;
                         if (rem < 0.0) continue;
                         const int k0 = (int)(sqrt(rem) / a.h[0]) + 1;
@@ -842,11 +843,11 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         // otherwise: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then farther
         // than s*hmin
         for (int s = 1; s <= FINE_SHELLS && !done; ++s) {
-            const int lo[3] = {I[0] - s, a.ndim > 1 ? I[1] - s : 0, a.ndim > 2 ? I[2] - s : 0};
-            const int hi[3] = {I[0] + s - 1, a.ndim > 1 ? I[1] + s - 1 : 0, a.ndim > 2 ? I[2] + s - 1 : 0};
+            const int lo[3] = {I[0] - s, ND > 1 ? I[1] - s : 0, ND > 2 ? I[2] - s : 0};
+            const int hi[3] = {I[0] + s - 1, ND > 1 ? I[1] + s - 1 : 0, ND > 2 ? I[2] + s - 1 : 0};
             for (int c2 = lo[2]; c2 <= hi[2]; ++c2)
                 for (int c1 = lo[1]; c1 <= hi[1]; ++c1) {
-                    const bool edge12 = (a.ndim > 2 && (c2 == lo[2] || c2 == hi[2])) || (a.ndim > 1 && (c1 == lo[1] || c1 == hi[1]));
+                    const bool edge12 = (ND > 2 && (c2 == lo[2] || c2 == hi[2])) || (ND > 1 && (c1 == lo[1] || c1 == hi[1]));
                     for (int c0 = lo[0]; c0 <= hi[0]; c0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) scan_cell(c0, c1, c2);   // shell cells only
                 }
             done = bslot[0] >= 0 && sqrt(bd[0]) <= (double)s * hmin;
@@ -856,17 +857,17 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         if (!done) {
             const int Bn[3] = {(I[0] < nc_[0] ? I[0] : nc_[0] - 1) / RB, (I[1] < nc_[1] ? I[1] : nc_[1] - 1) / RB, (I[2] < nc_[2] ? I[2] : nc_[2] - 1) / RB};
             for (int r = 0; r <= rmax && !done; ++r) {
-                const int lo[3] = {Bn[0] - r, a.ndim > 1 ? Bn[1] - r : 0, a.ndim > 2 ? Bn[2] - r : 0};
-                const int hi[3] = {Bn[0] + r, a.ndim > 1 ? Bn[1] + r : 0, a.ndim > 2 ? Bn[2] + r : 0};
+                const int lo[3] = {Bn[0] - r, ND > 1 ? Bn[1] - r : 0, ND > 2 ? Bn[2] - r : 0};
+                const int hi[3] = {Bn[0] + r, ND > 1 ? Bn[1] + r : 0, ND > 2 ? Bn[2] + r : 0};
                 for (int b2 = lo[2]; b2 <= hi[2]; ++b2)
                     for (int b1 = lo[1]; b1 <= hi[1]; ++b1) {
-                        const bool edge12 = (a.ndim > 2 && (b2 == lo[2] || b2 == hi[2])) || (a.ndim > 1 && (b1 == lo[1] || b1 == hi[1]));
+                        const bool edge12 = (ND > 2 && (b2 == lo[2] || b2 == hi[2])) || (ND > 1 && (b1 == lo[1] || b1 == hi[1]));
                         for (int b0 = lo[0]; b0 <= hi[0]; b0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) {
                             if (b0 < 0 || b0 >= nb_[0] || b1 < 0 || b1 >= nb_[1] || b2 < 0 || b2 >= nb_[2]) continue;
                             const int B[3] = {b0, b1, b2};
                             if (!blk[blk_lin(a, B)] || box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[0]) continue;
-                            for (int c2 = b2 * RB; c2 < (a.ndim > 2 ? (b2 + 1) * RB : 1); ++c2)
-                                for (int c1 = b1 * RB; c1 < (a.ndim > 1 ? (b1 + 1) * RB : 1); ++c1)
+                            for (int c2 = b2 * RB; c2 < (ND > 2 ? (b2 + 1) * RB : 1); ++c2)
+                                for (int c1 = b1 * RB; c1 < (ND > 1 ? (b1 + 1) * RB : 1); ++c1)
                                     scan_row(b0 * RB, (b0 + 1) * RB - 1, c1, c2);
                         }
                     }
@@ -1124,7 +1125,9 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         if (ndim == 3) hipLaunchKernelGGL(reinit_search_group_kernel<3>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
         else if (ndim == 2) hipLaunchKernelGGL(reinit_search_group_kernel<2>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
         else hipLaunchKernelGGL(reinit_search_group_kernel<1>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
-        hipLaunchKernelGGL(reinit_search_kernel, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
+        if (ndim == 3) hipLaunchKernelGGL(reinit_search_kernel<3>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
+        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_kernel<2>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
+        else hipLaunchKernelGGL(reinit_search_kernel<1>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         if (a.nv == 2)
             hipLaunchKernelGGL(reinit_newton_kernel<2>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
