@@ -125,3 +125,45 @@ def test_2048_squared_zalesak_rotation_step_is_symmetric_under_point_reflection(
     out = eq.current_state().values()
     assert np.abs(out - out[::-1, ::-1]).max() <= 1e-12
     assert np.abs(out - ic.vals).max() > 1e-4                       # it did move
+
+
+def test_stage_refuses_planes_of_two_gib_and_accepts_just_below(lsm):
+    """The stage kernel addresses a padded plane (the whole array in 1-D) through a 2 GiB buffer descriptor: lsm_stage
+    must refuse larger planes loudly, and a plane just below the limit must still be updated correctly at its far end."""
+    import ctypes as C
+    from lsm_amd import _lib as L
+    from lsm_amd.backend import HipBackend
+    import torch
+
+    def backend(n):
+        g = L.LsmGrid()
+        g.ndim, g.n[0], g.n[1], g.n[2] = 1, n, 1, 1
+        g.lc[0], g.hc[0] = 0.0, 1.0
+        bc = L.BcArray()
+        for d in range(3):
+            for s in range(2):
+                bc[d][s].kind, bc[d][s].degree = L.BC_EXTRAPOLATION, 0
+        return HipBackend(g, bc, mode="fast")
+
+    term = (L.LsmTerm * 1)()
+    term[0].kind, term[0].scheme = L.TERM_ADVECTION, L.SCHEME_UPWIND
+    term[0].coeff.kind = L.COEFF_CONST
+    term[0].coeff.value[0] = 1.0
+    big = backend((1 << 28) + 8)                      # (n + 6)·8 bytes >= 2 GiB
+    psi, out = big.alloc(), big.alloc()
+    with pytest.raises(lsm.LsmError, match="smaller than 2 GiB"):
+        big.stage(term, 1, psi, None, out, None, L.BASE_PSI, 1e-3, 0.0, 0.0)
+    del psi, out, big
+    torch.cuda.empty_cache()
+    n = (1 << 28) - 64                                # just below: 2 GiB - 464 bytes
+    b = backend(n)
+    psi, out = b.alloc(), b.alloc()
+    h = 1.0 / (n - 1)
+    org = int(b.lay.origin)
+    psi[org:org + n] = torch.arange(n, dtype=torch.float64, device=psi.device) * h      # ψ = x: D⁻ψ = 1
+    b.fill_ghosts(psi)
+    cdt = 0.25 * h
+    b.stage(term, 1, psi, None, out, None, L.BASE_PSI, cdt, 0.0, 0.0)
+    tail = out[org + n - 1000:org + n].cpu().numpy()
+    want = (np.arange(n - 1000, n) * h) - cdt * 1.0
+    assert np.abs(tail - want).max() <= 1e-12
