@@ -589,9 +589,10 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #else
 #define LSM_BARRIER() __syncthreads()
 #endif
-template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK>
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK, bool MASKED>
 __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const StageArgs a) {
-    constexpr bool PLAIN = AK >= 0;
+    constexpr bool PLAIN = AK >= 0;                 // coefficient kinds, term order and the single output fixed at compile time
+    constexpr bool NOMASK = PLAIN && !MASKED;       // ... and no band mask (MASKED: a plain variant over a narrow band)
     constexpr int CK = PLAIN ? (int)LSM_COEFF_CONST : -1;   // kind of the NormalMotion / curvature coefficients
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
     constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         double r1, r2;
         node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, PLAIN>(a, nv, op, r1, r2);
         // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
-        node_store<ST, PLAIN>(a, io, active && (PLAIN || !a.mask || ldg_u8(uniform_ptr(a.mask + corner), ocold >> 3, (int)0x80000000u) != 0), r1, r2);
+        node_store<ST, PLAIN>(a, io, active && (NOMASK || !a.mask || ldg_u8(uniform_ptr(a.mask + corner), ocold >> 3, (int)0x80000000u) != 0), r1, r2);
     } else {
         double zl[2 * G + 1];
 #pragma unroll
@@ -726,11 +727,11 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
         // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices).  The mask byte
         // of a plane is fetched one plane ahead, unconditionally: without a mask the descriptor's range is 0 and the
         // load returns 0 without an access (a load inside a branch would cost the loop its exact wait counts).
-        const bool nomask = PLAIN || a.mask == nullptr;
+        const bool nomask = NOMASK || a.mask == nullptr;
         const int mrange = nomask ? 0 : (int)0x80000000u;
         long long po = corner + (long long)m0 * sm;     // plane m of the pointwise operands (ϕⁿ, outputs, mask, side arrays)
         unsigned mk_next = 0;
-        if constexpr (!PLAIN) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
+        if constexpr (!NOMASK) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
         const ST* Pnx = plane(m0 + G);                  // plane m+G of ψ, advanced (and clamped) before each use
         const ST* Pn = plane(m0 + LEAD);
         const int plast = nm + G - 1;
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
 #pragma unroll
             for (int h = 0; h < HPT; ++h) hn[h] = ldg(Pn, hg[h]);   // lanes without a halo element: out-of-range offset, no access
             const unsigned mk = mk_next;
-            if constexpr (!PLAIN) mk_next = ldg_u8(uniform_ptr(a.mask + (po + sm)), ocold >> 3, mrange);
+            if constexpr (!NOMASK) mk_next = ldg_u8(uniform_ptr(a.mask + (po + sm)), ocold >> 3, mrange);
             // this plane's pointwise operands (coefficients, ϕⁿ): consumed after the arithmetic
             const NodeIO io{po, ocol, ocold, m + a.goff[NDIM - 1]};
             NodeOps op;
@@ -772,7 +773,7 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             LSM_BARRIER();
             const bool on = active && (nomask || mk != 0);
             double r1 = 0.0, r2 = 0.0;
-            if (PLAIN ? any_active : __builtin_amdgcn_ballot_w64(on) != 0) {   // a wave without a node to update skips the arithmetic (band mode)
+            if (NOMASK ? any_active : __builtin_amdgcn_ballot_w64(on) != 0) {   // a wave without a node to update skips the arithmetic (band mode)
                 const int rel = m - m0;
                 const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
                 const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
@@ -844,12 +845,18 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     // coefficients, and a catalogued advection coefficient
 #if !LSM_STRICT
     int ak = -1;
-    const bool plain = !b.mask && !b.out2 && b.natural && (!NM || b.nm.kind == LSM_COEFF_CONST) && (!CURV || b.curv.kind == LSM_COEFF_CONST) &&
+    const bool plain = !b.out2 && b.natural && (!NM || b.nm.kind == LSM_COEFF_CONST) && (!CURV || b.curv.kind == LSM_COEFF_CONST) &&
                        !getenv("LSM_STAGE_GENERIC");
+    const bool masked = b.mask != nullptr;          // narrow band: the plain variants exist with and without the band mask
     if (plain) ak = ADV ? b.adv.kind : (int)LSM_COEFF_CONST;
     if (ak == LSM_COEFF_FIELD) ak = -1;
 #endif
-#define LSM_LAUNCH(STT, AKK) hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, STT, AKK>), grid, block, 0, s, b)
+#define LSM_LAUNCH1(STT, AKK, MK) hipLaunchKernelGGL((stage_kernel<NDIM, ADV, NM, CURV, EIK, T::TX, T::TY, T::MC, STT, AKK, MK>), grid, block, 0, s, b)
+#if LSM_STRICT
+#define LSM_LAUNCH(STT, AKK) LSM_LAUNCH1(STT, AKK, false)
+#else
+#define LSM_LAUNCH(STT, AKK) do { if ((AKK) >= 0 && masked) LSM_LAUNCH1(STT, AKK, ((AKK) >= 0)); else LSM_LAUNCH1(STT, AKK, false); } while (0)
+#endif
 #if LSM_STRICT
     if (b.f32) LSM_LAUNCH(float, -1); else LSM_LAUNCH(double, -1);
 #else
@@ -859,6 +866,7 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     else { if (b.f32) LSM_LAUNCH(float, -1); else LSM_LAUNCH(double, -1); }
 #endif
 #undef LSM_LAUNCH
+#undef LSM_LAUNCH1
 }
 
 // the instantiated fused combinations (keep in sync with combo_available in lsm_api.hip)
