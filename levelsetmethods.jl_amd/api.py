@@ -869,20 +869,12 @@ class LevelSetEquation:
         import torch
         import torch.distributed as dist
         dev = self.state.buf.device
-        enc = [-1.0 if math.isnan(dt) else dt]                                                # NaN must win
-        if dev.type == "cuda":
-            # on a stream of its own: the 8-byte reduction (and the host's wait for it) must not queue behind the stages
-            # of the previous step on the main stream — the local Δt it combines did not either (lsm_compute_cfl)
-            if getattr(self, "_dt_stream", None) is None:
-                self._dt_stream = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(self._dt_stream):
-                x = torch.tensor(enc, dtype=torch.float64, device=dev)
-                dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.comm)
-                v = float(x.item())
-        else:
-            x = torch.tensor(enc, dtype=torch.float64, device=dev)
-            dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.comm)
-            v = float(x.item())
+        # on the current stream, behind the stages of the previous step: one collective in flight at a time per rank (the
+        # local Δt may come early from the library's CFL stream, but overlapping this all-reduce with the plane exchange
+        # of the previous step would run two communicators concurrently — not worth the 8 bytes)
+        x = torch.tensor([-1.0 if math.isnan(dt) else dt], dtype=torch.float64, device=dev)   # NaN must win
+        dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.comm)
+        v = float(x.item())
         return float("nan") if v < 0 else v
 
     # ---- _advance! (src/timestepping.jl:126-202)
