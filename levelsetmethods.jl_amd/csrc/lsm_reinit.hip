@@ -1024,11 +1024,29 @@ int interp_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-// returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
-int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
-               const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
-               void* out_field, hipStream_t stream, long long out_counts[3], const char** err) {
+// ---- the interface samples of a field and the structures that index them (candidate cells, samples per cell, occupancy
+// bits and blocks): built once per reinitialize! call, or kept in a NewtonSDF object for point queries
+struct SampleSet {
     ReinitArgs a;
+    int S = 0;                 // start points per cell
+    unsigned ncand = 0;        // candidate cells
+    long long nwork = 0;       // active nodes (band) or all nodes
+    int* cand_id = nullptr;
+    long long *cand_cell = nullptr, *maybe = nullptr, *node_list = nullptr;
+    unsigned* counters = nullptr;      // [0] scratch / candidates, [1] nfail, [2] nfar, [3] band nodes
+    double* pts = nullptr;
+    unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
+    unsigned long long* bits = nullptr;
+    void release() {
+        (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(node_list); (void)hipFree(counters);
+        (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(bits);
+        cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; bits = nullptr;
+    }
+};
+
+static int setup_args(ReinitArgs& a, int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3],
+                      const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, const void* phi, int f32,
+                      const unsigned char* mask, const char** err) {
     a.ndim = ndim;
     for (int d = 0; d < 3; ++d) { a.n[d] = n[d]; a.goff[d] = goff[d]; a.lc[d] = lc[d]; a.h[d] = h[d]; }
     a.s1 = s1; a.s2 = s2; a.origin = origin;
@@ -1037,52 +1055,52 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     if (!interp_matrix(order, ndim, a.M, &a.nv, &a.lambda)) { *err = "reinitialize: order must be in 1..5"; return 1; }
     a.off = -((a.nv - 1) - 1) / 2;
     if (a.nv + a.off - 1 > LSM_GHOST + 1 || -a.off > LSM_GHOST) { *err = "reinitialize: stencil exceeds the ghost layers"; return 1; }
+    return 0;
+}
+
+#define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; ss.release(); return 2; } } while (0)
+// candidate cells -> interface samples -> per-cell counts, occupancy bits and blocks (steps 1 and 2 above); ss.a is set
+static int build_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err) {
+    const ReinitArgs& a = ss.a;
+    const int ndim = a.ndim;
+    const int* n = a.n;
     long long nc = 1;
     for (int d = 0; d < ndim; ++d) nc *= n[d] - 1;
-    int S = 1;
-    for (int d = 0; d < ndim; ++d) S *= upsample + 1;
-    int* cand_id = nullptr;
-    long long *cand_cell = nullptr, *maybe = nullptr;
-    unsigned* counters = nullptr;      // [0] candidates, [1] nfail, [2] nfar
-    double* pts = nullptr;
-    unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
-    long long *node_list = nullptr, *seeds = nullptr;
-    unsigned long long* bits = nullptr;
-    auto cleanup = [&]() { (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(counters); (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt);
-                          (void)hipFree(blk); (void)hipFree(node_list); (void)hipFree(seeds); (void)hipFree(bits); };
-#define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; cleanup(); return 2; } } while (0)
-    RE_HIP(hipMalloc((void**)&cand_id, sizeof(int) * (size_t)nc));
-    RE_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
+    ss.S = 1;
+    for (int d = 0; d < ndim; ++d) ss.S *= a.upsample + 1;
+    const int S = ss.S;
+    RE_HIP(hipMalloc((void**)&ss.cand_id, sizeof(int) * (size_t)nc));
+    RE_HIP(hipMalloc((void**)&ss.counters, 4 * sizeof(unsigned)));
     unsigned nmaybe = 0, ncand = 0;
-    RE_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), stream));
+    RE_HIP(hipMemsetAsync(ss.counters, 0, 4 * sizeof(unsigned), stream));
     // band fields: the compact list of the active nodes first — candidate cells, the distance computation and the
     // commit all run over it (the band is ~1 % of a 3-D grid)
     const long long nodes = (long long)n[0] * n[1] * n[2];
-    long long nwork = nodes;
-    if (mask) {
+    ss.nwork = nodes;
+    if (a.mask) {
         unsigned nact = 0;
         const long long nvec = (total + 15) / 16;
         const unsigned gl = (unsigned)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, (long long*)nullptr, counters + 3);
-        RE_HIP(hipMemcpyAsync(&nact, counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, (long long*)nullptr, ss.counters + 3);
+        RE_HIP(hipMemcpyAsync(&nact, ss.counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
-        RE_HIP(hipMalloc((void**)&node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
-        RE_HIP(hipMemsetAsync(counters + 3, 0, sizeof(unsigned), stream));
-        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, node_list, counters + 3);
-        nwork = nact;
-        RE_HIP(hipMemsetAsync(cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
+        RE_HIP(hipMalloc((void**)&ss.node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
+        RE_HIP(hipMemsetAsync(ss.counters + 3, 0, sizeof(unsigned), stream));
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, ss.counters + 3);
+        ss.nwork = nact;
+        RE_HIP(hipMemsetAsync(ss.cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
     }
-    const long long ncell_work = mask ? nwork : nc;
+    const long long ncell_work = a.mask ? ss.nwork : nc;
     const unsigned gb = (unsigned)((ncell_work + 255) / 256 > 65535 ? 65535 : (ncell_work + 255) / 256);
-    RE_HIP(hipMalloc((void**)&maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
-    if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, cand_id, maybe, counters, node_list, nwork);
-    RE_HIP(hipMemcpyAsync(&nmaybe, counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    RE_HIP(hipMalloc((void**)&ss.maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
+    if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, ss.cand_id, ss.maybe, ss.counters, ss.node_list, ss.nwork);
+    RE_HIP(hipMemcpyAsync(&nmaybe, ss.counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     RE_HIP(hipStreamSynchronize(stream));
-    RE_HIP(hipMalloc((void**)&cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
+    RE_HIP(hipMalloc((void**)&ss.cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
     if (nmaybe) {
         const dim3 g2((nmaybe + 255) / 256), b2(256);
-#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, maybe, nmaybe, cand_id, cand_cell, counters + 1)
-        const int ncf = order + 1;
+#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, nmaybe, ss.cand_id, ss.cand_cell, ss.counters + 1)
+        const int ncf = a.order + 1;
         if (a.nv == 4 && ncf == 4 && ndim == 3) LSM_CELLS2(4, 4, 3);
         else if (a.nv == 4 && ncf == 4 && ndim == 2) LSM_CELLS2(4, 4, 2);
         else if (a.nv == 4 && ncf == 3 && ndim == 3) LSM_CELLS2(4, 3, 3);
@@ -1091,62 +1109,80 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         else if (a.nv == 2 && ncf == 2 && ndim == 2) LSM_CELLS2(2, 2, 2);
         else LSM_CELLS2(0, 0, 0);
 #undef LSM_CELLS2
-        RE_HIP(hipMemcpyAsync(&ncand, counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RE_HIP(hipMemcpyAsync(&ncand, ss.counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
     }
-    RE_HIP(hipMemsetAsync(counters, 0, 3 * sizeof(unsigned), stream));
+    ss.ncand = ncand;
+    RE_HIP(hipMemsetAsync(ss.counters, 0, 3 * sizeof(unsigned), stream));
     const size_t slots = (size_t)(ncand ? ncand : 1) * S;
-    RE_HIP(hipMalloc((void**)&pts, sizeof(double) * 3 * slots));
-    RE_HIP(hipMalloc((void**)&valid, slots));
-    RE_HIP(hipMemsetAsync(valid, 0, slots, stream));
+    RE_HIP(hipMalloc((void**)&ss.pts, sizeof(double) * 3 * slots));
+    RE_HIP(hipMalloc((void**)&ss.valid, slots));
+    RE_HIP(hipMemsetAsync(ss.valid, 0, slots, stream));
     size_t nblk = 1;
     for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
-    RE_HIP(hipMalloc((void**)&cnt, (size_t)(ncand ? ncand : 1)));
-    RE_HIP(hipMalloc((void**)&blk, nblk));
-    RE_HIP(hipMemsetAsync(cnt, 0, (size_t)(ncand ? ncand : 1), stream));
-    RE_HIP(hipMemsetAsync(blk, 0, nblk, stream));
+    RE_HIP(hipMalloc((void**)&ss.cnt, (size_t)(ncand ? ncand : 1)));
+    RE_HIP(hipMalloc((void**)&ss.blk, nblk));
+    RE_HIP(hipMemsetAsync(ss.cnt, 0, (size_t)(ncand ? ncand : 1), stream));
+    RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
     size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
     for (int d = 1; d < ndim; ++d) nwords *= (size_t)(n[d] - 1);
-    RE_HIP(hipMalloc((void**)&bits, sizeof(unsigned long long) * nwords));
-    RE_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long) * nwords, stream));
+    RE_HIP(hipMalloc((void**)&ss.bits, sizeof(unsigned long long) * nwords));
+    RE_HIP(hipMemsetAsync(ss.bits, 0, sizeof(unsigned long long) * nwords, stream));
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
-        if (a.nv == 2) hipLaunchKernelGGL(reinit_sample_kernel<2>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
-        else if (a.nv == 4) hipLaunchKernelGGL(reinit_sample_kernel<4>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
-        else hipLaunchKernelGGL(reinit_sample_kernel<6>, dim3(gs), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid);
-        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, cand_cell, ncand, S, pts, valid, cnt, blk, bits);
+        if (a.nv == 2) hipLaunchKernelGGL(reinit_sample_kernel<2>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
+        else if (a.nv == 4) hipLaunchKernelGGL(reinit_sample_kernel<4>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
+        else hipLaunchKernelGGL(reinit_sample_kernel<6>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
+        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid, ss.cnt,
+                           ss.blk, ss.bits);
     }
+    return 0;
+}
+
+// returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
+int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
+               const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
+               void* out_field, hipStream_t stream, long long out_counts[3], const char** err) {
+    SampleSet ss;
+    if (int r = setup_args(ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, phi, f32, mask, err)) return r;
+    if (int r = build_samples(ss, total, stream, err)) return r;
+    const ReinitArgs& a = ss.a;
+    const int S = ss.S;
+    const long long nwork = ss.nwork;
+    long long* seeds = nullptr;
     if (nwork) {
-        RE_HIP(hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork));
+        if (hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return 2; }
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
         const long long grp_blocks = (nwork * GRP + 255) / 256;
         const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
-        if (ndim == 3) hipLaunchKernelGGL(reinit_search_group_kernel<3>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
-        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_group_kernel<2>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
-        else hipLaunchKernelGGL(reinit_search_group_kernel<1>, gg, dim3(256), 0, stream, a, cand_id, S, pts, cnt, bits, node_list, nwork, seeds);
-        if (ndim == 3) hipLaunchKernelGGL(reinit_search_kernel<3>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
-        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_kernel<2>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
-        else hipLaunchKernelGGL(reinit_search_kernel<1>, dim3(gsr), dim3(256), 0, stream, a, cand_id, S, pts, cnt, blk, bits, node_list, nwork, seeds);
+        if (ndim == 3) hipLaunchKernelGGL(reinit_search_group_kernel<3>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
+        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_group_kernel<2>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
+        else hipLaunchKernelGGL(reinit_search_group_kernel<1>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
+        if (ndim == 3) hipLaunchKernelGGL(reinit_search_kernel<3>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_kernel<2>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+        else hipLaunchKernelGGL(reinit_search_kernel<1>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         if (a.nv == 2)
-            hipLaunchKernelGGL(reinit_newton_kernel<2>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
+            hipLaunchKernelGGL(reinit_newton_kernel<2>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
         else if (a.nv == 4)
-            hipLaunchKernelGGL(reinit_newton_kernel<4>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
+            hipLaunchKernelGGL(reinit_newton_kernel<4>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
         else
-            hipLaunchKernelGGL(reinit_newton_kernel<6>, dim3(gn), dim3(128), 0, stream, a, S, pts, node_list, nwork, seeds, out_field, counters + 1, counters + 2);
-    }
-    if (nwork)
+            hipLaunchKernelGGL(reinit_newton_kernel<6>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
         hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nwork + 255) / 256 > 65535 ? 65535 : (nwork + 255) / 256)), dim3(256), 0, stream, a,
-                           out_field, phi, node_list, nwork);
+                           out_field, phi, ss.node_list, nwork);
+    }
     unsigned cn[4] = {0, 0, 0, 0};
-    RE_HIP(hipMemcpyAsync(cn, counters, sizeof(cn), hipMemcpyDeviceToHost, stream));
-    RE_HIP(hipStreamSynchronize(stream));
-    RE_HIP(hipGetLastError());
+    hipError_t e = hipMemcpyAsync(cn, ss.counters, sizeof(cn), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(seeds);
+    const unsigned ncand = ss.ncand;
+    ss.release();
+    if (e != hipSuccess) { *err = "reinitialize: device error"; return 2; }
     out_counts[0] = ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
-#undef RE_HIP
-    cleanup();
     return 0;
 }
+#undef RE_HIP
 
 }  // namespace lsm
