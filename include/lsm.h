@@ -254,6 +254,20 @@ int lsm_band_geometry(LsmHandle* h, int what, const void* phi, const void* mask,
 int lsm_interpolate(LsmHandle* h, void* phi, int order, int64_t npoints, const void* points, void* values, void* gradients,
                     void* hessians, void* stream);
 
+/* ---- NewtonSDF(ϕ; order, upsample, maxiters, xtol, ftol) (src/sdf.jl:57-127): the interface of a private copy of ϕ
+ *      sampled once (the first half of reinitialize!), then signed distances at arbitrary points: exact nearest sample,
+ *      Newton–Lagrange closest point on the seed cell's patch (further near samples as fall-back seeds),
+ *      sign(dot(x - cp, ∇p(cp)))·‖x - cp‖.  phi: ghosts filled (dense) or a prepared band stage input with its mask.
+ *      lsm_sdf_eval: points npoints x ndim doubles on the device; distances npoints; closest_points npoints x ndim or NULL;
+ *      *nfail := queries whose solve did not converge (their best iterate is returned); NaN where the field has no
+ *      interface sample at all.  lsm_sdf_samples: the nsamples x ndim sample points (get_sample_points).  Synchronous. */
+typedef struct LsmSdf LsmSdf;
+int lsm_sdf_create(LsmHandle* h, void* phi, const void* mask, int order, int upsample, int maxiters, double xtol, double ftol,
+                   LsmSdf** out, int64_t* nsamples);
+int lsm_sdf_eval(LsmSdf* s, int64_t npoints, const void* points, void* distances, void* closest_points, int64_t* nfail);
+int lsm_sdf_samples(LsmSdf* s, void* points_out);
+void lsm_sdf_destroy(LsmSdf* s);
+
 /* ---- NarrowBandMeshField (src/meshfield.jl:314-588) on the device.
  *      The band is a byte mask (1 = active node) over the same padded index space as the values
  *      (allocate LsmLayout.total bytes; ghost entries stay 0).  Values stay in the dense padded array.

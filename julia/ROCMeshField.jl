@@ -286,6 +286,30 @@ function interpolate!(val::ROCVector{Float64}, ϕ::ROCMeshField, order::Integer,
     return val
 end
 
+# NewtonSDF(ϕ; ...) (src/sdf.jl:57-127) as a device object: build once, query points, read the samples back
+mutable struct ROCNewtonSDF
+    ptr::Ptr{Cvoid}
+    handle::Ptr{Cvoid}
+    nsamples::Int64
+end
+function ROCNewtonSDF(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters = 10, xtol = nothing, ftol = nothing, mask = nothing)
+    xt, ft = something(xtol, sqrt(eps(Float64))), something(ftol, sqrt(eps(Float64)))
+    out, ns = Ref{Ptr{Cvoid}}(), Ref{Int64}()
+    _check(ϕ.handle, ccall((:lsm_sdf_create, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Float64, Float64, Ref{Ptr{Cvoid}}, Ref{Int64}),
+        ϕ.handle, pointer(ϕ.buf), mask === nothing ? C_NULL : pointer(mask), order, upsample, maxiters, xt, ft, out, ns), "lsm_sdf_create")
+    sdf = ROCNewtonSDF(out[], ϕ.handle, ns[])
+    finalizer(s -> ccall((:lsm_sdf_destroy, libhiplsm), Cvoid, (Ptr{Cvoid},), s.ptr), sdf)
+    return sdf
+end
+# signed distances at the columns of `pts` (ndim x npts device matrix); `cp` optionally receives the closest points
+function (sdf::ROCNewtonSDF)(dist::ROCVector{Float64}, pts::ROCMatrix{Float64}; cp = nothing)
+    nfail = Ref{Int64}()
+    _check(sdf.handle, ccall((:lsm_sdf_eval, libhiplsm), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}),
+        sdf.ptr, size(pts, 2), pointer(pts), pointer(dist), cp === nothing ? C_NULL : pointer(cp), nfail), "lsm_sdf_eval")
+    return dist
+end
+
 # reinitialize!(ϕ; ...) (src/reinitializer.jl:12-42)
 function LSM.reinitialize!(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
     xt, ft = something(xtol, sqrt(eps(Float64))), something(ftol, sqrt(eps(Float64)))

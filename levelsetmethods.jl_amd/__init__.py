@@ -12,7 +12,7 @@ from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm
                   NarrowBandMeshField, NeumannBC, NormalMotionTerm, PeriodicBC, RK2, RK3, RigidRotation, ROCMeshField,
                   ROCNarrowBandMeshField, SeparableCoefficient,
                   SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_, reinitialize_,
-                  perimeter, volume, InterpolatedField, SideField, curvature, curvature_field, gradient, gradient_field, normal, normal_field,
+                  perimeter, volume, InterpolatedField, NewtonSDF, hausdorff_distance, SideField, curvature, curvature_field, gradient, gradient_field, normal, normal_field,
                   vortex_deformation)
 
 __all__ = [
@@ -22,5 +22,5 @@ __all__ = [
     "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
     "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "reinitialize_", "LsmError", "build",
-    "InterpolatedField", "SideField", "curvature", "curvature_field", "gradient", "gradient_field", "normal", "normal_field",
+    "InterpolatedField", "NewtonSDF", "hausdorff_distance", "SideField", "curvature", "curvature_field", "gradient", "gradient_field", "normal", "normal_field",
 ]

@@ -92,6 +92,11 @@ _SIGS = [
     ("lsm_band_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_interpolate", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("lsm_sdf_create", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_int64)]),
+    ("lsm_sdf_eval", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    ("lsm_sdf_samples", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lsm_sdf_destroy", None, [C.c_void_p]),
     ("lsm_extend_along_normals", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_double, C.c_double, C.c_double]),
     ("lsm_band_tile_count", C.c_int, [_H, C.c_int, C.POINTER(C.c_int64)]),

@@ -1321,6 +1321,67 @@ class InterpolatedField:
         return self._eval(x, True, True)
 
 
+class NewtonSDF:
+    """NewtonSDF(ϕ; order = 3, upsample = 2, maxiters = 10, xtol, ftol) (src/sdf.jl:57-78) on the device: samples the
+    interface of a private copy of ϕ once; `sdf(x)` is the signed distance at a point or an (npts, ndim) array of
+    points (src/sdf.jl:80-84); `get_sample_points()`; `closest_point(x)`.  ϕ: a dense or narrow-band device field."""
+
+    def __init__(self, phi, order=3, upsample=2, maxiters=10, xtol=None, ftol=None):
+        if not isinstance(phi, ROCMeshField):
+            raise ValueError("NewtonSDF takes a device field (ROCMeshField / ROCNarrowBandMeshField)")
+        eps = float(np.sqrt(np.finfo(np.float64).eps))
+        b = phi.backend
+        mask = None
+        if isinstance(phi, ROCNarrowBandMeshField):
+            phi.prepare(phi.buf)
+            mask = phi.mask
+        else:
+            b.fill_ghosts(phi.buf)
+            phi.ghosts_dirty = False
+        self.backend, self.ndim = b, phi.mesh.ndim
+        self._h, self.nsamples = b.sdf_create(phi.buf, mask, order, upsample, maxiters, eps if xtol is None else xtol, eps if ftol is None else ftol)
+
+    def _eval(self, x, want_cp):
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        pts = x[None, :] if single else x
+        if pts.ndim != 2 or pts.shape[1] != self.ndim:
+            raise ValueError(f"points must have {self.ndim} coordinates")
+        d, cp, nfail = self.backend.sdf_eval(self._h, pts, want_cp)
+        if single:
+            return float(d[0]), (cp[0] if want_cp else None), nfail
+        return d, cp, nfail
+
+    def __call__(self, x):
+        return self._eval(x, False)[0]
+
+    def closest_point(self, x):
+        """(closest point(s), number of non-converged solves) — _closest_point_on_interface, src/sdf.jl:113-127"""
+        _, cp, nfail = self._eval(x, True)
+        return cp, nfail
+
+    def get_sample_points(self):
+        return self.backend.sdf_samples(self._h, self.nsamples)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None:
+            try:
+                self.backend.sdf_destroy(h)
+            except Exception:
+                pass
+
+
+def hausdorff_distance(sdf1, sdf2):
+    """hausdorff_distance(sdf₁, sdf₂) (src/sdf.jl:129-150): the larger of the two one-sided maxima over the sample points of
+    one interface of the distance to the other."""
+    def one_sided(a, b):
+        pts = a.get_sample_points()
+        cp, _ = b.closest_point(pts)
+        return float(np.sqrt(((pts - cp) ** 2).sum(axis=1)).max())
+    return max(one_sided(sdf1, sdf2), one_sided(sdf2, sdf1))
+
+
 def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
     """reinitialize!(ϕ; order = 3, upsample = 2, maxiters = 20, xtol = nothing, ftol = nothing)
     (src/reinitializer.jl:12-42): overwrite every active node of ϕ with its signed distance to the interface,

@@ -173,6 +173,31 @@ class HipBackend:
         self.sync()
         return val.cpu().numpy(), (grad.cpu().numpy() if want_grad else None), (hess.cpu().numpy() if want_hess else None)
 
+    # ---- NewtonSDF objects (lsm_sdf_*)
+    def sdf_create(self, phi, mask, order, upsample, maxiters, xtol, ftol):
+        out, ns = C.c_void_p(), C.c_int64()
+        L.check(self.h, self.lib.lsm_sdf_create(self.h, self.ptr(phi), self.ptr(mask), int(order), int(upsample), int(maxiters), float(xtol), float(ftol),
+                                                C.byref(out), C.byref(ns)), "lsm_sdf_create")
+        return out, int(ns.value)
+
+    def sdf_eval(self, sdf, pts, want_cp):
+        t = self.torch
+        p = t.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(self.device)
+        n, N = int(p.shape[0]), self.ndim
+        dist = t.empty(n, dtype=t.float64, device=self.device)
+        cp = t.empty((n, N), dtype=t.float64, device=self.device) if want_cp else None
+        nf = C.c_int64()
+        L.check(self.h, self.lib.lsm_sdf_eval(sdf, n, self.ptr(p), self.ptr(dist), self.ptr(cp), C.byref(nf)), "lsm_sdf_eval")
+        return dist.cpu().numpy(), (cp.cpu().numpy() if want_cp else None), int(nf.value)
+
+    def sdf_samples(self, sdf, nsamples):
+        out = self.torch.empty((max(nsamples, 1), self.ndim), dtype=self.torch.float64, device=self.device)
+        L.check(self.h, self.lib.lsm_sdf_samples(sdf, self.ptr(out)), "lsm_sdf_samples")
+        return out[:nsamples].cpu().numpy()
+
+    def sdf_destroy(self, sdf):
+        self.lib.lsm_sdf_destroy(sdf)
+
     def extend_along_normals(self, F, phi, frozen, nb_iters, cfl, interface_band, min_norm):
         work = [self.alloc()] + [self.alloc_side() for _ in range(self.ndim)]   # F staging + the normal components
         w = [self.ptr(x) for x in work] + [None] * (4 - len(work))

@@ -1203,6 +1203,50 @@ int lsm_interpolate(LsmHandle* h, void* phi, int order, int64_t npoints, const v
     return LSM_OK;
 }
 
+// NewtonSDF (src/sdf.jl:57-127): build once, query signed distances at points, read the samples back
+struct LsmSdf { LsmHandle* h; SdfObject* o; int ndim; };
+int lsm_sdf_create(LsmHandle* h, void* phi, const void* mask, int order, int upsample, int maxiters, double xtol, double ftol, LsmSdf** out,
+                   int64_t* nsamples) {
+    if (!h || !phi || !out) return h ? fail(h, LSM_ERR_INVALID, "lsm_sdf_create: null argument") : LSM_ERR_INVALID;
+    if (upsample < 1 || upsample > 16) return fail(h, LSM_ERR_INVALID, "lsm_sdf_create: upsample must be in 1..16");
+    if (maxiters < 1) return fail(h, LSM_ERR_INVALID, "lsm_sdf_create: maxiters must be positive");
+    if (!(xtol > 0) || !(ftol > 0)) return fail(h, LSM_ERR_INVALID, "lsm_sdf_create: tolerances must be positive");
+    LSM_TRY(check_single_device(h));
+    const int N = h->grid.ndim;
+    double lc[3] = {0, 0, 0};
+    for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
+    const char* err = nullptr;
+    SdfObject* o = nullptr;
+    long long ns = 0;
+    const int r = sdf_build(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->lay.total, lc, h->h, order, upsample, maxiters,
+                            xtol, ftol, phi, is_f32(h), (const unsigned char*)mask, h->stream, &o, &ns, &err);
+    if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_sdf_create");
+    if (r) return fail(h, LSM_ERR_HIP, err ? err : "lsm_sdf_create");
+    *out = new LsmSdf{h, o, N};
+    if (nsamples) *nsamples = ns;
+    return LSM_OK;
+}
+int lsm_sdf_eval(LsmSdf* s, int64_t npoints, const void* points, void* distances, void* closest_points, int64_t* nfail) {
+    if (!s || npoints < 0 || (npoints > 0 && (!points || !distances))) return LSM_ERR_INVALID;
+    const char* err = nullptr;
+    long long nf = 0;
+    if (sdf_eval(s->o, npoints, (const double*)points, (double*)distances, (double*)closest_points, &nf, &err))
+        return fail(s->h, LSM_ERR_HIP, err ? err : "lsm_sdf_eval");
+    if (nfail) *nfail = nf;
+    return LSM_OK;
+}
+int lsm_sdf_samples(LsmSdf* s, void* points_out) {
+    if (!s || !points_out) return LSM_ERR_INVALID;
+    const char* err = nullptr;
+    if (sdf_samples(s->o, (double*)points_out, &err)) return fail(s->h, LSM_ERR_HIP, err ? err : "lsm_sdf_samples");
+    return LSM_OK;
+}
+void lsm_sdf_destroy(LsmSdf* s) {
+    if (!s) return;
+    sdf_free(s->o);
+    delete s;
+}
+
 int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;

@@ -161,6 +161,14 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
 int interp_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
                const void* phi, int f32, long long npts, const double* pts, double* val, double* grad, double* hess, hipStream_t stream, const char** err);
 
+struct SdfObject;
+int sdf_build(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
+              const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, const void* phi, int f32,
+              const unsigned char* mask, hipStream_t stream, SdfObject** out, long long* nsamples, const char** err);
+int sdf_eval(SdfObject* o, long long npts, const double* xs, double* dist, double* cps, long long* nfail, const char** err);
+int sdf_samples(SdfObject* o, double* out, const char** err);
+void sdf_free(SdfObject* o);
+
 // compile-time description of one instantiated fused kernel
 struct Combo {
     int adv;   // 0 none, 1 upwind, 2 weno5

@@ -1185,4 +1185,186 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
 }
 #undef RE_HIP
 
+// ---- NewtonSDF(ϕ; order, upsample, maxiters, xtol, ftol) (src/sdf.jl:57-78) as an object: the interface samples of a
+// private copy of ϕ (the reference deep-copies the field) kept on the device, and signed-distance queries at arbitrary
+// points (src/sdf.jl:80-84,113-127): exact nearest sample (the reference: KD-tree nn) -> Newton–Lagrange closest point on
+// the seed cell's patch, further near samples as fall-back seeds -> sign(dot(x - cp, ∇p(cp))) · ‖x - cp‖.
+struct SdfObject {
+    SampleSet ss;
+    void* phi_copy = nullptr;
+    unsigned char* mask_copy = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+// One thread per query point.  The nearest sample: Chebyshev shells of cells around the (clamped) cell of x, occupied
+// cells from the occupancy bits; every cell not yet visited after shell r lies at least r·hmin away from x, so the search
+// stops once the best sample is nearer than that — exact.  The next shell is scanned as well for the fall-back seeds.
+template <int NV>
+__global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
+                                                         const unsigned long long* bits, long long npts, const double* xs, double* dist, double* cps,
+                                                         unsigned* nfail) {
+    double hmin = a.h[0], hmax = a.h[0];
+    for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
+    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
+    int rmax = nc_[0];
+    for (int d = 1; d < a.ndim; ++d) rmax = nc_[d] > rmax ? nc_[d] : rmax;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npts; p += (long long)gridDim.x * blockDim.x) {
+        double xq[3] = {0, 0, 0};
+        for (int d = 0; d < a.ndim; ++d) xq[d] = xs[p * a.ndim + d];
+        int C[3];
+        cell_of(a, xq, C);
+        double bd[NSEED];
+        long long bs[NSEED];
+        for (int k = 0; k < NSEED; ++k) { bd[k] = __builtin_inf(); bs[k] = -1; }
+        auto scan_cell = [&](int c0, int c1, int c2) {
+            const int J[3] = {c0, c1, c2};
+            const int id = cand_id[cell_lin(a, J)];
+            if (id < 0) return;
+            const int m = cnt[id];
+            for (int k = 0; k < m; ++k) {
+                const long long slot = (long long)id * S + k;
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
+                if (!(d2 < bd[NSEED - 1])) continue;
+                int q = NSEED - 1;                        // sorted insertion
+                while (q > 0 && d2 < bd[q - 1]) { bd[q] = bd[q - 1]; bs[q] = bs[q - 1]; --q; }
+                bd[q] = d2; bs[q] = slot;
+            }
+        };
+        auto scan_row = [&](int lo, int hi, int c1, int c2) {      // cells lo..hi of row (c1, c2), by occupancy words
+            if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) return;
+            lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
+            if (lo > hi) return;
+            const long long row = bits_row(a, c1, c2);
+            for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
+                unsigned long long m = bits[row + w0];
+                if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
+                if (w0 == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    scan_cell(w0 * 64 + b, c1, c2);
+                }
+            }
+        };
+        int extra = 1;                                    // shells still to scan after the nearest sample is settled
+        for (int r = 0; r <= rmax && extra >= 0; ++r) {
+            const int r1 = a.ndim > 1 ? r : 0, r2 = a.ndim > 2 ? r : 0;
+            for (int d2i = -r2; d2i <= r2; ++d2i)
+                for (int d1i = -r1; d1i <= r1; ++d1i) {
+                    const bool face = (a.ndim > 2 && (d2i == -r || d2i == r)) || (a.ndim > 1 && (d1i == -r || d1i == r));
+                    if (face || r == 0) scan_row(C[0] - r, C[0] + r, C[1] + d1i, C[2] + d2i);
+                    else { scan_row(C[0] - r, C[0] - r, C[1] + d1i, C[2] + d2i); scan_row(C[0] + r, C[0] + r, C[1] + d1i, C[2] + d2i); }
+                }
+            if (bs[0] >= 0 && bd[0] <= ((double)r * hmin) * ((double)r * hmin)) --extra;
+        }
+        double cp[3] = {xq[0], xq[1], xq[2]}, g[3] = {0, 0, 0};
+        bool conv = false, have = false;
+        if (bs[0] >= 0) {
+            const double safeguard = 1.5 * hmax;
+            double bestd = __builtin_inf();
+            for (int k = 0; k < NSEED && bs[k] >= 0 && !conv; ++k) {
+                const double seed[3] = {pts[3 * bs[k]], pts[3 * bs[k] + 1], pts[3 * bs[k] + 2]};
+                int J[3];
+                cell_of(a, seed, J);
+                double c3[3];
+                conv = closest_on_patch<NV>(a, J, xq, seed, safeguard, c3);
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
+                if (conv || d2 < bestd) {
+                    bestd = d2; cp[0] = c3[0]; cp[1] = c3[1]; cp[2] = c3[2];
+                    double val, H[6];
+                    patch_eval<NV>(a, J, c3, false, val, g, H);      // ∇p(cp) on the seed cell's patch (src/sdf.jl:102-104)
+                    have = true;
+                }
+            }
+        }
+        if (!conv) atomicAdd(nfail, 1u);
+        double d2 = 0.0, dot = 0.0;
+        for (int d = 0; d < a.ndim; ++d) { d2 += (xq[d] - cp[d]) * (xq[d] - cp[d]); dot += (xq[d] - cp[d]) * g[d]; }
+        const double sgn = dot > 0 ? 1.0 : (dot < 0 ? -1.0 : dot);
+        dist[p] = have ? sgn * sqrt(d2) : __builtin_nan("");      // no interface sample at all: NaN
+        if (cps) for (int d = 0; d < a.ndim; ++d) cps[p * a.ndim + d] = cp[d];
+    }
+}
+
+// compacts the valid samples into out (nsamples x ndim, point-major); count only when out == NULL
+__global__ void __launch_bounds__(256) sdf_samples_kernel(int ndim, unsigned ncand, int S, const double* pts, const unsigned char* cnt, double* out,
+                                                          unsigned long long* count) {
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
+        const int m = cnt[id];
+        if (!m) continue;
+        const unsigned long long at = atomicAdd(count, (unsigned long long)m);
+        if (!out) continue;
+        for (int k = 0; k < m; ++k)
+            for (int d = 0; d < ndim; ++d) out[(at + k) * ndim + d] = pts[3 * ((long long)id * S + k) + d];
+    }
+}
+
+int sdf_build(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
+              const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, const void* phi, int f32,
+              const unsigned char* mask, hipStream_t stream, SdfObject** out, long long* nsamples, const char** err) {
+    SdfObject* o = new SdfObject();
+    o->stream = stream;
+    const size_t bytes = (size_t)total * (f32 ? 4 : 8);
+    auto bail = [&](const char* what) { *err = what; (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); o->ss.release(); delete o; return 2; };
+    if (hipMalloc(&o->phi_copy, bytes) != hipSuccess) return bail("hipMalloc(phi copy)");
+    if (hipMemcpyAsync(o->phi_copy, phi, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return bail("copy of phi");
+    if (mask) {
+        if (hipMalloc((void**)&o->mask_copy, (size_t)total) != hipSuccess) return bail("hipMalloc(mask copy)");
+        if (hipMemcpyAsync(o->mask_copy, mask, (size_t)total, hipMemcpyDeviceToDevice, stream) != hipSuccess) return bail("copy of mask");
+    }
+    if (int r = setup_args(o->ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, o->phi_copy, f32, o->mask_copy, err)) {
+        (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); delete o; return r;
+    }
+    if (int r = build_samples(o->ss, total, stream, err)) { (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); delete o; return r; }
+    unsigned long long* cnt = nullptr;
+    unsigned long long hc = 0;
+    if (hipMalloc((void**)&cnt, 8) != hipSuccess || hipMemsetAsync(cnt, 0, 8, stream) != hipSuccess) return bail("hipMalloc(count)");
+    if (o->ss.ncand)
+        hipLaunchKernelGGL(sdf_samples_kernel, dim3((o->ss.ncand + 255) / 256), dim3(256), 0, stream, ndim, o->ss.ncand, o->ss.S, o->ss.pts, o->ss.cnt,
+                           (double*)nullptr, cnt);
+    hipError_t e = hipMemcpyAsync(&hc, cnt, 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(cnt);
+    if (e != hipSuccess) return bail("sample count");
+    *nsamples = (long long)hc;
+    *out = o;
+    return 0;
+}
+int sdf_eval(SdfObject* o, long long npts, const double* xs, double* dist, double* cps, long long* nfail, const char** err) {
+    const ReinitArgs& a = o->ss.a;
+    if (npts <= 0) { if (nfail) *nfail = 0; return 0; }
+    (void)hipMemsetAsync(o->ss.counters + 1, 0, sizeof(unsigned), o->stream);
+    const unsigned gb = (unsigned)((npts + 127) / 128 > 65535 ? 65535 : (npts + 127) / 128);
+#define LSM_SDF(NV_) hipLaunchKernelGGL(sdf_points_kernel<NV_>, dim3(gb), dim3(128), 0, o->stream, a, o->ss.cand_id, o->ss.S, o->ss.pts, o->ss.cnt, o->ss.bits, npts, xs, dist, cps, o->ss.counters + 1)
+    if (a.nv == 2) LSM_SDF(2); else if (a.nv == 4) LSM_SDF(4); else LSM_SDF(6);
+#undef LSM_SDF
+    unsigned nf = 0;
+    hipError_t e = hipMemcpyAsync(&nf, o->ss.counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, o->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { *err = "NewtonSDF evaluation: device error"; return 2; }
+    if (nfail) *nfail = nf;
+    return 0;
+}
+int sdf_samples(SdfObject* o, double* out, const char** err) {
+    unsigned long long* cnt = nullptr;
+    if (hipMalloc((void**)&cnt, 8) != hipSuccess || hipMemsetAsync(cnt, 0, 8, o->stream) != hipSuccess) { *err = "hipMalloc(count)"; return 2; }
+    if (o->ss.ncand)
+        hipLaunchKernelGGL(sdf_samples_kernel, dim3((o->ss.ncand + 255) / 256), dim3(256), 0, o->stream, o->ss.a.ndim, o->ss.ncand, o->ss.S, o->ss.pts,
+                           o->ss.cnt, out, cnt);
+    const hipError_t e = hipStreamSynchronize(o->stream);
+    (void)hipFree(cnt);
+    if (e != hipSuccess) { *err = "NewtonSDF samples: device error"; return 2; }
+    return 0;
+}
+void sdf_free(SdfObject* o) {
+    if (!o) return;
+    o->ss.release();
+    (void)hipFree(o->phi_copy);
+    (void)hipFree(o->mask_copy);
+    delete o;
+}
+
 }  // namespace lsm

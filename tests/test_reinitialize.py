@@ -168,3 +168,111 @@ def test_gpu_narrow_band_reinitialize(lsm):
     exact = np.hypot(X[0] - 0.1, X[1]) - math.sqrt(0.3)
     assert np.abs(v[m] - exact[m]).max() < 1e-4
     assert np.abs(before[m] - exact[m]).max() > 1e-2
+
+
+# ------------------------------------------------------------------ NewtonSDF objects (point queries)
+
+@pytest.mark.gpu
+def test_newton_sdf_2d_circle_reference_test():
+    """test/test-reinitializer.jl:13-36: spot checks inside / on / outside the interface and the sampled-grid error."""
+    import lsm_amd as lsm
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (50, 50))
+    r = 0.5
+    exact = lambda x: np.hypot(x[..., 0], x[..., 1]) - r
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - r, grid), bc=lsm.ExtrapolationBC(2))
+    sdf = lsm.NewtonSDF(eq.current_state(), upsample=4)
+    assert abs(sdf([0.0, 0.0]) + r) < 2e-5
+    assert abs(sdf([r, 0.0])) < 2e-5
+    assert abs(sdf([1.0, 0.0]) - (1 - r)) < 2e-5
+    X = np.stack(np.meshgrid(*grid.coords(), indexing="ij"), axis=-1).reshape(-1, 2, order="F")[::10]
+    assert np.abs(sdf(X) - exact(X)).max() < 1e-5
+    # get_sample_points (:56-63): the samples lie on the interface of the interpolant
+    pts = sdf.get_sample_points()
+    itp = lsm.InterpolatedField(eq.current_state(), 3)
+    assert len(pts) > 0 and np.abs(itp(pts)).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_newton_sdf_3d_sphere_reference_test():
+    """test/test-reinitializer.jl:38-54"""
+    import lsm_amd as lsm
+    grid = lsm.CartesianGrid((-1.0,) * 3, (1.0,) * 3, (25, 25, 25))
+    r = 0.45
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - r, grid),
+                              bc=lsm.ExtrapolationBC(2))
+    sdf = lsm.NewtonSDF(eq.current_state(), upsample=3)
+    assert abs(sdf([r, 0.0, 0.0])) < 1e-4
+    assert abs(sdf([0.0, 0.0, 0.0]) + r) < 1e-4
+    X = np.stack(np.meshgrid(*grid.coords(), indexing="ij"), axis=-1).reshape(-1, 3, order="F")[::20]
+    assert np.abs(sdf(X) - (np.sqrt((X ** 2).sum(axis=1)) - r)).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_newton_sdf_from_a_narrow_band_and_sign_far_outside():
+    """test/test-narrow-band.jl:105-145: an SDF built from a band agrees with the one of the full field near the
+    interface, and its sign far outside the band (domain corners) comes from the closest point's normal."""
+    import lsm_amd as lsm
+    r = 0.5
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (50, 50))
+    f = lambda x: np.hypot(x[0], x[1]) - r
+    band = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(f, grid), nlayers=5), bc=lsm.ExtrapolationBC(2))
+    full = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(f, grid), bc=lsm.ExtrapolationBC(2))
+    sdf, sdf_full = lsm.NewtonSDF(band.current_state(), upsample=4), lsm.NewtonSDF(full.current_state(), upsample=4)
+    assert abs(sdf([r, 0.0])) < 2e-5 and abs(sdf([0.0, 0.0]) + r) < 2e-5
+    for x in ([0.5, 0.0], [0.3, 0.0], [0.6, 0.0]):
+        assert abs(sdf(x) - sdf_full(x)) < 1e-5
+    grid2 = lsm.CartesianGrid((-2.0, -2.0), (2.0, 2.0), (80, 80))
+    band2 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(f, grid2), nlayers=5), bc=lsm.ExtrapolationBC(2))
+    sdf2 = lsm.NewtonSDF(band2.current_state(), upsample=4)
+    for x in ([1.8, 1.8], [-1.8, 1.8], [1.8, -1.8], [-1.8, -1.8]):
+        v = sdf2(x)
+        assert v > 0 and abs(v - (np.hypot(*x) - r)) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_newton_sdf_points_match_the_restatement(orc, ndim):
+    """Closest points and signed distances at random points (near, far, outside the grid) against the literal restatement
+    (exact KD-tree seed + the same Newton–Lagrange solve), to 1e-9."""
+    import lsm_amd as lsm
+    from _reinit_ref import ReinitRef
+    n = (33, 29, 25)[:ndim]
+    lc, hc = (-1.0,) * ndim, (1.0,) * ndim
+    og = orc.Grid(lc, hc, n)
+    X = np.meshgrid(*og.coords(), indexing="ij")
+    vals = np.asfortranarray(np.sqrt(sum((x - 0.05 * (d + 1)) ** 2 for d, x in enumerate(X))) - 0.5 + 0.08 * np.sin(3 * X[0]) * np.cos(2 * X[-1]))
+    obc = orc.make_bc(("extrapolation", 2), ndim)
+    ref = ReinitRef(lambda J: orc.get(og, obc, vals, J), n, lc, hc, order=3, upsample=2, maxiters=10)
+    lg = lsm.CartesianGrid(lc, hc, n)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(vals, lg), bc=lsm.ExtrapolationBC(2))
+    sdf = lsm.NewtonSDF(eq.current_state(), order=3, upsample=2, maxiters=10)
+    assert sdf.nsamples == len(ref.pts)
+    rng = np.random.default_rng(9)
+    pts = -1.0 + 2.0 * rng.random((40, ndim))
+    pts[:4] *= 1.2                                  # some outside the grid
+    cp, nfail = sdf.closest_point(pts)
+    d = sdf(pts)
+    assert nfail == 0
+    for k, x in enumerate(pts):
+        rcp, ok = ref.closest_point(x)
+        assert ok
+        assert np.abs(cp[k] - rcp).max() <= 1e-9, (k, cp[k], rcp)
+        I = ref.cell_of(rcp)
+        _, g, _ = ref.vgh(I, rcp)
+        want = np.sign(np.dot(x - rcp, g)) * np.linalg.norm(x - rcp)
+        assert abs(d[k] - want) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hausdorff_distance_of_two_circles():
+    """src/sdf.jl:129-150: concentric circles of radii 0.5 and 0.6 are 0.1 apart; a shifted one by its shift."""
+    import lsm_amd as lsm
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (81, 81))
+
+    def make(cx, r):
+        eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(lambda x: np.hypot(x[0] - cx, x[1]) - r, grid), bc=lsm.ExtrapolationBC(2))
+        return lsm.NewtonSDF(eq.current_state(), upsample=3)
+    a, b, c = make(0.0, 0.5), make(0.0, 0.6), make(0.07, 0.5)
+    assert abs(lsm.hausdorff_distance(a, b) - 0.1) < 1e-4
+    assert abs(lsm.hausdorff_distance(a, c) - 0.07) < 1e-3
+    assert lsm.hausdorff_distance(a, a) < 1e-7
