@@ -60,10 +60,11 @@ class CartesianGrid:
             g.hc[d] = self.hc[d] if d < self.ndim else 1.0
         return g
 
-    def __repr__(self):
-        dom = " × ".join(f"[{a}, {b}]" for a, b in zip(self.lc, self.hc))
-        return (f"CartesianGrid in ℝ{self.ndim}\n  ├─ domain:  {dom}\n  ├─ nodes:   {' × '.join(map(str, self.n))}\n"
-                f"  └─ spacing: h = ({', '.join(f'{x:.4g}' for x in self.meshsize())})")
+    def _show(self):
+        """src/meshes.jl:226-242."""
+        return "\n".join([f"CartesianGrid in ℝ{_superscript(self.ndim)}"] + _grid_fields(self))
+
+    __repr__ = _show
 
 
 # ----------------------------------------------------------------------------- boundaryconditions.jl
@@ -142,6 +143,95 @@ def _bc_c(bcs, ndim, slab_faces=(False, False)):
             else:
                 arr[d][s].kind, arr[d][s].degree = L.BC_EXTRAPOLATION, 0
     return arr
+
+
+# ----------------------------------------------------------------------------- show (text/plain) helpers
+# The reference prints trees (src/meshes.jl:226-242, src/meshfield.jl:294-312,395-414, src/levelsetequation.jl:91-116,
+# src/boundaryconditions.jl:197-211, src/timestepping.jl:94-97; checked by test/test-show.jl): `show(x)` returns the
+# same text, `repr(x)` of an equation the compact one-line form.
+
+def _superscript(n):
+    return "".join("⁰¹²³⁴⁵⁶⁷⁸⁹"[int(d)] for d in str(int(n)))
+
+
+def _jl_float(x):
+    """A Float64 as Julia prints it: shortest round-trip digits, exponent form below 1e-4 and from 1e6 on."""
+    x = float(x)
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    if x == 0.0:
+        return "-0.0" if math.copysign(1.0, x) < 0 else "0.0"
+    r = repr(x)
+    mant, _, ex = r.partition("e")
+    if "e" in r:
+        e = int(ex)
+        digits = mant.replace("-", "").replace(".", "")
+        point = (mant.replace("-", "").index(".") if "." in mant else len(mant.replace("-", ""))) + e
+    else:
+        digits = mant.replace("-", "").replace(".", "")
+        point = mant.replace("-", "").index(".") if "." in mant else len(digits)
+    lead = len(digits) - len(digits.lstrip("0"))
+    digits, point = digits[lead:].rstrip("0") or "0", point - lead
+    sign = "-" if x < 0 else ""
+    e10 = point - 1                                  # decimal exponent of the leading digit
+    if -5 < e10 < 6:                                 # Julia: plain notation for 1e-4 <= |x| < 1e6
+        if point <= 0:
+            return f"{sign}0.{'0' * (-point)}{digits}"
+        if point >= len(digits):
+            return f"{sign}{digits}{'0' * (point - len(digits))}.0"
+        return f"{sign}{digits[:point]}.{digits[point:]}"
+    return f"{sign}{digits[0]}.{digits[1:] or '0'}e{e10}"
+
+
+def _sig4(x):
+    """round(x; sigdigits = 4) printed as Julia prints the result."""
+    x = float(x)
+    if x == 0.0 or math.isnan(x) or math.isinf(x):
+        return _jl_float(x)
+    return _jl_float(float(f"{x:.3e}"))
+
+
+def _bc_str(bcs):
+    """src/boundaryconditions.jl:197-211."""
+    allb = [b for pair in bcs for b in pair]
+    if all(_same_bc(b, allb[0]) for b in allb):
+        return f"{allb[0]!r} (all)"
+    names = ("x", "y", "z") if len(bcs) <= 3 else tuple(f"d{i + 1}" for i in range(len(bcs)))
+    return ", ".join(f"{names[d]}: " + (repr(l) if _same_bc(l, r) else f"{l!r} ↔ {r!r}") for d, (l, r) in enumerate(bcs))
+
+
+def _grid_fields(g, prefix="  ", last=True):
+    dom = " × ".join(f"[{_jl_float(a)}, {_jl_float(b)}]" for a, b in zip(g.lc, g.hc))
+    h = "(" + ", ".join(_sig4(x) for x in g.meshsize()) + ")"
+    return [f"{prefix}├─ domain:  {dom}", f"{prefix}├─ nodes:   {' × '.join(map(str, g.n))}",
+            f"{prefix}{'└─' if last else '├─'} spacing: h = {h}"]
+
+
+def _field_fields(mesh, bcs, valtype, extrema, prefix="  ", active=None):
+    lines = _grid_fields(mesh, prefix, last=False)
+    if bcs is not None:
+        lines.append(f"{prefix}├─ bc:     {_bc_str(bcs)}")
+    if active is not None:
+        lines.append(f"{prefix}├─ active:  {active[0]} nodes ({active[1]}-layer halo)")
+    if extrema is None:
+        lines.append(f"{prefix}└─ valtype: {valtype}")
+    else:
+        lines.append(f"{prefix}├─ valtype: {valtype}")
+        lines.append(f"{prefix}└─ values:  min = {_sig4(extrema[0])},  max = {_sig4(extrema[1])}")
+    return lines
+
+
+def _embed_show(label, text, indent="  "):
+    """src/levelsetequation.jl:91-99."""
+    parts = text.split("\n")
+    return [f"{indent}├─ {label}: {parts[0]}"] + [f"{indent}│{line}" for line in parts[1:]]
+
+
+def show(x):
+    """The text/plain `show` of the reference for grids, fields, integrators and equations (test/test-show.jl)."""
+    return x._show() if hasattr(x, "_show") else repr(x)
 
 
 # ----------------------------------------------------------------------------- meshfield.jl
@@ -260,11 +350,15 @@ class MeshField:
 
     __or__, __and__, __sub__, __neg__ = union, intersect, setdiff, complement     # ϕ₁ ∪ ϕ₂, ϕ₁ ∩ ϕ₂, setdiff, complement
 
-    def __repr__(self):
-        s = f"MeshField on {self.mesh!r}"
-        if self.vals.ndim == self.mesh.ndim:
-            s += f"\n  values: min = {self.vals.min():.4g},  max = {self.vals.max():.4g}"
-        return s
+    def _show(self):
+        """src/meshfield.jl:294-312."""
+        scalar = self.vals.ndim == self.mesh.ndim
+        et = "Float32" if self.vals.dtype == np.float32 else "Float64"
+        vt = et if scalar else f"SVector{{{self.vals.shape[0]}, {et}}}"
+        ext = (self.vals.min(), self.vals.max()) if scalar else None
+        return "\n".join([f"MeshField on CartesianGrid in ℝ{_superscript(self.mesh.ndim)}"] + _field_fields(self.mesh, self.bcs, vt, ext))
+
+    __repr__ = _show
 
 
 class LazyMeshField:
@@ -345,9 +439,15 @@ class ROCMeshField:
         self.buf[self._offset(I)] = float(val)
         self.ghosts_dirty = True
 
-    def __repr__(self):
-        lo, hi = self.extrema()
-        return f"ROCMeshField on {self.mesh!r}\n  values: min = {lo:.4g},  max = {hi:.4g}"
+    def _valtype(self):
+        return "Float32" if np.dtype(getattr(self.backend, "dtype", np.float64)) == np.float32 else "Float64"
+
+    def _show(self):
+        """src/meshfield.jl:294-312 — the device field prints as the reference's MeshField does (extrema by lsm_extrema)."""
+        return "\n".join([f"MeshField on CartesianGrid in ℝ{_superscript(self.mesh.ndim)}"] +
+                         _field_fields(self.mesh, self.bcs, self._valtype(), self.extrema()))
+
+    __repr__ = _show
 
 
 class NarrowBandMeshField:
@@ -412,6 +512,15 @@ class ROCNarrowBandMeshField(ROCMeshField):
 
     def active_count(self):
         return self.backend.band_count(self.mask)
+
+    def _show(self):
+        """src/meshfield.jl:395-414: the extrema are those of the band's values (off-band entries are scratch)."""
+        vals = self.values()[self.active_mask()]
+        ext = (vals.min(), vals.max()) if vals.size else (float("nan"), float("nan"))
+        return "\n".join([f"NarrowBandMeshField on CartesianGrid in ℝ{_superscript(self.mesh.ndim)}"] +
+                         _field_fields(self.mesh, self.bcs, self._valtype(), ext, active=(self.active_count(), self.nlayers)))
+
+    __repr__ = _show
 
     def active_nodeindices(self):
         return [tuple(int(i) for i in I) for I in np.argwhere(self.active_mask())]
@@ -687,8 +796,11 @@ class TimeIntegrator:
     def __init__(self, cfl=0.5):
         self.cfl = float(cfl)
 
-    def __repr__(self):
-        return f"{self._describe}\n  └─ cfl: {self.cfl}"
+    def _show(self):
+        """src/timestepping.jl:94-97."""
+        return f"{self._describe}\n  └─ cfl: {_jl_float(self.cfl)}"
+
+    __repr__ = _show
 
 
 class ForwardEuler(TimeIntegrator):
@@ -836,9 +948,18 @@ class LevelSetEquation:
     def time_integrator(self):
         return self.integrator
 
+    def _pde(self):
+        return "ϕₜ + " + " + ".join(repr(t) for t in self.terms) + " = 0"
+
+    def _show(self):
+        """src/levelsetequation.jl:101-110 (text/plain)."""
+        lines = ["LevelSetEquation", f"  ├─ equation: {self._pde()}", f"  ├─ time:     {_jl_float(self.t)}"]
+        lines += _embed_show("integrator", show(self.integrator)) + _embed_show("state", show(self.state))
+        return "\n".join(lines + ["  ╰─"])
+
     def __repr__(self):
-        terms = " + ".join(repr(t) for t in self.terms)
-        return f"LevelSetEquation\n  ├─ equation: ϕₜ + {terms} = 0\n  ├─ time:     {self.t}\n  ├─ integrator: {self.integrator._describe}"
+        """src/levelsetequation.jl:113-117 (compact form)."""
+        return f"LevelSetEquation({self._pde()}, t={_jl_float(self.t)})"
 
     # ---- update_term! (src/levelsetterms.jl:14,65-69,148-152) + slow-path coefficient sampling
     def _needs_hook(self):

@@ -227,19 +227,24 @@ LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pr
 
 // Everything one node needs: pointers into the LDS ring at the node's own position and the
 // register line along the march axis.
-template <int NDIM, int G, int W>
+// RN > 0: the register line is a RING of RN = 2G+1 entries — plane m+k sits in zl[(R + G + k) % RN], R = the
+// iteration's rotation, a compile-time constant of an RN-fold unrolled plane loop: advancing a plane overwrites the
+// oldest entry instead of shifting the line (2G v_mov_b64 per plane, 4 issue cycles each on gfx950).
+template <int NDIM, int G, int W, int R = 0, int RN = 0>
 struct NodeView {
     const double* T0;   // plane m   (own position)
     const double* Tm;   // plane m-1 (curvature only)
     const double* Tp;   // plane m+1 (curvature only)
-    const double* zl;   // register line, zl[G] = centre (MARCH only)
+    const double* zl;   // register line, z(0) = centre (MARCH only)
     double c;           // centre value
+    // neighbour at offset k along the march axis
+    LSM_DEV double z(int k) const { return zl[RN > 0 ? (R + G + k + RN) % (RN > 0 ? RN : 1) : G + k]; }
     // neighbour at offset k along dimension D
     template <int D>
     LSM_DEV double at(int k) const {
         if constexpr (D == 0) return T0[k];
         else if constexpr (D == 1 && NDIM == 3) return T0[k * W];
-        else return zl[G + k];
+        else return z(k);
     }
     // neighbour at (sa along A, sb along B), A<B, for the mixed second difference
     template <int A, int B>
@@ -281,8 +286,8 @@ LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, bool have_n
     };
     auto reg = [&](auto Sc) {            // march-axis neighbours from the register line
         constexpr int ss = decltype(Sc)::value;
-        return weno5_undivided_pq<PQ>(nv.zl[G - 2 * ss] - nv.zl[G - 3 * ss], nv.zl[G - ss] - nv.zl[G - 2 * ss], nv.c - nv.zl[G - ss],
-                                      nv.zl[G + ss] - nv.c, nv.zl[G + 2 * ss] - nv.zl[G + ss], epsf, P, Q);
+        return weno5_undivided_pq<PQ>(nv.z(-2 * ss) - nv.z(-3 * ss), nv.z(-ss) - nv.z(-2 * ss), nv.c - nv.z(-ss),
+                                      nv.z(ss) - nv.c, nv.z(2 * ss) - nv.z(ss), epsf, P, Q);
     };
     constexpr bool IN_LDS = D == 0 || (D == 1 && NDIM == 3);
     double w;
@@ -303,12 +308,12 @@ LSM_DEV double weno_term(const NV& nv, const StageArgs& a, double v, bool have_n
             q[3] = nv.c;
             q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
         } else {
-            q[0] = sel64(m, nv.zl[G - 3], nv.zl[G + 3]);
-            q[1] = sel64(m, nv.zl[G - 2], nv.zl[G + 2]);
-            q[2] = sel64(m, nv.zl[G - 1], nv.zl[G + 1]);
+            q[0] = sel64(m, nv.z(-3), nv.z(3));
+            q[1] = sel64(m, nv.z(-2), nv.z(2));
+            q[2] = sel64(m, nv.z(-1), nv.z(1));
             q[3] = nv.c;
-            q[4] = sel64(m, nv.zl[G + 1], nv.zl[G - 1]);
-            q[5] = sel64(m, nv.zl[G + 2], nv.zl[G - 2]);
+            q[4] = sel64(m, nv.z(1), nv.z(-1));
+            q[5] = sel64(m, nv.z(2), nv.z(-2));
         }
         w = weno5_undivided_pq<PQ>(q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], epsf, P, Q);
     }
@@ -327,12 +332,12 @@ LSM_DEV double weno_dim(const NV& nv, const StageArgs& a, double v) {
         q[3] = nv.c;
         q[4] = nv.T0[ss]; q[5] = nv.T0[2 * ss];
     } else {
-        q[0] = up ? nv.zl[G - 3] : nv.zl[G + 3];
-        q[1] = up ? nv.zl[G - 2] : nv.zl[G + 2];
-        q[2] = up ? nv.zl[G - 1] : nv.zl[G + 1];
+        q[0] = up ? nv.z(-3) : nv.z(3);
+        q[1] = up ? nv.z(-2) : nv.z(2);
+        q[2] = up ? nv.z(-1) : nv.z(1);
         q[3] = nv.c;
-        q[4] = up ? nv.zl[G + 1] : nv.zl[G - 1];
-        q[5] = up ? nv.zl[G + 2] : nv.zl[G - 2];
+        q[4] = up ? nv.z(1) : nv.z(-1);
+        q[5] = up ? nv.z(2) : nv.z(-2);
     }
     const double hs = up ? a.h[D] : -a.h[D];
     const double ihs = up ? a.inv_h[D] : -a.inv_h[D];
@@ -582,6 +587,9 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #ifndef LSM_WAVES_PER_EU
 #define LSM_WAVES_PER_EU 1
 #endif
+#ifndef LSM_ZROT
+#define LSM_ZROT 1
+#endif
 // build switches of the A/B experiments recorded in DESIGN.md §3.1 (tools/variants.sh): occupancy hint, and a
 // timing-only build without the per-plane barrier (its results are wrong)
 #ifdef LSM_EXP_NOBARRIER
@@ -590,7 +598,8 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #define LSM_BARRIER() __syncthreads()
 #endif
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK, bool MASKED>
-__global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const StageArgs a) {
+__global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2 && AK >= 0 && !MASKED && !CURV && !NM) ? 5 : LSM_WAVES_PER_EU)
+    stage_kernel(const StageArgs a) {   // the plain dense WENO5 kernels sit two registers above the 5-waves-per-SIMD step: capped there
     constexpr bool PLAIN = AK >= 0;                 // coefficient kinds, term order and the single output fixed at compile time
     constexpr bool NOMASK = PLAIN && !MASKED;       // ... and no band mask (MASKED: a plain variant over a narrow band)
     constexpr int CK = PLAIN ? (int)LSM_COEFF_CONST : -1;   // kind of the NormalMotion / curvature coefficients
@@ -598,6 +607,8 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
     constexpr bool HAS_Y = NDIM == 3, MARCH = NDIM >= 2;
     constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
     constexpr int NSLOT = MARCH ? 2 * LEAD + 2 : 1;
+    // the march line as a register ring with the plane loop unrolled 2G+1-fold: the WENO5 kernels in 3-D (7 moves a plane)
+    constexpr bool ZROT = LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2;
     constexpr int W = TX + 2 * G;
     constexpr int H = HAS_Y ? TY + 2 * G : 1;
     constexpr int HW = H * W;
@@ -745,7 +756,11 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
             for (int d = 0; d < NDIM; ++d) neg_pre[d] = __builtin_amdgcn_ballot_w64(__double2hiint(pre_adv[d]) < 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
-        for (int m = m0; m < m1; ++m) {
+        // One plane of the march.  ROT > 0: the register line is a ring (see NodeView) and the loop below is unrolled
+        // ROT-fold with the rotation Rc a compile-time constant of each copy.
+        constexpr int ROT = ZROT ? 2 * G + 1 : 0, RM = ROT > 0 ? ROT : 1;
+        auto plane_iter = [&](auto Rc, int m) {
+            constexpr int R = decltype(Rc)::value;
             // issue the next plane's loads early; they land in LDS after this plane's arithmetic
             Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
             Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
@@ -778,22 +793,49 @@ __global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel(const S
                 const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
                 const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
                 const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
-                NodeView<NDIM, G, W> nv{T0, Tm, Tp, zl, zl[G]};
+                NodeView<NDIM, G, W, R, ROT> nv{T0, Tm, Tp, zl, zl[ROT > 0 ? (R + G) % RM : G]};
                 node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, PLAIN>(a, nv, op, r1, r2);
             }
             // next plane's table entries: scalar loads, issued behind the LDS reads (they share a counter with them)
             plane_tab<NDIM, ADV, NM, CURV, AK>(a, (m + 1 < m1 ? m + 1 : m) + a.goff[NDIM - 1], pt);
-            // shift the register line, write the next plane to its ring slot
+            // advance the register line (ring: overwrite the oldest entry; otherwise shift), write the next plane to its ring slot
+            if constexpr (ROT > 0) {
+                zl[R % RM] = nxt;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
-            zl[2 * G] = nxt;
+                for (int j = 0; j < 2 * G; ++j) zl[j] = zl[j + 1];
+                zl[2 * G] = nxt;
+            }
             const int wslot = (m - m0 + 1 + 2 * LEAD) % NSLOT;
-            tile[wslot * HW + lpos] = zl[G + LEAD];
+            tile[wslot * HW + lpos] = zl[ROT > 0 ? (R + 1 + G + LEAD) % RM : G + LEAD];
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
                 if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];
             node_store<ST, PLAIN>(a, io, on, r1, r2);
             po += sm;
+        };
+        if constexpr (ROT > 0) {
+            int m = m0;
+            while (m < m1) {
+                // ROT copies of the body; each leaves the loop when the chunk is done (scalar branch)
+                bool go = true;
+                auto step = [&](auto Rc) {
+                    if (go) {
+                        plane_iter(Rc, m);
+                        ++m;
+                        go = m < m1;
+                    }
+                };
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{});
+                step(std::integral_constant<int, 4>{});
+                if constexpr (ROT > 5) step(std::integral_constant<int, 5>{});
+                if constexpr (ROT > 6) step(std::integral_constant<int, 6>{});
+            }
+        } else {
+            for (int m = m0; m < m1; ++m) plane_iter(std::integral_constant<int, 0>{}, m);
         }
     }
 }

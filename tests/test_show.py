@@ -1,0 +1,100 @@
+"""The reference's text/plain `show` (test/test-show.jl) and the LevelSetEquation doctest
+(src/levelsetequation.jl:33-57: spacing h = (0.04082, 0.04082), min = -0.2492, max = 1.75) through the host mirror.
+
+CPU: grids, boundary conditions, host fields, integrators, and the equation tree over the TEST-ONLY oracle backend
+(extrema from the oracle).  GPU: the same equation tree with the extrema computed by lsm_extrema on the device."""
+import numpy as np
+import pytest
+
+import lsm_amd as lsm
+
+DOCTEST = """LevelSetEquation
+  ├─ equation: ϕₜ + 𝐮 ⋅ ∇ ϕ = 0
+  ├─ time:     0.0
+  ├─ integrator: RK2 (2nd order TVD Runge-Kutta, Heun's method)
+  │  └─ cfl: 0.5
+  ├─ state: MeshField on CartesianGrid in ℝ²
+  │  ├─ domain:  [-1.0, 1.0] × [-1.0, 1.0]
+  │  ├─ nodes:   50 × 50
+  │  ├─ spacing: h = (0.04082, 0.04082)
+  │  ├─ bc:     Neumann (all)
+  │  ├─ valtype: Float64
+  │  └─ values:  min = -0.2492,  max = 1.75
+  ╰─"""
+
+
+def _doctest_equation(**kw):
+    """src/levelsetequation.jl:33-40, verbatim set-up."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (50, 50))
+    phi = lsm.MeshField(lambda x: x[0] ** 2 + x[1] ** 2 - 0.5 ** 2, grid)
+    u = lsm.MeshField(lambda x: (1.0 + 0 * x[0], 0.0 * x[0]), grid)
+    return lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(u),), ic=phi, bc=lsm.NeumannBC(), **kw)
+
+
+def test_grid_and_bc_show():
+    s = lsm.show(lsm.CartesianGrid((0, 0), (1, 1), (10, 4)))          # test/test-show.jl:8-15
+    assert s.startswith("CartesianGrid in ℝ²")
+    assert "├─ domain:  [0.0, 1.0] × [0.0, 1.0]" in s and "├─ nodes:   10 × 4" in s
+    assert "└─ spacing: h = (0.1111, 0.3333)" in s
+    assert repr(lsm.PeriodicBC()) == "Periodic" and repr(lsm.NeumannBC()) == "Neumann"       # :25-31
+    assert repr(lsm.LinearExtrapolationBC()) == "Linear extrapolation"
+    assert repr(lsm.ExtrapolationBC(4)) == "Degree 4 extrapolation" and repr(lsm.SymmetryBC()) == "Symmetry"
+
+
+def test_meshfield_show():
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (5, 5))
+    s = lsm.show(lsm.MeshField(lambda x: x[0] ** 2 + x[1] ** 2 - 0.5 ** 2, grid))           # :36-46
+    assert s.startswith("MeshField on CartesianGrid in ℝ²")
+    assert "├─ domain:  [-1.0, 1.0] × [-1.0, 1.0]" in s and "├─ nodes:   5 × 5" in s
+    assert "├─ spacing: h = (0.5, 0.5)" in s and "bc:" not in s
+    assert "├─ valtype: Float64" in s and "└─ values:  min = -0.25,  max = 1.75" in s
+    s = lsm.show(lsm.MeshField(lambda x: (x[0], x[1]), grid))                              # :56-63
+    assert "└─ valtype: SVector{2, Float64}" in s and "values" not in s and "bc:" not in s
+
+
+def test_integrator_show():
+    assert lsm.show(lsm.ForwardEuler()) == "ForwardEuler (1st order explicit)\n  └─ cfl: 0.5"       # :76-82
+    assert lsm.show(lsm.RK2()) == "RK2 (2nd order TVD Runge-Kutta, Heun's method)\n  └─ cfl: 0.5"
+    assert lsm.show(lsm.RK3()) == "RK3 (3rd order TVD Runge-Kutta)\n  └─ cfl: 0.5"
+    assert lsm.show(lsm.ForwardEuler(cfl=0.3)) == "ForwardEuler (1st order explicit)\n  └─ cfl: 0.3"
+
+
+def test_julia_float_printing():
+    from lsm_amd.api import _jl_float, _sig4
+    assert [_jl_float(x) for x in (1.0, 0.5, 1e-5, 1e-4, 123456.0, 1234567.0, 1e20, -0.0)] == \
+        ["1.0", "0.5", "1.0e-5", "0.0001", "123456.0", "1.234567e6", "1.0e20", "-0.0"]
+    assert [_sig4(x) for x in (2 / 49, -0.2492, 1.75, 12345.678, 1 / 9)] == ["0.04082", "-0.2492", "1.75", "12350.0", "0.1111"]
+
+
+def test_equation_doctest_on_the_oracle_backend():
+    from _oracle_backend import OracleBackend
+    eq = _doctest_equation(backend_factory=lambda g, b, s: OracleBackend(g, b, s))
+    assert lsm.show(eq) == DOCTEST
+    assert repr(eq) == "LevelSetEquation(ϕₜ + 𝐮 ⋅ ∇ ϕ = 0, t=0.0)"                               # test/test-show.jl:102
+    assert "├─ bc:     Neumann (all)" in lsm.show(eq.current_state())                          # :48-53
+
+
+@pytest.mark.gpu
+def test_equation_doctest_on_the_device():
+    """The doctest's extrema and spacing with min/max reduced by lsm_extrema."""
+    eq = _doctest_equation()
+    assert lsm.show(eq) == DOCTEST
+    lo, hi = eq.current_state().extrema()
+    ref = eq.current_state().values()
+    assert lo == ref.min() and hi == ref.max()
+    eq3 = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(1.0), lsm.EikonalReinitializationTerm()), ic=lsm.MeshField(
+        lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (12, 12, 12))),
+        bc=(lsm.PeriodicBC(), (lsm.NeumannBC(), lsm.ExtrapolationBC(2)), lsm.SymmetryBC()), integrator=lsm.RK3())
+    s = lsm.show(eq3)
+    assert "├─ equation: ϕₜ + v|∇ϕ| + sign(ϕ) (|∇ϕ| - 1) = 0" in s and "├─ state: MeshField on CartesianGrid in ℝ³" in s
+    assert "│  ├─ bc:     x: Periodic, y: Neumann ↔ Degree 2 extrapolation, z: Symmetry" in s and s.endswith("╰─")
+
+
+@pytest.mark.gpu
+def test_narrowband_show_on_the_device():
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (20, 20))                                    # test/test-show.jl:66-74
+    phi = lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - 0.5, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(1.0),), ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.NeumannBC())
+    s = lsm.show(eq.current_state())
+    assert s.startswith("NarrowBandMeshField on CartesianGrid in ℝ²")
+    assert "├─ active:" in s and "(3-layer halo)" in s and "└─ values:" in s
