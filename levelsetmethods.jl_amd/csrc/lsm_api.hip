@@ -377,6 +377,8 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     }
     a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
     a.dxmin = h->dxmin;
+    a.uniform_h = 1;                      // 1/h² equal in every used dimension: the Godunov sums are scaled once
+    for (int d = 1; d < h->grid.ndim; ++d) a.uniform_h = a.uniform_h && h->inv_h2[d] == h->inv_h2[0];
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     a.f32 = is_f32(h);

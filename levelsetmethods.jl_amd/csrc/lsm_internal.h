@@ -43,6 +43,7 @@ struct StageArgs {
     double inv_h[3];
     double inv_h2[3];
     double dxmin;      // minimum(meshsize)
+    int uniform_h;     // inv_h2 equal in every used dimension (FAST build: the Godunov sums are scaled once, not per dimension)
     // fields
     const double* psi;
     const double* phin;

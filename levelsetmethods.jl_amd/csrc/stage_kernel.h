@@ -411,11 +411,9 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
         double g2 = 0.0;
         const unsigned long long vpos = __builtin_amdgcn_ballot_w64(v > 0);   // one sign per wave is the rule (constant speeds)
         if (LSM_UNIFORM_PATHS && vpos == __builtin_amdgcn_ballot_w64(true)) {
-#pragma unroll
-            for (int d = 0; d < NDIM; ++d) g2 += godunov_pos(A[d], B[d], a.inv_h2[d]);
+            g2 = godunov_sum<NDIM, true>(A, B, a.inv_h2, a.uniform_h != 0);
         } else if (LSM_UNIFORM_PATHS && vpos == 0) {
-#pragma unroll
-            for (int d = 0; d < NDIM; ++d) g2 += godunov_neg(A[d], B[d], a.inv_h2[d]);
+            g2 = godunov_sum<NDIM, false>(A, B, a.inv_h2, a.uniform_h != 0);
         } else {
             const double sg = v > 0 ? 1.0 : -1.0;
 #pragma unroll
@@ -506,11 +504,9 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
         // without the sign factor
         const unsigned long long poss = __builtin_amdgcn_ballot_w64(s > 0);
         if (LSM_UNIFORM_PATHS && poss == __builtin_amdgcn_ballot_w64(true)) {
-#pragma unroll
-            for (int d = 0; d < NDIM; ++d) n2 += godunov_pos(A[d], B[d], a.inv_h2[d]);
+            n2 = godunov_sum<NDIM, true>(A, B, a.inv_h2, a.uniform_h != 0);
         } else if (LSM_UNIFORM_PATHS && poss == 0) {
-#pragma unroll
-            for (int d = 0; d < NDIM; ++d) n2 += godunov_neg(A[d], B[d], a.inv_h2[d]);
+            n2 = godunov_sum<NDIM, false>(A, B, a.inv_h2, a.uniform_h != 0);
         } else {
             const double sg = s > 0 ? 1.0 : -1.0;
 #pragma unroll
@@ -873,6 +869,10 @@ void launch_one(const StageArgs& a, hipStream_t s) {
     b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
     if (NDIM >= 2 && a.me <= a.mb) return;
     int mc = a.mc > 0 ? a.mc : T::MC;
+    if (a.mc <= 0 && NDIM == 3) {   // A/B switch: planes per march chunk
+        static const int mc_env = getenv("LSM_STAGE_MC") ? atoi(getenv("LSM_STAGE_MC")) : 0;
+        if (mc_env > 0) mc = mc_env;
+    }
     // small grids: a workgroup marching 64 planes leaves most of the 256 CUs idle (48^3 = 12 workgroups, a serial walk
     // of 48 planes each).  Shorter chunks — down to 8 planes — until there are ~8 workgroups per CU; each chunk pays its
     // 2G+1 planes of prologue, which is why large grids keep the long march.

@@ -223,6 +223,26 @@ LSM_DEV double godunov_neg(double A, double B, double inv_h2) {   // min(A,0)² 
     const double b = vmax0(B);
     return __builtin_fma(a, a, b * b) * inv_h2;
 }
+// Σ_d over NDIM dimensions with one sign per wave; equal spacings (the rule): the undivided squares are summed in one
+// FMA chain and scaled once (2 instructions fewer in 3-D than scaling per dimension)
+template <int NDIM, bool POS>
+LSM_DEV double godunov_sum(const double* A, const double* B, const double* inv_h2, bool uniform_h) {
+    if (uniform_h) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            const double a = POS ? vmax0(A[d]) : vmin0(A[d]);
+            const double b = POS ? vmin0(B[d]) : vmax0(B[d]);
+            s = d == 0 ? a * a : __builtin_fma(a, a, s);
+            s = __builtin_fma(b, b, s);
+        }
+        return s * inv_h2[0];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < NDIM; ++d) s += POS ? godunov_pos(A[d], B[d], inv_h2[d]) : godunov_neg(A[d], B[d], inv_h2[d]);
+    return s;
+}
 #endif
 
 }  // namespace LSM_NS
