@@ -7,7 +7,8 @@ WENO5 advection by the vortex-deformation field + Eikonal reinitialisation, fp64
 N = 1: 512³ on one MI355X (the configuration the metric is quoted on).
 N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is 1024 × 1024 × 128·N,
 slab-decomposed along the last dimension (every rank owns 1024 × 1024 × 128 = 512³ cells: weak
-scaling), ghost planes exchanged over RCCL/xGMI after every stage, Δt all-reduced.
+scaling), ghost planes exchanged over RCCL/xGMI after every stage and Δt all-reduced INSIDE libhiplsm
+(lsm_comm_attach_rccl; torch.distributed only carries the RCCL unique id to the ranks).
 
 A "step" is one pass of the reference's step loop body (src/timestepping.jl:104-116):
 compute_cfl + the 3 fused RK3 stage kernels + ghost fills (hooks = identity).  Inputs are resident
@@ -118,23 +119,24 @@ def main():
     # fall back to the plain sequence and say so.
     overlap_note = "n/a"
     if world > 1:
-        overlap_note = "off"
-        if eq.overlap:
-            keep = eq.state.buf.clone()
-            eq.overlap = True
-            one_step(eq, 0.0)
-            a_res = eq.state.buf.clone()
-            eq.state.buf.copy_(keep)
-            eq.state.ghosts_dirty = True
-            eq.overlap = False
-            one_step(eq, 0.0)
-            same = torch.tensor([1.0 if torch.equal(a_res, eq.state.buf) else 0.0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            eq.state.buf.copy_(keep)
-            eq.state.ghosts_dirty = True
-            eq.overlap = bool(same.item() == 1.0)
-            overlap_note = "on (self-check passed)" if eq.overlap else "off (self-check mismatch)"
-            del keep, a_res
+        # the slab step runs inside the library (lsm_advance_rk3 on a handle with an RCCL communicator attached:
+        # boundary planes first, exchange overlapped behind the interior update)
+        assert eq.lib_comm, "the dense slab path must run on the library's RCCL communicator"
+        keep = eq.state.buf.clone()
+        one_step(eq, 0.0)
+        a_res = eq.state.buf.clone()
+        eq.state.buf.copy_(keep)
+        eq.state.ghosts_dirty = True
+        eq.backend.comm_set_overlap(False)
+        one_step(eq, 0.0)
+        same = torch.tensor([1.0 if torch.equal(a_res, eq.state.buf) else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        eq.state.buf.copy_(keep)
+        eq.state.ghosts_dirty = True
+        ok = bool(same.item() == 1.0)
+        eq.backend.comm_set_overlap(ok)
+        overlap_note = "on (self-check passed)" if ok else "off (self-check mismatch)"
+        del keep, a_res
 
     tc = 0.0
     for _ in range(args.warmup):

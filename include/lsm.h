@@ -187,13 +187,52 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
 int lsm_cfl_cache(LsmHandle* h, int enable);
 
 /* ---- _advance! per integrator.  phi's ghosts are (re)filled on entry and valid on return.
- *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63). */
+ *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63).
+ *      On a slab handle with a communicator attached these run the slab's step (see "multi-GPU" below). */
 int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1,
                    double tc, double dt, LsmStageHook hook, void* user);
 int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2,
                     double tc, double dt, LsmStageHook hook, void* user);
 int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2,
                     double tc, double dt, LsmStageHook hook, void* user);
+
+/* ---- multi-GPU: the grid is cut into slabs of the LAST dimension, one handle per slab (lsm_create with an
+ *      LsmSlab and LSM_BC_NONE on the faces towards neighbouring ranks — on BOTH faces of every rank when that dimension
+ *      is periodic: the ring closes across the wrap, whose period is n-1, src/boundaryconditions.jl:107-119).  After every
+ *      stage the LSM_GHOST full padded planes next to each interface are exchanged with rank±1 (they carry their own ghosts of
+ *      the leading dimensions, so the corner composition of _getindexbc, src/meshfield.jl:248-260, is preserved), and Δt of
+ *      compute_cfl is min-reduced over the ranks with NaN winning (src/levelsetterms.jl:22-28: `min` propagates NaN).
+ *      Two transports:
+ *        RCCL   one process per GPU.  Rank 0 calls lsm_comm_unique_id and hands the LSM_COMM_ID_BYTES to every rank out of
+ *               band (MPI, a file, torch.distributed's store ...); then every rank calls lsm_comm_attach_rccl (collective).
+ *               librccl is opened at run time; the planes travel as grouped ncclSend/ncclRecv over xGMI on a stream of the
+ *               communicator's own, so that a stage's interior update overlaps the exchange of its boundary planes.
+ *        LOCAL  all ranks are handles of ONE process (any devices): lsm_comm_attach_local(handles, world), one call.
+ *               Planes move by peer copies.  lsm_halo_wait / lsm_allreduce_dt / lsm_advance_* block the calling thread until
+ *               every rank of the group has made the matching call: drive the ranks from one host thread each, or from one
+ *               thread stage by stage (lsm_stage_planes ..., lsm_halo_start on every handle, then lsm_halo_wait on every
+ *               handle; reduce Δt yourself).
+ *      With a communicator attached to a slab handle, lsm_advance_fe/rk2/rk3 run the slab's stages with the exchange
+ *      overlapped (boundary planes first, interior while they travel) and expect phi's ghosts — boundary conditions and
+ *      neighbour planes — valid on entry (they are on return; after writing the field from outside call
+ *      lsm_fill_ghosts(h, phi, 7, NULL) + lsm_halo_exchange(h, phi)).  lsm_compute_cfl stays local: follow it with
+ *      lsm_allreduce_dt.  lsm_destroy detaches. */
+#define LSM_COMM_ID_BYTES 128
+enum { LSM_COMM_NONE = 0, LSM_COMM_RCCL = 1, LSM_COMM_LOCAL = 2 };
+int lsm_comm_unique_id(void* id_out /* LSM_COMM_ID_BYTES */);
+int lsm_comm_attach_rccl(LsmHandle* h, const void* unique_id, int rank, int world);
+int lsm_comm_attach_local(LsmHandle* const* handles, int world);     /* handles[r] = rank r */
+int lsm_comm_detach(LsmHandle* h);
+int lsm_comm_info(const LsmHandle* h, int* rank, int* world, int* transport);   /* any pointer may be NULL */
+/* boundary-first stages with the exchange overlapped behind the interior update (default; LSM_SLAB_OVERLAP=0 in the
+ * environment at attach time, or enable = 0, selects the plain stage -> ghost fill -> exchange order: same results) */
+int lsm_comm_set_overlap(LsmHandle* h, int enable);
+/* exchange of `field`'s ghost planes: start after the planes next to the interfaces are final on the handle's stream, wait
+ * before anything reads the ghost planes (the handle's stream waits; no host synchronisation with RCCL) */
+int lsm_halo_start(LsmHandle* h, void* field);
+int lsm_halo_wait(LsmHandle* h);
+int lsm_halo_exchange(LsmHandle* h, void* field);                    /* start + wait */
+int lsm_allreduce_dt(LsmHandle* h, double* dt /* in: local, out: global */);   /* synchronous */
 
 /* ---- EikonalReinitializationTerm(ϕ₀) constructor map: S0 = v/sqrt(v^2+Δx^2) (src/levelsetterms.jl:217-221) */
 int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream);

@@ -13,7 +13,7 @@ from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm
                   ROCNarrowBandMeshField, SeparableCoefficient,
                   SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_, reinitialize_,
                   perimeter, volume, InterpolatedField, NewtonSDF, hausdorff_distance, SideField, curvature, curvature_field, gradient, gradient_field, normal, normal_field,
-                  vortex_deformation, show)
+                  vortex_deformation, show, LocalGroup)
 
 __all__ = [
     "AdvectionTerm", "BoundaryCondition", "CartesianGrid", "CurvatureTerm", "EikonalReinitializationTerm",
@@ -22,5 +22,5 @@ __all__ = [
     "RigidRotation", "ROCMeshField",
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
     "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "reinitialize_", "LsmError", "build",
-    "InterpolatedField", "NewtonSDF", "hausdorff_distance", "SideField", "curvature", "curvature_field", "gradient", "gradient_field", "normal", "normal_field", "show",
+    "InterpolatedField", "NewtonSDF", "hausdorff_distance", "SideField", "curvature", "curvature_field", "gradient", "gradient_field", "normal", "normal_field", "show", "LocalGroup",
 ]

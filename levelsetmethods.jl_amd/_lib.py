@@ -25,6 +25,8 @@ MODE_FAST, MODE_STRICT = 0, 1
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 GEOM_CURVATURE, GEOM_GRADIENT, GEOM_NORMAL = 0, 1, 2
+COMM_ID_BYTES = 128
+COMM_NONE, COMM_RCCL, COMM_LOCAL = 0, 1, 2
 
 
 class LsmGrid(C.Structure):
@@ -85,6 +87,16 @@ _SIGS = [
                                   C.c_double, StageHook, C.c_void_p]),
     ("lsm_advance_rk3", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                   C.c_double, StageHook, C.c_void_p]),
+    ("lsm_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("lsm_comm_attach_rccl", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    ("lsm_comm_attach_local", C.c_int, [C.POINTER(_H), C.c_int]),
+    ("lsm_comm_detach", C.c_int, [_H]),
+    ("lsm_comm_info", C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("lsm_comm_set_overlap", C.c_int, [_H, C.c_int]),
+    ("lsm_halo_start", C.c_int, [_H, C.c_void_p]),
+    ("lsm_halo_wait", C.c_int, [_H]),
+    ("lsm_halo_exchange", C.c_int, [_H, C.c_void_p]),
+    ("lsm_allreduce_dt", C.c_int, [_H, C.POINTER(C.c_double)]),
     ("lsm_eikonal_sign", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("lsm_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,

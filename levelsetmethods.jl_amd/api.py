@@ -660,7 +660,7 @@ class _Coeff:
                 t = backend.table(np.concatenate(spec.tables[k]))
                 self._keep.append(t)
                 self.c.sep[k] = t.data_ptr()
-        elif isinstance(spec, (MeshField, ROCMeshField)) or callable(spec):
+        elif isinstance(spec, (MeshField, ROCMeshField)) or callable(spec) or self._device_components(spec):
             self.c.kind = L.COEFF_FIELD
             self.fields = [getattr(backend, "alloc_side", backend.alloc)() for _ in range(ncomp)]
             for k, t in enumerate(self.fields):
@@ -668,7 +668,7 @@ class _Coeff:
             if callable(spec):
                 self.callable = spec
             else:
-                self.set_values(spec.vals if isinstance(spec, MeshField) else spec)
+                self.set_values(spec)
         else:
             vals = spec if isinstance(spec, (tuple, list, np.ndarray)) else (spec,)
             if len(vals) != ncomp:
@@ -682,8 +682,27 @@ class _Coeff:
             return a
         return a[..., self.slab[0]:self.slab[0] + self.slab[1]]
 
+    @staticmethod
+    def _device_components(spec):
+        return isinstance(spec, (tuple, list)) and len(spec) > 0 and all(isinstance(x, ROCMeshField) for x in spec)
+
     def set_values(self, vals):
-        """Upload new values (global array of shape grid.n or (ncomp, *grid.n))."""
+        """New values of a FIELD coefficient: a host array of shape grid.n or (ncomp, *grid.n) / a host MeshField
+        (uploaded), or device fields — a ROCMeshField (scalar speed / b) or one per component (velocity) — copied
+        device to device into the coefficient's float64 side arrays (a float32 field widens exactly)."""
+        if isinstance(vals, ROCMeshField) or self._device_components(vals):
+            comps = [vals] if isinstance(vals, ROCMeshField) else list(vals)
+            if len(comps) != self.ncomp:
+                raise ValueError(f"expected {self.ncomp} coefficient component(s), got {len(comps)}")
+            for k, src in enumerate(comps):
+                if src.buf.numel() == self.fields[k].numel() and src.buf.device == self.fields[k].device:
+                    self.fields[k].copy_(src.buf)                      # same padded layout: HBM to HBM
+                else:
+                    v = src.values().astype(np.float64)                # another handle's layout (e.g. a whole-grid field on a slab)
+                    getattr(self.backend, "upload_side", self.backend.upload)(self.fields[k], v if v.shape == tuple(self.backend.local_shape()) else self._local(v))
+            return
+        if isinstance(vals, MeshField):
+            vals = vals.vals
         vals = np.asarray(vals, dtype=np.float64)
         if vals.ndim == self.grid.ndim:
             vals = vals[None]
@@ -826,6 +845,38 @@ def _eps(x):
     return float(np.spacing(abs(float(x))))
 
 
+# ----------------------------------------------------------------------------- slab groups inside one process
+
+class LocalGroup:
+    """Every rank of a slab decomposition as a handle of THIS process (include/lsm.h: LSM_COMM_LOCAL; any devices):
+    `g = LocalGroup(world)`, then `LevelSetEquation(..., comm=g.rank(r), device=...)` on one host thread per rank.
+    Ghost planes move by peer copies inside the library; no torch.distributed, no RCCL."""
+
+    def __init__(self, world):
+        import threading
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+
+    def rank(self, r):
+        if not 0 <= r < self.world:
+            raise ValueError("rank out of range")
+        return _LocalRank(self, int(r))
+
+    def exchange(self, r, v):
+        """all_gather_object among the ranks' threads."""
+        self._slots[r] = v
+        self._barrier.wait()
+        out = list(self._slots)
+        self._barrier.wait()
+        return out
+
+
+class _LocalRank:
+    def __init__(self, group, r):
+        self.group, self.r = group, r
+
+
 # ----------------------------------------------------------------------------- levelsetequation.jl
 
 class LevelSetEquation:
@@ -863,8 +914,11 @@ class LevelSetEquation:
         self.slab = None
         slab_faces = (False, False)
         if comm is not None:
-            import torch.distributed as dist
-            self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
+            if isinstance(comm, _LocalRank):
+                self.rank, self.world = comm.r, comm.group.world
+            else:
+                import torch.distributed as dist
+                self.rank, self.world = dist.get_rank(comm), dist.get_world_size(comm)
             nl = grid.n[N - 1]
             base, rem = divmod(nl, self.world)
             counts = [base + (1 if r < rem else 0) for r in range(self.world)]
@@ -872,6 +926,12 @@ class LevelSetEquation:
             self.slab = (lo, counts[self.rank])
             self.counts = counts
             self.own = (0, counts[self.rank])      # local plane range of the planes this rank owns
+            if self.world > 1 and min(counts) < L.GHOST + 1:
+                # every rank raises the same error (a rank failing alone would leave the others in their next collective):
+                # the periodic wrap sends planes shifted by one node, and a SymmetryBC end face reads LSM_GHOST planes inwards
+                raise ValueError(f"a slab needs at least {L.GHOST + 1} planes: {nl} planes over {self.world} ranks leave {min(counts)}")
+            if isinstance(ic, NarrowBandMeshField) and self.world > 1 and isinstance(comm, _LocalRank):
+                raise ValueError("a slab-decomposed NarrowBandMeshField needs a torch.distributed group (its sparse plane exchange runs there)")
             if isinstance(ic, NarrowBandMeshField) and self.world > 1:
                 # a band needs its neighbours' mask AND values up to 7 planes deep (nearest band node within 6, its
                 # slope neighbour) plus the stencil reach: every rank keeps BAND_OVERLAP planes of its neighbours as
@@ -906,6 +966,11 @@ class LevelSetEquation:
         elif self.dtype != np.float64:
             raise ValueError("float32 fields need the HIP backend")
         self.backend = factory(grid._c(), _bc_c(bcs, N, slab_faces), self.slab)
+        # dense slabs on the HIP backend: the plane exchange and the Δt all-reduce run inside the library
+        # (lsm_comm_attach_rccl / _local); torch.distributed only carries the RCCL unique id to the ranks
+        self.lib_comm = False
+        if comm is not None and self.world > 1 and not isinstance(ic, NarrowBandMeshField) and hasattr(self.backend, "comm_attach_rccl"):
+            self._attach_library_comm()
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
         self.band = isinstance(ic, NarrowBandMeshField)
         if self.band:
@@ -986,7 +1051,32 @@ class LevelSetEquation:
             raise ValueError(f"invalid time-step based on CFL condition: Δt = {dt} (check for NaN/Inf in velocity or speed)")
         return dt
 
+    def _attach_library_comm(self):
+        b = self.backend
+        if isinstance(self.comm, _LocalRank):
+            g = self.comm.group
+            backs = g.exchange(self.rank, b)
+            if self.rank == 0:
+                type(b).comm_attach_local(backs)
+            g.exchange(self.rank, None)            # nobody runs ahead of the attachment
+        else:
+            import torch.distributed as dist
+            box = [b.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.comm, 0), group=self.comm)
+            b.comm_attach_rccl(box[0], self.rank, self.world)
+        self.lib_comm = True
+
+    def _all_gather_object(self, v):
+        if isinstance(self.comm, _LocalRank):
+            return self.comm.group.exchange(self.rank, v)
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, v, group=self.comm)
+        return parts
+
     def _allreduce_min(self, dt):
+        if self.lib_comm:
+            return self.backend.allreduce_dt(dt)   # lsm_allreduce_dt: MIN over the ranks, NaN wins
         import torch
         import torch.distributed as dist
         dev = self.state.buf.device
@@ -1010,7 +1100,11 @@ class LevelSetEquation:
         name = self.integrator.name
         if self.band:
             return self._advance_band(tc, dt, b1, b2)
-        if self.comm is None:
+        if self.comm is None or self.lib_comm:
+            if self.lib_comm and self.state.ghosts_dirty:   # a slab's lsm_advance_* expects valid ghosts on entry
+                b.fill_ghosts(phi, 7)
+                b.halo_exchange(phi)
+                self.state.ghosts_dirty = False
             hook = None
             if self._needs_hook():
                 def cb(_user, stage, field_ptr, t_stage):
@@ -1242,12 +1336,8 @@ class LevelSetEquation:
         if self.comm is None or self.world == 1:
             return v
         v = v[..., self.own[0]:self.own[0] + self.own[1]]       # a band slab also holds copies of its neighbours' planes
-        import torch
-        import torch.distributed as dist
         N = self.mesh_.ndim
-        parts = [None] * self.world
-        dist.all_gather_object(parts, v, group=self.comm)
-        return np.asfortranarray(np.concatenate(parts, axis=N - 1))
+        return np.asfortranarray(np.concatenate(self._all_gather_object(v), axis=N - 1))
 
 
 def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
@@ -1275,6 +1365,8 @@ def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
 def _sum_over_ranks(ls, x):
     if ls.comm is None or ls.world == 1:
         return x
+    if isinstance(ls.comm, _LocalRank):
+        return float(sum(ls._all_gather_object(float(x))))   # rank order: the same sum on every rank
     import torch
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device=ls.state.buf.device)

@@ -1,6 +1,7 @@
 """HipBackend — device memory (torch tensors as plain HBM buffers), streams and the calls into
-libhiplsm.so.  torch is plumbing here: allocation, the current HIP stream, and (in slab mode)
-torch.distributed point-to-point over RCCL/xGMI for the ghost-plane exchange.
+libhiplsm.so.  torch is plumbing here: allocation, the current HIP stream, and — in slab mode — the bootstrap
+of the library's own RCCL communicator (the ghost-plane exchange and the Δt all-reduce of a dense slab run
+inside the library; only the slab-decomposed narrow band still moves its planes with torch.distributed).
 
 The interface (layout / alloc / upload / download / fill_ghosts / stage / compute_cfl_local /
 advance_single / eikonal_sign / extrema / table) is the seam the host logic in api.py talks to.
@@ -140,6 +141,47 @@ class HipBackend:
         else:
             code = self.lib.lsm_advance_rk3(self.h, terms_c, nterms, self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
         L.check(self.h, code, f"lsm_advance_{which}")
+
+    # ---- multi-GPU: slab communicator inside the library (include/lsm.h, "multi-GPU")
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        L.check(None, self.lib.lsm_comm_unique_id(buf), "lsm_comm_unique_id")
+        return buf.raw
+
+    def comm_attach_rccl(self, unique_id, rank, world):
+        """Collective over the ranks: ncclCommInitRank on this handle's device."""
+        L.check(self.h, self.lib.lsm_comm_attach_rccl(self.h, C.c_char_p(unique_id), rank, world), "lsm_comm_attach_rccl")
+
+    @staticmethod
+    def comm_attach_local(backends):
+        """All ranks in this process: backends[r] = rank r (LSM_COMM_LOCAL)."""
+        arr = (C.c_void_p * len(backends))(*[b.h for b in backends])
+        code = backends[0].lib.lsm_comm_attach_local(arr, len(backends))
+        if code != L.OK:
+            msgs = [b.lib.lsm_last_error(b.h) for b in backends]
+            raise L.LsmError(f"lsm_comm_attach_local failed ({code}): " + "; ".join(m.decode() for m in msgs if m))
+
+    def comm_info(self):
+        r, w, t = C.c_int(), C.c_int(), C.c_int()
+        L.check(self.h, self.lib.lsm_comm_info(self.h, C.byref(r), C.byref(w), C.byref(t)), "lsm_comm_info")
+        return r.value, w.value, t.value
+
+    def comm_set_overlap(self, enable):
+        L.check(self.h, self.lib.lsm_comm_set_overlap(self.h, 1 if enable else 0), "lsm_comm_set_overlap")
+
+    def halo_start(self, t):
+        L.check(self.h, self.lib.lsm_halo_start(self.h, self.ptr(t)), "lsm_halo_start")
+
+    def halo_wait(self):
+        L.check(self.h, self.lib.lsm_halo_wait(self.h), "lsm_halo_wait")
+
+    def halo_exchange(self, t):
+        L.check(self.h, self.lib.lsm_halo_exchange(self.h, self.ptr(t)), "lsm_halo_exchange")
+
+    def allreduce_dt(self, dt):
+        v = C.c_double(dt)
+        L.check(self.h, self.lib.lsm_allreduce_dt(self.h, C.byref(v)), "lsm_allreduce_dt")
+        return v.value
 
     def eikonal_sign(self, phi0, s0):
         L.check(self.h, self.lib.lsm_eikonal_sign(self.h, self.ptr(phi0), self.ptr(s0), None), "lsm_eikonal_sign")

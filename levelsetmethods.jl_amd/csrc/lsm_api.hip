@@ -30,62 +30,7 @@ bool combo_available(const Combo& c) {
 
 using namespace lsm;
 
-struct LsmHandle {
-    LsmGrid grid;
-    LsmBc bc[LSM_MAX_DIM][2];
-    LsmSlab slab;
-    int dtype, mode, device;
-    LsmLayout lay;
-    int nloc[3], goff[3], gn[3];
-    double h[3], h2[3], inv_h[3], inv_h2[3], dxmin;
-    double w[3][2][LSM_GHOST][8];
-    hipStream_t stream;
-    bool own_stream;
-    double* d_w;         // device copy of w
-    signed char* d_ring; // narrow band: distance-sorted offset ring
-    int nring;
-    int nring_lds;       // ring entries before the first with a component beyond the LDS apron (3)
-    int* d_miss;
-    unsigned long long* d_count;
-    unsigned char* d_work;             // per-tile work flags (narrow band)
-    int64_t work_cap;
-    const unsigned char* band_mask;    // set for the duration of a *_band call
-    const unsigned char* band_tiles;
-    int band_mc;
-    const int* band_list;              // compact active-tile list for a stage (NULL = flags only)
-    unsigned band_nlist;
-    // compact tile lists of the band last updated (built on the device by lsm_band_update, lengths read back by
-    // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
-    int* d_act_list;
-    int* d_work_list;
-    unsigned* d_lcounts;
-    const void* lists_tiles;           // the tile-flag buffer the lists describe
-    int lists_mc;
-    bool lists_host_valid;
-    unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
-    bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
-    bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
-    double* d_partial;   // 2 * MAXB doubles
-    int* d_flag;
-    double* d_result;    // 2 doubles
-    double* h_result;    // pinned, 2 doubles
-    std::string err;
-    bool cfl_cache_on;
-    std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients
-    struct CflCand { LsmTerm key; long long* d_cand; unsigned count; };
-    std::vector<CflCand> cfl_cand;                       // SEPARABLE × g(t): the arg-max candidates are time-independent
-    unsigned* d_cand_count;
-    // Δt of a ϕ-independent term (constant / catalogued analytic coefficient) is reduced on a stream of its own, with
-    // its own scratch: the host gets it without waiting for the stages queued on the main stream, and can queue the
-    // next step behind them
-    hipStream_t cfl_stream;
-    double *c_partial, *c_result, *ch_result;
-    int* c_flag;
-    std::vector<const void*> cfl_seen;   // coefficient tables known to have landed
-    bool prof;
-    std::vector<hipEvent_t> ev_start, ev_stop;
-    size_t ev_used;
-};
+#include "lsm_handle.h"
 
 struct LsmHandle;
 static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work);
@@ -96,6 +41,7 @@ static int fail(LsmHandle* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
 }
+int lsm_fail(LsmHandle* h, int code, const std::string& msg) { return fail(h, code, msg); }
 #define LSM_HIP(h, call)                                                                              \
     do {                                                                                              \
         hipError_t e_ = (call);                                                                       \
@@ -164,6 +110,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     memcpy(h->bc, bc, sizeof(h->bc));
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
+    h->comm = nullptr;
     h->cfl_cache_on = true;
     h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
@@ -244,6 +191,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
 
 void lsm_destroy(LsmHandle* h) {
     if (!h) return;
+    (void)lsm_comm_detach(h);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
@@ -651,9 +599,14 @@ static int check_single_device(LsmHandle* h) {
     const int N = h->grid.ndim;
     if (h->bc[N - 1][0].kind == LSM_BC_NONE || h->bc[N - 1][1].kind == LSM_BC_NONE)
         return fail(h, LSM_ERR_INVALID,
-                    "this entry point works on a whole grid: the handle is a slab of a multi-GPU grid (drive a slab with lsm_stage + "
-                    "lsm_fill_ghosts + halo exchange)");
+                    "this entry point works on a whole grid: the handle is a slab of a multi-GPU grid (attach a communicator — "
+                    "lsm_comm_attach_rccl / lsm_comm_attach_local — or drive the slab with lsm_stage + lsm_fill_ghosts + lsm_halo_*)");
     return LSM_OK;
+}
+// a slab handle with a communicator attached: the stages exchange their ghost planes
+static bool is_slab(const LsmHandle* h) {
+    const int N = h->grid.ndim;
+    return h->comm != nullptr && (h->bc[N - 1][0].kind == LSM_BC_NONE || h->bc[N - 1][1].kind == LSM_BC_NONE);
 }
 static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, const void* field, double t) {
     if (!hook) return LSM_OK;
@@ -663,10 +616,63 @@ static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, cons
 }
 #define LSM_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
 
+// One stage of a slab followed by its ghost resolution.  The LSM_GHOST+1 planes next to each slab
+// interface are updated and ghost-filled first, their exchange is started, and the interior is updated while the planes
+// travel; then the physical-BC ghost planes of the end ranks.  Every node is computed by the same kernel from the same
+// inputs as in the plain stage -> ghost fill -> exchange order (lsm_comm_set_overlap(h, 0) selects it), so the
+// results are identical.  The exchanged planes carry their own ghosts of the leading dimensions: the corner
+// composition of _getindexbc (src/meshfield.jl:248-260) is preserved.
+static int stage_slab(LsmHandle* h, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out, void* out2,
+                      int base_mode, double cdt, double cdt2, double t) {
+    const int N = h->grid.ndim;
+    const int nloc = h->nloc[N - 1];
+    const int B = LSM_GHOST + 1;                 // +1: the periodic wrap sends planes shifted by one node
+    if (!lsm_comm_overlap(h) || N < 2 || nloc < 2 * B + 1) {
+        LSM_TRY(lsm_stage(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, nullptr));
+        LSM_TRY(lsm_fill_ghosts(h, out, 7, nullptr));
+        return lsm_halo_exchange(h, out);
+    }
+    const int64_t edge[2][2] = {{0, B}, {nloc - B, nloc}};
+    for (auto& e : edge) {
+        LSM_TRY(lsm_stage_planes(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, e[0], e[1], nullptr));
+        LSM_TRY(lsm_fill_ghosts_planes(h, out, e[0], e[1], 0, nullptr));
+    }
+    LSM_TRY(lsm_halo_start(h, out));
+    LSM_TRY(lsm_stage_planes(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, B, nloc - B, nullptr));
+    LSM_TRY(lsm_fill_ghosts_planes(h, out, B, nloc - B, 0, nullptr));
+    LSM_TRY(lsm_halo_wait(h));
+    return lsm_fill_ghosts(h, out, 1 << (N - 1), nullptr);   // physical ghost planes of the last dimension (interfaces are skipped)
+}
+
+// _advance! of a slab (communicator attached).  phi's ghosts — boundary conditions AND the neighbours' planes — must be
+// valid on entry: they are on return of the previous step; after the field was written from outside call
+// lsm_fill_ghosts(7) + lsm_halo_exchange first.
+static int advance_slab(LsmHandle* h, int integ, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc,
+                        double dt, LsmStageHook hook, void* user) {
+    LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
+    if (integ == 0) {           // ForwardEuler — src/timestepping.jl:128-137
+        LSM_TRY(stage_slab(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
+        LSM_HIP(h, hipMemcpyAsync(phi, buf1, esize(h) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));   // copy!(ϕ, dst): ghosts travel with the padded buffer
+        return LSM_OK;
+    }
+    if (integ == 1) {           // RK2 — src/timestepping.jl:143-164
+        LSM_TRY(stage_slab(h, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc));
+        LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+        return stage_slab(h, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt);
+    }
+    // RK3 — src/timestepping.jl:170-202
+    LSM_TRY(stage_slab(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
+    LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+    LSM_TRY(stage_slab(h, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt));
+    LSM_TRY(run_hook(h, hook, user, 2, buf2, tc + 0.5 * dt));
+    return stage_slab(h, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt);
+}
+
 // _advance!(::ForwardEuler) — src/timestepping.jl:128-137
 int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, double tc, double dt,
                    LsmStageHook hook, void* user) {
     if (!h || !phi || !buf1) return LSM_ERR_INVALID;
+    if (is_slab(h)) return advance_slab(h, 0, terms, nterms, phi, buf1, nullptr, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
@@ -680,6 +686,7 @@ int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, vo
 int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc, double dt,
                     LsmStageHook hook, void* user) {
     if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
+    if (is_slab(h)) return advance_slab(h, 1, terms, nterms, phi, buf1, buf2, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
@@ -694,6 +701,7 @@ int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, v
 int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc, double dt,
                     LsmStageHook hook, void* user) {
     if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
+    if (is_slab(h)) return advance_slab(h, 2, terms, nterms, phi, buf1, buf2, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
     LSM_TRY(lsm_fill_ghosts(h, phi, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));

@@ -1,0 +1,72 @@
+// lsm_handle.h — the handle behind the C ABI (include/lsm.h), shared by lsm_api.hip and lsm_comm.hip.
+#pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lsm_internal.h"
+
+struct LsmComm;   // lsm_comm.hip: slab communicator (RCCL or in-process), NULL on a single-device handle
+
+struct LsmHandle {
+    LsmGrid grid;
+    LsmBc bc[LSM_MAX_DIM][2];
+    LsmSlab slab;
+    int dtype, mode, device;
+    LsmLayout lay;
+    int nloc[3], goff[3], gn[3];
+    double h[3], h2[3], inv_h[3], inv_h2[3], dxmin;
+    double w[3][2][LSM_GHOST][8];
+    hipStream_t stream;
+    bool own_stream;
+    double* d_w;         // device copy of w
+    signed char* d_ring; // narrow band: distance-sorted offset ring
+    int nring;
+    int nring_lds;       // ring entries before the first with a component beyond the LDS apron (3)
+    int* d_miss;
+    unsigned long long* d_count;
+    unsigned char* d_work;             // per-tile work flags (narrow band)
+    int64_t work_cap;
+    const unsigned char* band_mask;    // set for the duration of a *_band call
+    const unsigned char* band_tiles;
+    int band_mc;
+    const int* band_list;              // compact active-tile list for a stage (NULL = flags only)
+    unsigned band_nlist;
+    // compact tile lists of the band last updated (built on the device by lsm_band_update, lengths read back by
+    // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
+    int* d_act_list;
+    int* d_work_list;
+    unsigned* d_lcounts;
+    const void* lists_tiles;           // the tile-flag buffer the lists describe
+    int lists_mc;
+    bool lists_host_valid;
+    unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
+    bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
+    bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
+    double* d_partial;   // 2 * MAXB doubles
+    int* d_flag;
+    double* d_result;    // 2 doubles
+    double* h_result;    // pinned, 2 doubles
+    std::string err;
+    bool cfl_cache_on;
+    std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients
+    struct CflCand { LsmTerm key; long long* d_cand; unsigned count; };
+    std::vector<CflCand> cfl_cand;                       // SEPARABLE × g(t): the arg-max candidates are time-independent
+    unsigned* d_cand_count;
+    // Δt of a ϕ-independent term (constant / catalogued analytic coefficient) is reduced on a stream of its own, with
+    // its own scratch: the host gets it without waiting for the stages queued on the main stream, and can queue the
+    // next step behind them
+    hipStream_t cfl_stream;
+    double *c_partial, *c_result, *ch_result;
+    int* c_flag;
+    std::vector<const void*> cfl_seen;   // coefficient tables known to have landed
+    bool prof;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used;
+    LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
+};
+
+// shared helpers (lsm_api.hip)
+int lsm_fail(LsmHandle* h, int code, const std::string& msg);
+// lsm_comm.hip: the attached communicator wants boundary-first stages (lsm_comm_set_overlap; LSM_SLAB_OVERLAP=0 at attach time)
+bool lsm_comm_overlap(const LsmHandle* h);

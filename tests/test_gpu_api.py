@@ -130,6 +130,35 @@ def test_callable_velocity_and_update_func_hooks(lsm, orc):
     assert len(calls) > 0 and len(calls) % 4 == 0   # once before the CFL + once per RK3 stage
 
 
+def test_device_fields_as_coefficients(lsm):
+    """A ROCMeshField as NormalMotionTerm speed and one per component as AdvectionTerm velocity (the reference's
+    `MeshField` coefficients, src/levelsetterms.jl:42, resident on the device): copied HBM to HBM into the term's
+    coefficient arrays at construction and by `coeff.set_values(...)` inside an update_func — equal to the host-array
+    route bit for bit; a float32 device field widens exactly."""
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (48, 40))
+    X, Y = np.meshgrid(*grid.coords(), indexing="ij")
+    ic = lsm.MeshField(lambda x: np.hypot(x[0] - 0.1, x[1]) - 0.5, grid)
+    sp = np.asfortranarray(0.3 + 0.2 * X * Y)
+    u = [np.asfortranarray(0.5 - Y), np.asfortranarray(0.25 + X * X)]
+    mk = lambda speed, vel, **kw: lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(speed, **kw), lsm.AdvectionTerm(vel, lsm.WENO5())),
+                                                        ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK2())
+    ref = mk(lsm.MeshField(sp, grid), lsm.MeshField(np.stack(u), grid))
+    lsm.integrate_(ref, 0.05)
+    want = ref.current_state().values()
+    donor = mk(0.0, (0.0, 0.0))                         # a handle of the same layout to put device fields on
+    dev = lambda a: lsm.ROCMeshField.from_host(donor.backend, lsm.MeshField(a, grid), donor.bcs)
+    eq = mk(dev(sp), (dev(u[0]), dev(u[1])))
+    lsm.integrate_(eq, 0.05)
+    assert np.array_equal(eq.current_state().values(), want)
+    # refreshed from a device field inside the hook (the natural update_func-driven speed)
+    calls = []
+    eq2 = mk(dev(0 * sp), (dev(u[0]), dev(u[1])), update_func=lambda coeff, field, t: (calls.append(t), coeff.set_values(dev(sp))))
+    lsm.integrate_(eq2, 0.05)
+    assert calls and np.array_equal(eq2.current_state().values(), want)
+    with pytest.raises(ValueError, match="component"):
+        mk(dev(sp), (dev(u[0]),))
+
+
 def test_state_is_a_copy_and_hooks_can_mutate(lsm):
     """src/levelsetequation.jl:67-76 (ic is copied) and :180-185 (hooks may mutate the state)."""
     grid = lsm.CartesianGrid((-1, -1), (1, 1), (32, 32))
@@ -279,33 +308,41 @@ def _patch_dist(monkeypatch):
     monkeypatch.setattr(dist, "all_gather_object", all_gather_object)
 
 
-@pytest.mark.parametrize("world,bc,overlap", [(2, "neumann", True), (3, "neumann", False), (3, "periodic", True), (2, "periodic", False)])
-def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkeypatch, world, bc, overlap):
-    """True slab handles (plane offset, LSM_BC_NONE interfaces, plane-range stages, the exchange driver of
-    api.py) on the GPU: `world` ranks run as threads of this process over an in-process stand-in for the RCCL
-    group.  The concatenated slabs must equal the single-device run bit for bit, Δt reduction included."""
+@pytest.mark.parametrize("world,bc,overlap,integ", [(2, "neumann", True, "rk3"), (3, "neumann", False, "rk3"), (3, "periodic", True, "rk3"),
+                                                   (2, "periodic", False, "rk3"), (3, "periodic", True, "rk2"), (2, "neumann", True, "fe"),
+                                                   (4, "extrap2", True, "rk2")])
+def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkeypatch, world, bc, overlap, integ):
+    """True slab handles (plane offset, LSM_BC_NONE interfaces) driven through the library's own slab step: `world`
+    ranks run as threads of this process over an LSM_COMM_LOCAL group (include/lsm.h, "multi-GPU"), i.e.
+    lsm_comm_attach_local + lsm_advance_* with lsm_halo_start / lsm_halo_wait / lsm_allreduce_dt inside.  The
+    concatenated slabs must equal the single-device run bit for bit, Δt reduction included."""
     import threading
-    _patch_dist(monkeypatch)
     monkeypatch.setenv("LSM_SLAB_OVERLAP", "1" if overlap else "0")
     grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (24, 20, 41))
     ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.4) ** 2) - 0.2, grid)
-    bcs = lsm.PeriodicBC() if bc == "periodic" else lsm.NeumannBC()
+    bcs = {"periodic": lsm.PeriodicBC(), "neumann": lsm.NeumannBC(), "extrap2": (lsm.NeumannBC(), lsm.SymmetryBC(), lsm.ExtrapolationBC(2))}[bc]
+    I = {"rk3": lsm.RK3, "rk2": lsm.RK2, "fe": lsm.ForwardEuler}[integ]
     mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()),
-                                                  lsm.EikonalReinitializationTerm()), ic=ic, bc=bcs, integrator=lsm.RK3(), **kw)
+                                                  lsm.EikonalReinitializationTerm()), ic=ic, bc=bcs, integrator=I(), **kw)
     ref = mk()
     lsm.integrate_(ref, 0.03)
     want = ref.current_state().values()
-    w = _FakeWorld(world)
-    got, errs = [None] * world, []
+    g = lsm.LocalGroup(world)
+    got, errs, info = [None] * world, [], [None] * world
 
     def run(r):
         try:
-            eq = mk(comm=_FakeRank(w, r))
+            eq = mk(comm=g.rank(r))
+            assert eq.lib_comm
+            info[r] = eq.backend.comm_info()
             lsm.integrate_(eq, 0.03)
             got[r] = eq.current_state().values()
+            full = eq.gather_state()
+            assert np.array_equal(full, want)
         except BaseException as e:   # noqa: BLE001 - reported by the main thread
-            errs.append((r, repr(e)))
-            w.barrier.abort()
+            import traceback
+            errs.append((r, traceback.format_exc()))
+            g._barrier.abort()
 
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in ts:
@@ -313,6 +350,7 @@ def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkey
     for t in ts:
         t.join(300)
     assert not errs, errs
+    assert info == [(r, world, 2) for r in range(world)]            # LSM_COMM_LOCAL
     full = np.concatenate(got, axis=2)
     assert full.shape == want.shape
     assert np.array_equal(full, want), np.abs(full - want).max()

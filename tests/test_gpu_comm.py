@@ -1,0 +1,139 @@
+"""The multi-GPU entry points of the C ABI (include/lsm.h, "multi-GPU"): lsm_comm_attach_rccl / _local, lsm_halo_*,
+lsm_allreduce_dt and lsm_advance_* on slab handles — on ONE GPU: a one-rank RCCL communicator (the real librccl), and
+LSM_COMM_LOCAL groups whose ranks are handles of this process (one thread per rank in test_gpu_api.py; here one thread
+driving every rank stage by stage).  Real multi-GPU runs are the driver's SCALE bench."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsm():
+    import lsm_amd
+    return lsm_amd
+
+
+def _equation(lsm, grid, ic, **kw):
+    return lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.vortex_deformation(grid), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+                                ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3(), **kw)
+
+
+def test_one_rank_rccl_communicator(lsm):
+    """ncclCommInitRank through the library (librccl opened at run time), a one-rank group on a whole-grid handle:
+    attach, info, Δt all-reduce (NaN survives), an exchange with no neighbours, overlap switch, detach; the step
+    through lsm_advance_rk3 with the communicator attached equals the plain one bit for bit."""
+    from lsm_amd import _lib as L
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (40, 36, 44))
+    ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+    ref = _equation(lsm, grid, ic)
+    lsm.integrate_(ref, 0.02)
+    eq = _equation(lsm, grid, ic)
+    b = eq.backend
+    uid = b.comm_unique_id()
+    assert len(uid) == L.COMM_ID_BYTES and any(uid)
+    b.comm_attach_rccl(uid, 0, 1)
+    assert b.comm_info() == (0, 1, L.COMM_RCCL)
+    with pytest.raises(L.LsmError, match="already attached"):
+        b.comm_attach_rccl(uid, 0, 1)
+    assert b.allreduce_dt(0.125) == 0.125 and math.isnan(b.allreduce_dt(float("nan"))) and b.allreduce_dt(float("inf")) == float("inf")
+    b.halo_exchange(eq.state.buf)
+    b.comm_set_overlap(False)
+    b.comm_set_overlap(True)
+    lsm.integrate_(eq, 0.02)
+    assert np.array_equal(eq.current_state().values(), ref.current_state().values())
+    L.check(b.h, b.lib.lsm_comm_detach(b.h), "lsm_comm_detach")
+    assert b.comm_info() == (0, 1, L.COMM_NONE)
+    with pytest.raises(L.LsmError, match="no communicator"):
+        b.halo_exchange(eq.state.buf)
+
+
+def test_attach_validates_the_slab_faces(lsm):
+    from lsm_amd import _lib as L
+    from lsm_amd.api import _bc_c, _normalize_bc
+    from lsm_amd.backend import HipBackend
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (16, 16, 24))
+    bcs = _normalize_bc(lsm.NeumannBC(), 3)
+    whole = HipBackend(grid._c(), _bc_c(bcs, 3, (False, False)))
+    slab0 = HipBackend(grid._c(), _bc_c(bcs, 3, (False, True)), slab=(0, 12))
+    slab1 = HipBackend(grid._c(), _bc_c(bcs, 3, (True, False)), slab=(12, 12))
+    with pytest.raises(L.LsmError, match="LSM_BC_NONE"):
+        HipBackend.comm_attach_local([slab0, whole])          # rank 1 lacks the interface face
+    with pytest.raises(L.LsmError, match="one-rank group"):
+        HipBackend.comm_attach_local([slab0])
+    HipBackend.comm_attach_local([slab0, slab1])
+    assert slab0.comm_info() == (0, 2, L.COMM_LOCAL) and slab1.comm_info() == (1, 2, L.COMM_LOCAL)
+    t = slab0.alloc()
+    slab0.halo_start(t)
+    with pytest.raises(L.LsmError, match="has not been waited for"):
+        slab0.halo_start(t)
+    slab1.halo_start(slab1.alloc())
+    slab0.halo_wait()
+    slab1.halo_wait()
+    for b in (slab0, slab1, whole):
+        b.close()
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_local_group_driven_stage_by_stage_from_one_thread(lsm, periodic):
+    """One host thread, every rank: the interface planes of each slab first (lsm_stage_planes + lsm_fill_ghosts_planes),
+    lsm_halo_start on every handle, the interiors, lsm_halo_wait on every handle, then the physical ghost planes —
+    three RK3 stages by hand.  Equal to the single-device step bit for bit."""
+    from lsm_amd import _lib as L
+    from lsm_amd.api import _bc_c, _normalize_bc, _terms_c
+    from lsm_amd.backend import HipBackend
+    n, world = (20, 24, 37), 3
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), n)
+    bc = lsm.PeriodicBC() if periodic else (lsm.NeumannBC(), lsm.ExtrapolationBC(2), lsm.SymmetryBC())
+    ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.4) ** 2 + (x[1] - 0.5) ** 2 + (x[2] - 0.45) ** 2) - 0.25, grid)
+    mk = lambda: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((0.7, -0.4, 1.1), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+                                      ic=ic, bc=bc, integrator=lsm.RK3())
+    ref = mk()
+    dt = 0.5 * ref.compute_cfl(0.0)
+    ref._advance(0.0, dt)
+    want = ref.current_state().values()
+
+    bcs = _normalize_bc(bc, 3)
+    counts = [13, 12, 12]
+    los = [0, 13, 25]
+    backs = [HipBackend(grid._c(), _bc_c(bcs, 3, (r > 0 or periodic, r < world - 1 or periodic)), slab=(los[r], counts[r])) for r in range(world)]
+    HipBackend.comm_attach_local(backs)
+    terms = mk().terms                      # constant coefficients: the same LsmTerm array serves every rank
+    for t in terms:
+        t._bind(grid, backs[0], None)
+    arr, nt = _terms_c(terms), len(terms)
+    phi = [b.alloc() for b in backs]
+    b1 = [b.alloc() for b in backs]
+    b2 = [b.alloc() for b in backs]
+    for r, b in enumerate(backs):
+        b.upload(phi[r], ic.vals[..., los[r]:los[r] + counts[r]])
+        b.fill_ghosts(phi[r], 7)
+    for r, b in enumerate(backs):
+        b.halo_start(phi[r])
+    for b in backs:
+        b.halo_wait()
+    B = L.GHOST + 1
+
+    def stage(psi, phin, out, mode, cdt, t):
+        for r, b in enumerate(backs):
+            for m0, m1 in ((0, B), (counts[r] - B, counts[r])):
+                b.stage_planes(arr, nt, psi[r], phin[r] if phin else None, out[r], None, mode, cdt, 0.0, t, m0, m1)
+                b.fill_ghosts_planes(out[r], m0, m1)
+            b.halo_start(out[r])
+        for r, b in enumerate(backs):
+            b.stage_planes(arr, nt, psi[r], phin[r] if phin else None, out[r], None, mode, cdt, 0.0, t, B, counts[r] - B)
+            b.fill_ghosts_planes(out[r], B, counts[r] - B)
+        for r, b in enumerate(backs):
+            b.halo_wait()
+            b.fill_ghosts(out[r], 1 << 2)
+
+    stage(phi, None, b1, L.BASE_PSI, dt, 0.0)
+    stage(b1, phi, b2, L.BASE_RK3_S2, 0.25 * dt, dt)
+    stage(b2, phi, phi, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.5 * dt)
+    got = np.concatenate([b.download(phi[r]) for r, b in enumerate(backs)], axis=2)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    for b in backs:
+        b.close()
