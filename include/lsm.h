@@ -120,6 +120,19 @@ enum {
                              within 1e-13*max|phi| of the reference arithmetic per stage */
     LSM_MODE_STRICT = 1   /* literal reference operation order, IEEE division, no contraction */
 };
+/* Domain of LSM_MODE_FAST (the 1e-13 bound above holds inside it):
+ *  - differences between neighbouring nodes must stay below 1e35 in magnitude: the WENO5 weights are formed as products
+ *    of squared smoothness indicators with ONE reciprocal (src/derivatives.jl:73-78 divides six times), which leave the
+ *    fp64 range beyond that and produce Inf/NaN.  LSM_FAST_MAX_ABS bounds |phi| so that no difference can get there;
+ *    lsm_check_range tests a field against it (the host layers call it when an equation is built and every 64 steps, and
+ *    refuse to go on: rescale the field or create the handle with LSM_MODE_STRICT, which has no such limit).
+ *  - the floor of the WENO5 regularisation eps = 1e-6*max(v_k^2) + 1e-99 (src/derivatives.jl:72) is, in undivided
+ *    differences, 1e-99*h^2; FAST raises it to 1e-75 so that the weight denominator needs no guard.  Results change only
+ *    where all five differences of a stencil are below ~3e-35, and there by less than those differences: a deviation
+ *    from the reference by design, far inside the tolerance; exactly flat data gives exactly 0 in both modes.
+ *  - an advection velocity component u_d = +0.0 takes the left-biased stencil where the reference takes the right-biased
+ *    one; the term is |0|*W = 0 either way (a NaN velocity gives NaN in both). */
+#define LSM_FAST_MAX_ABS 2.5e34
 /* storage type of the level-set fields of a handle (ϕ, stage buffers, extension targets).  LSM_DTYPE_F32 is a
  * storage format only: values widen exactly on load, every computation is fp64, results are rounded to nearest
  * on store (the reference's Float32 fields compute in mixed Float32/Float64 by Julia's promotion rules; its
@@ -239,6 +252,10 @@ int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream)
 
 /* ---- min/max of the interior, for show (src/meshfield.jl:300-303) ---- */
 int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax);
+/* ---- is `phi` inside the domain of the handle's arithmetic mode?  *ok := 1 for LSM_MODE_STRICT handles and for fields
+ *      with max|phi| <= LSM_FAST_MAX_ABS (NaN entries do not count: they propagate in both modes), else 0;
+ *      *max_abs := max|phi| over the non-NaN interior values (may be NULL).  One reduction pass; synchronous. */
+int lsm_check_range(LsmHandle* h, const void* phi, int* ok, double* max_abs);
 
 /* ---- volume(ϕ) = prod(h)·Σ H(-ϕ) and perimeter(ϕ) = prod(h)·Σ δ(ϕ)‖∇ϕ‖ with the smoothed Heaviside /
  *      Dirac delta of width min(h) (src/levelsetops.jl:27-33,139-149,171-183) over the local slab;

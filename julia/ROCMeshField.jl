@@ -146,7 +146,7 @@ function ROCMeshField(ϕ::LSM.MeshField{N, T}; strict = false, slab = nothing) w
     f = ROCMeshField{N, T, typeof(bcs), S}(buf, LSM.mesh(ϕ), bcs, h, Dict{UInt, Vector{ROCVector{Float64}}}())
     host = _local(values(ϕ), slab)
     _check(h.ptr, ccall((:lsm_upload, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, pointer(buf), host), "lsm_upload")
-    return f
+    return check_range(f)
 end
 
 # values(ϕ): host copy of the (local) interior on demand (show, hooks, tests)
@@ -315,6 +315,14 @@ function LSM._advance!(::LSM.RK3, ϕ::ROCMeshField, (buf1, buf2), terms, tc, Δt
     GC.@preserve hook _check(ϕ.h.ptr, ccall((:lsm_advance_rk3, libhiplsm), Cint,
         (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
         ϕ.h.ptr, ts, length(ts), pointer(ϕ.buf), pointer(buf1.buf), pointer(buf2.buf), tc, Δt, hook, C_NULL), "lsm_advance_rk3")
+    return ϕ
+end
+
+# domain of the FAST arithmetic mode (include/lsm.h, LSM_FAST_MAX_ABS): called when a field is handed to an equation
+function check_range(ϕ::ROCMeshField)
+    ok, m = Ref{Cint}(), Ref{Float64}()
+    _check(ϕ.h.ptr, ccall((:lsm_check_range, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}, Ref{Float64}), ϕ.h.ptr, pointer(ϕ.buf), ok, m), "lsm_check_range")
+    ok[] != 0 || throw(ArgumentError("max|ϕ| = $(m[]) is outside the domain of the FAST arithmetic mode; rescale the field or use ROCMeshField(ϕ; strict = true)"))
     return ϕ
 end
 

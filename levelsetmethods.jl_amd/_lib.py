@@ -25,6 +25,7 @@ MODE_FAST, MODE_STRICT = 0, 1
 DTYPE_F64 = 0
 DTYPE_F32 = 1
 GEOM_CURVATURE, GEOM_GRADIENT, GEOM_NORMAL = 0, 1, 2
+FAST_MAX_ABS = 2.5e34
 COMM_ID_BYTES = 128
 COMM_NONE, COMM_RCCL, COMM_LOCAL = 0, 1, 2
 
@@ -99,6 +100,7 @@ _SIGS = [
     ("lsm_allreduce_dt", C.c_int, [_H, C.POINTER(C.c_double)]),
     ("lsm_eikonal_sign", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("lsm_check_range", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("lsm_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     ("lsm_band_geometry", C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,

@@ -993,6 +993,8 @@ class LevelSetEquation:
             self.backend.upload(self.state.buf, v if self.slab is None else v[..., self.slab[0]:self.slab[0] + self.slab[1]])
         for term in terms:
             term._bind(grid, self.backend, self.slab)
+        self._range_checked_at = 0
+        self._check_range()
         self._bufs = None
         self._hook_keep = None
         import os as _os
@@ -1025,6 +1027,16 @@ class LevelSetEquation:
     def __repr__(self):
         """src/levelsetequation.jl:113-117 (compact form)."""
         return f"LevelSetEquation({self._pde()}, t={_jl_float(self.t)})"
+
+    def _check_range(self):
+        """FAST arithmetic has a domain (include/lsm.h, LSM_MODE_FAST): refuse to run outside it instead of returning
+        Inf/NaN silently.  Checked when the equation is built and every 64 steps (one reduction pass)."""
+        if not hasattr(self.backend, "check_range"):
+            return
+        ok, m = self.backend.check_range(self.state.buf)
+        if not ok:
+            raise ValueError(f"max|ϕ| = {m:.3g} is outside the domain of the FAST arithmetic mode (differences between neighbouring nodes "
+                             f"must stay below 1e35: max|ϕ| <= {L.FAST_MAX_ABS:g}); rescale the field or build the equation with mode=\"strict\"")
 
     # ---- update_term! (src/levelsetterms.jl:14,65-69,148-152) + slow-path coefficient sampling
     def _needs_hook(self):
@@ -1355,6 +1367,9 @@ def integrate_(ls, tf, dt=float("inf"), prehook=None, posthook=None):
         ls._advance(tc, step)
         tc += step
         ls.t = tc
+        ls._range_checked_at += 1
+        if ls._range_checked_at % 64 == 0:
+            ls._check_range()
         ls.update_band()   # re-tube before the posthook (no-op on a full grid) — src/timestepping.jl:115
         if posthook is not None:
             posthook(ls)

@@ -142,6 +142,12 @@ class HipBackend:
             code = self.lib.lsm_advance_rk3(self.h, terms_c, nterms, self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
         L.check(self.h, code, f"lsm_advance_{which}")
 
+    def check_range(self, t):
+        """(ok, max|ϕ|): is the field inside the domain of the handle's arithmetic mode (include/lsm.h, LSM_FAST_MAX_ABS)?"""
+        ok, m = C.c_int(), C.c_double()
+        L.check(self.h, self.lib.lsm_check_range(self.h, self.ptr(t), C.byref(ok), C.byref(m)), "lsm_check_range")
+        return bool(ok.value), m.value
+
     # ---- multi-GPU: slab communicator inside the library (include/lsm.h, "multi-GPU")
     def comm_unique_id(self):
         buf = C.create_string_buffer(L.COMM_ID_BYTES)

@@ -737,6 +737,17 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     return LSM_OK;
 }
 
+int lsm_check_range(LsmHandle* h, const void* phi, int* ok, double* max_abs) {
+    if (!h || !phi || !ok) return LSM_ERR_INVALID;
+    double lo = 0.0, hi = 0.0;
+    LSM_TRY(lsm_extrema(h, phi, &lo, &hi));     // the reduction skips NaN entries unless every entry is NaN
+    double m = fabs(lo) > fabs(hi) ? fabs(lo) : fabs(hi);
+    if (lo > hi) m = 0.0;                       // every entry NaN: nothing to bound
+    if (max_abs) *max_abs = m;
+    *ok = h->mode == LSM_MODE_STRICT || m <= LSM_FAST_MAX_ABS;
+    return LSM_OK;
+}
+
 // volume / perimeter of the LOCAL slab (src/levelsetops.jl:27-33,139-149); mode 0 / 1
 static int measure(LsmHandle* h, int mode, void* phi, double* out) {
     if (!h || !phi || !out) return LSM_ERR_INVALID;

@@ -406,3 +406,35 @@ def test_slab_decomposed_narrow_band_matches_single_device(lsm, monkeypatch, wor
     assert np.array_equal(m, want_m)
     d = np.abs(np.where(m, v - want_v, 0.0))
     assert np.array_equal(v[m], want_v[m]), (float(d.max()), np.argwhere(d > 0)[:8].tolist(), int((d > 0).sum()))
+
+
+def test_fast_mode_refuses_fields_outside_its_domain(lsm):
+    """include/lsm.h, LSM_MODE_FAST: beyond |Δϕ| ≈ 1e35 the one-reciprocal WENO5 weights leave the fp64 range.  The host
+    layer asks lsm_check_range when the equation is built (and every 64 steps) and refuses — no silent Inf/NaN; STRICT
+    mode has no such limit and reproduces the oracle on the same 1e40-scaled field."""
+    from oracle import oracle as orc
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (40, 36))
+    base = lsm.MeshField(lambda x: np.hypot(x[0] - 0.1, x[1]) - 0.5, grid).vals
+    mk = lambda scale, mode: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((0.7, -0.4), lsm.WENO5()),), ic=lsm.MeshField(scale * base, grid),
+                                                  bc=lsm.NeumannBC(), integrator=lsm.RK3(), mode=mode)
+    with pytest.raises(ValueError, match="outside the domain of the FAST arithmetic mode"):
+        mk(1e40, "fast")
+    ok_eq = mk(1e30, "fast")                                   # large but inside: still within the stated tolerance
+    assert ok_eq.backend.check_range(ok_eq.state.buf) == (True, float(np.abs(1e30 * base).max()))
+    eq = mk(1e40, "strict")
+    assert eq.backend.check_range(eq.state.buf)[0]
+    dt = 0.5 * eq.compute_cfl(0.0)
+    eq._advance(0.0, dt)
+    og = orc.Grid((-1, -1), (1, 1), (40, 36))
+    ref = np.asfortranarray(1e40 * base)
+    orc.advance(orc.RK3, og, orc.make_bc("neumann", 2), ref, [orc.advection(orc.const(0.7, -0.4))], 0.0, dt)
+    assert np.array_equal(eq.current_state().values(), ref)
+    ok_eq._advance(0.0, dt)
+    ref30 = np.asfortranarray(1e30 * base)
+    orc.advance(orc.RK3, og, orc.make_bc("neumann", 2), ref30, [orc.advection(orc.const(0.7, -0.4))], 0.0, dt)
+    assert np.abs(ok_eq.current_state().values() - ref30).max() <= 3e-13 * np.abs(ref30).max()
+    # a field that grows out of the domain during a run is caught by the periodic check
+    ok_eq.state.copy_(lsm.MeshField(1e36 * base, grid))
+    ok_eq._range_checked_at = 63
+    with pytest.raises(ValueError, match="outside the domain"):
+        lsm.integrate_(ok_eq, ok_eq.current_time() + 2 * dt)
