@@ -48,7 +48,7 @@ def one_step(eq, tc):
     return tc + dt
 
 
-def cpu_baseline(n_sample, threads):
+def cpu_baseline(n_sample, threads, steps=1):
     """The reference-faithful CPU oracle timed on a bounded sample of the same workload
     (kind 'port': the reference is Julia and cannot run here)."""
     from oracle import oracle as orc
@@ -63,10 +63,24 @@ def cpu_baseline(n_sample, threads):
     phi = g.sample(lambda X, Y, Z: np.sqrt((X - 0.35) ** 2 + (Y - 0.35) ** 2 + (Z - 0.35) ** 2) - 0.15)
     orc.set_threads(threads)
     t0 = time.perf_counter()
-    steps, _, _ = orc.integrate(orc.RK3, g, bc, phi, terms, 1.0, max_steps=1)
+    done, _, _ = orc.integrate(orc.RK3, g, bc, phi, terms, 1.0, max_steps=steps)
     el = time.perf_counter() - t0
     orc.set_threads(1)
-    return n_sample ** 3 * steps / el / 1e6, el
+    return n_sample ** 3 * done / el / 1e6, el
+
+
+def committed_profile(n, world, mode):
+    """The rocprofv3 PMC summary committed for THIS build of the kernels and THIS workload, or None.
+    profiles/r2/pmc_per_dispatch.json records the sha256 of the kernel sources it was measured on (the GPU box has no
+    .git, so the key is the source text, not a commit) and the workload; anything else gets no traffic figure."""
+    try:
+        import lsm_amd
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r2", "pmc_per_dispatch.json")))
+        if pj.get("csrc_sha256") != lsm_amd._lib.source_hash() or pj.get("grid") != [n, n, n] or pj.get("n_gpus") != world or pj.get("mode") != mode:
+            return None
+        return pj
+    except Exception:
+        return None
 
 
 def main():
@@ -77,8 +91,16 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="cells per side of the per-GPU 512³-equivalent workload")
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="side of the single-thread oracle sample")
+    ap.add_argument("--cpu-full", action="store_true", help="SURVEY.md §8d's full CPU sample: 10 steps at 256^3 on one core, 2 at 512^3 on all (minutes)")
+    ap.add_argument("--config", default="headline", choices=["headline", "2", "3", "5"],
+                    help="headline = BASELINE config 4's equation at 512^3 on one GPU (the metric); 2, 3, 5: the other single-GPU BASELINE configs (tools/configs.py)")
     args = ap.parse_args()
+    if args.config != "headline":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import configs
+        print(json.dumps(configs.run(args.config, steps=args.steps, warmup=args.warmup)))
+        return
 
     import torch
     import torch.distributed as dist
@@ -188,33 +210,52 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "stage_time_fraction_of_step": round(stage_ms / (el * 1e3), 4)},
     }
-    # HBM traffic of the stage kernel: PMC counters cannot be collected from inside this process, so the
-    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/r1/,
-    # tools/profile.sh), corrected as calibrated on gfx950 with known-traffic kernels of the same access
-    # width (tools/configs.py calib): FETCH_SIZE counts 1/2 of 8-byte-per-lane reads, WRITE_SIZE is exact.
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_per_dispatch.json")))
-        st = next(v for k, v in pj.items() if "stage_kernel<3, 2, 0, 0, 2" in k)
-        out["roofline"]["traffic"] = round((2.0 * st["FETCH_SIZE"] + st["WRITE_SIZE"]) * 1024.0)
-        out["roofline"]["traffic_source"] = "profiles/r1/pmc_per_dispatch.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> B, per 512^3 launch)"
-    except Exception:
-        pass
-    # the binding resource is the fp64 vector pipe: 239 VALU instructions per node-stage (SQ_INSTS_VALU), ≈225 of
-    # them fp64 arithmetic, 72 of those FMAs: ≈294 flop (per-block opcode counts of the wave-uniform path,
-    # tools/isa_blocks.py)
-    flop_per_node_stage = 294.0
+    # Counter-derived figures cannot be collected from inside this process: they come from the rocprofv3 passes of this
+    # same command committed under profiles/r2/ (tools/profile_r2.sh) — and only when that summary was measured on the
+    # kernel sources this library was built from, on this grid, GPU count and mode.  Otherwise traffic stays null.
+    #   traffic = 2·FETCH_SIZE + WRITE_SIZE (KiB -> B) per launch: FETCH_SIZE counts half of the bytes of the 8-byte-per-lane
+    #   reads of this kernel, WRITE_SIZE is exact (calibrated on known-traffic kernels of the same access width).
+    prof = committed_profile(args.n, world, args.mode) if world == 1 else None
+    if prof:
+        out["roofline"]["traffic"] = int(prof["hbm_traffic_bytes_per_launch"])
+        out["roofline"]["traffic_source"] = "profile-derived: profiles/r2/pmc_per_dispatch.json (same kernel sources, grid, mode)"
+    # The binding resource is the fp64 vector pipe, not HBM: every fp64 VALU instruction holds its SIMD for
+    # 4 cycles (v_rcp/v_rsq_f64: 16; tools/ubench2.hip), and the kernel issues `valu_cycles_per_node_stage` of them per node.
+    # frac_of_issue = that issue time at the clock the kernel holds ÷ the measured launch time.
+    if prof and n_launch:
+        wave_planes = local_cells / 64.0
+        simds = 256 * 4
+        cyc = prof["valu_busy_cycles_per_wave_plane"]
+        clk = prof.get("in_kernel_clock_ghz") or prof["clock_ghz_grbm"]
+        issue_s = wave_planes * cyc / simds / (clk * 1e9)
+        out["roofline_compute"] = {"bound": "fp64_valu", "valu_per_node_stage": round(prof["valu_per_wave_plane"], 1),
+                                   "valu_issue_cycles_per_node_stage": round(cyc, 1),
+                                   "clock_ghz_measured": clk,
+                                   "clock_source": "s_memtime/s_memrealtime stamps, diagnostic build (tools/clock_probe.py)" if prof.get("in_kernel_clock_ghz")
+                                   else "GRBM_GUI_ACTIVE / 8 / duration (rocprofv3)",
+                                   "clock_ghz_nominal": 2.4,
+                                   "frac_of_issue": round(issue_s / avg_launch_s, 4),
+                                   "frac_of_issue_at_nominal_clock": round(wave_planes * cyc / simds / 2.4e9 / avg_launch_s, 4),
+                                   "source": "profiles/r2/pmc_per_dispatch.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU per dispatch) × this run's launch time"}
+    # ≈290 flop per node-stage (72 FMAs among ≈220 fp64 instructions; per-block opcode counts of the wave-uniform path, tools/isa_blocks.py)
+    flop_per_node_stage = 290.0
     out["fp64_vector"] = {"achieved_tflops": round(local_cells * 3 * args.steps * flop_per_node_stage / (stage_ms * 1e-3) / 1e12, 2)
                           if n_launch else 0.0, "peak_tflops": FP64_PEAK_TFLOPS,
                           "note": "algorithmic flop estimate from the ISA of the fused stage kernel (DESIGN.md §3.1)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle on ONE core (the reference's hot path is single-threaded, src/timestepping.jl:101-202)
+        # and OpenMP over all host cores.  Default: 2 RK3 steps at 256^3 on one core, 2 at 512^3 on all cores (≈25 s each);
+        # --cpu-full: 10 steps at 256^3 on one core as SURVEY asks (≈2 min; the rate is the same: profiles/r2/cpu_full.json).
         from oracle import oracle as orc
-        v1, t1 = cpu_baseline(args.cpu_sample, 1)
+        s1 = 10 if args.cpu_full else 2
+        v1, t1 = cpu_baseline(args.cpu_sample, 1, s1)
         nthr = orc.max_threads()
-        vN, tN = cpu_baseline(args.cpu_sample, nthr)
+        vN, tN = cpu_baseline(args.n, nthr, 2)
         out["cpu_baseline"] = {"value": round(v1, 4), "unit": "Mcells/s", "cores": 1, "kind": "port",
-                               "sample": f"1 RK3 step of the same equation on {args.cpu_sample}^3 (oracle, single thread as the "
+                               "sample": f"{s1} RK3 steps of the same equation on {args.cpu_sample}^3 (oracle, single thread as the "
                                          f"reference runs; {t1:.1f} s)",
-                               "all_cores": {"value": round(vN, 4), "cores": nthr, "seconds": round(tN, 2)}}
+                               "all_cores": {"value": round(vN, 4), "cores": nthr, "seconds": round(tN, 2),
+                                             "sample": f"2 RK3 steps on {args.n}^3, OpenMP over the outer dimension"}}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -140,6 +140,19 @@ _SIGS = [
 EXPORTS = [s[0] for s in _SIGS]
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, include/lsm.h): ties a committed profile to the build
+    it was measured on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "lsm.h"), "rb").read())
+    return h.hexdigest()
+
+
 def build(jobs=8):
     """Compile libhiplsm.so for gfx950 with hipcc (csrc/Makefile); works without a GPU."""
     subprocess.check_call(["make", "-s", "-j", str(jobs), "-C", CSRC])

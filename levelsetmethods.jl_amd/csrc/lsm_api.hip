@@ -111,6 +111,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->comm = nullptr;
+    h->d_stamp = nullptr;
     h->cfl_cache_on = true;
     h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
@@ -193,6 +194,7 @@ void lsm_destroy(LsmHandle* h) {
     if (!h) return;
     (void)lsm_comm_detach(h);
     (void)hipSetDevice(h->device);
+    if (h->d_stamp) (void)hipFree(h->d_stamp);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
@@ -330,6 +332,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     a.f32 = is_f32(h);
+    a.stamp = h->d_stamp;
 }
 
 static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
@@ -736,6 +739,34 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     *vmax = h->h_result[1];
     return LSM_OK;
 }
+
+#ifdef LSM_STAMP
+// Diagnostic build only (`make stamp` -> variants/libhiplsm_stamp.so; not declared in include/lsm.h): the stage kernels
+// stamp s_memtime / s_memrealtime around their plane loop.  enable = 1 arms the stamps, enable = 0 reads them back:
+// *clock_ghz = median over the workgroups of Δs_memtime ÷ Δs_memrealtime × 0.1 (MI355X_MICROARCH.md, DVFS item 6).
+int lsm_debug_stamp(LsmHandle* h, int enable, double* clock_ghz, double* loop_us) {
+    if (!h) return LSM_ERR_INVALID;
+    LSM_HIP(h, hipSetDevice(h->device));
+    if (enable) {
+        if (!h->d_stamp) LSM_HIP(h, hipMalloc((void**)&h->d_stamp, sizeof(unsigned long long) * 2 * 8192));
+        LSM_HIP(h, hipMemsetAsync(h->d_stamp, 0, sizeof(unsigned long long) * 2 * 8192, h->stream));
+        return LSM_OK;
+    }
+    if (!h->d_stamp || !clock_ghz) return LSM_ERR_INVALID;
+    std::vector<unsigned long long> v(2 * 8192);
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_HIP(h, hipMemcpy(v.data(), h->d_stamp, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
+    std::vector<double> clk, us;
+    for (int i = 0; i < 8192; ++i)
+        if (v[2 * i + 1]) { clk.push_back((double)v[2 * i] / (double)v[2 * i + 1] * 0.1); us.push_back((double)v[2 * i + 1] * 0.01); }
+    if (clk.empty()) return fail(h, LSM_ERR_INVALID, "lsm_debug_stamp: no stamps (no stage kernel ran since the stamps were armed)");
+    std::sort(clk.begin(), clk.end());
+    std::sort(us.begin(), us.end());
+    *clock_ghz = clk[clk.size() / 2];
+    if (loop_us) *loop_us = us[us.size() / 2];
+    return LSM_OK;
+}
+#endif
 
 int lsm_check_range(LsmHandle* h, const void* phi, int* ok, double* max_abs) {
     if (!h || !phi || !ok) return LSM_ERR_INVALID;

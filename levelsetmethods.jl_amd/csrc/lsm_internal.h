@@ -68,6 +68,7 @@ struct StageArgs {
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
     unsigned ntile_list;
     int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
+    unsigned long long* stamp;         // diagnostic build (-DLSM_STAMP, `make stamp`): per-workgroup {Δs_memtime, Δs_memrealtime} of the plane loop
 };
 
 struct GhostArgs {

@@ -752,6 +752,11 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
             for (int d = 0; d < NDIM; ++d) neg_pre[d] = __builtin_amdgcn_ballot_w64(__double2hiint(pre_adv[d]) < 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the prologue's loads have landed; the loop counts its own
+#ifdef LSM_STAMP
+        // diagnostic build only (MI355X_MICROARCH.md, DVFS item 6): the clock this kernel holds = Δs_memtime ÷ Δs_memrealtime × 100 MHz
+        // around the plane loop, one pair per workgroup, written where nothing else in the kernel reads
+        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // One plane of the march.  ROT > 0: the register line is a ring (see NodeView) and the loop below is unrolled
         // ROT-fold with the rotation Rc a compile-time constant of each copy.
         constexpr int ROT = ZROT ? 2 * G + 1 : 0, RM = ROT > 0 ? ROT : 1;
@@ -833,6 +838,13 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
         } else {
             for (int m = m0; m < m1; ++m) plane_iter(std::integral_constant<int, 0>{}, m);
         }
+#ifdef LSM_STAMP
+        if (a.stamp && threadIdx.x == 0) {
+            const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+            a.stamp[2 * (blockIdx.x % 8192u)] = st_t1 - st_t0;
+            a.stamp[2 * (blockIdx.x % 8192u) + 1] = st_r1 - st_r0;
+        }
+#endif
     }
 }
 

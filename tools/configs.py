@@ -148,6 +148,24 @@ def calib(n=512):
     return {"calib_bytes_read_each": n ** 3 * 8}
 
 
+def run(which, steps=None, warmup=None):
+    """`python bench.py --config {2,3,5}`: one JSON object in bench.py's vocabulary for a non-headline BASELINE config."""
+    kw = {} if steps is None else {"steps": steps}
+    r = {"2": config2, "3": config3, "5": config5}[which](**kw)
+    out = {"metric": "Mcells/s per RK3 step", "unit": "Mcells/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+           "dtype": "f32 storage / f64 arithmetic" if which == "5" else "f64", "config": {"workload": r["config"]}, "detail": r}
+    if which == "2":
+        out["value"], out["ms_per_step"] = round(r["advect_Mcells_s"], 1), round(r["advect_ms_per_step"], 4)
+    elif which == "3":
+        out["value"], out["ms_per_step"] = round(r["Mcells_s"], 1), round(r["ms_per_step"], 4)
+        a = r["GBs_algorithmic"]
+        out["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 4), "traffic": None,
+                           "kernel": "stage_kernel<3,NormalMotion,Curvature>", "avg_launch_ms": round(r["stage_ms"], 4)}
+    else:
+        out["value"], out["ms_per_step"] = r["float32"]["Mcells_s_grid"], r["float32"]["ms_per_step"]
+    return out
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []

@@ -1,24 +1,28 @@
 #!/usr/bin/env python
-"""Cost of the slab driver on ONE device (no neighbours, so no transfer): the per-rank workload of
-`bench.py --gpus N` (2n x 2n x n/4 nodes) stepped (a) by lsm_advance_rk3, (b) by the stage-by-stage slab driver,
-(c) by the slab driver with the boundary-first split used to overlap the halo exchange."""
+"""Cost of the slab step on ONE device (GPU box).  Grid = two ranks' share of `bench.py --gpus N` (2n x 2n x n/2 nodes):
+  (a) one whole-grid handle stepped by lsm_advance_rk3;
+  (b) the same grid as TWO slab handles of this process (LSM_COMM_LOCAL, one thread per rank) stepped by lsm_advance_rk3
+      with the library's slab step: interface planes first, plane exchange (device-to-device copies here, xGMI on a real
+      node) overlapped with the interior, Δt all-reduce — both ranks share the one GPU, so the time is the sum of their
+      work plus everything the decomposition adds;
+  (c) the same with the overlap switched off (stage -> ghost fill -> exchange).
+(b)/(a) - 1 is the overhead of the decomposition itself, transfers excluded."""
 import json
 import os
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-import torch.distributed as dist
 
 import bench
 import lsm_amd as lsm
 
 
-def run(n, comm, force, steps=6):
-    eq, _, _ = bench.build_equation(lsm, n, comm, 0, "fast")
-    eq._force_overlap = force
+def run_whole(n, steps):
+    eq, _, _ = bench.build_equation(lsm, n, None, 0, "fast")
     tc = 0.0
     for _ in range(2):
         tc = bench.one_step(eq, tc)
@@ -30,13 +34,47 @@ def run(n, comm, force, steps=6):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def run_slabs(n, steps, overlap, world=2):
+    g = lsm.LocalGroup(world)
+    bar = threading.Barrier(world)
+    out, errs = [0.0] * world, []
+
+    def rank(r):
+        try:
+            eq, _, _ = bench.build_equation(lsm, n, g.rank(r), 0, "fast")
+            eq.backend.comm_set_overlap(overlap)
+            tc = 0.0
+            for _ in range(2):
+                tc = bench.one_step(eq, tc)
+            torch.cuda.synchronize()
+            bar.wait()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tc = bench.one_step(eq, tc)
+            torch.cuda.synchronize()
+            bar.wait()
+            out[r] = (time.perf_counter() - t0) / steps * 1e3
+        except BaseException as e:   # noqa: BLE001
+            errs.append(repr(e))
+            bar.abort()
+            g._barrier.abort()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise RuntimeError(errs)
+    return max(out)
+
+
 if __name__ == "__main__":
     base = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    n = (2 * base, 2 * base, base // 4)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    dist.init_process_group("nccl", rank=0, world_size=1)
-    out = {"grid": n, "advance_ms": round(run(n, None, False), 3), "slab_driver_ms": round(run(n, dist.group.WORLD, False), 3),
-           "slab_driver_split_ms": round(run(n, dist.group.WORLD, True), 3)}
-    dist.destroy_process_group()
-    print(json.dumps(out))
+    steps = 6
+    n = (2 * base, 2 * base, base // 2)
+    a = run_whole(n, steps)
+    b = run_slabs(n, steps, True)
+    c = run_slabs(n, steps, False)
+    print(json.dumps({"grid": n, "whole_grid_ms": round(a, 3), "two_local_slabs_overlap_ms": round(b, 3), "two_local_slabs_plain_ms": round(c, 3),
+                      "decomposition_overhead": round(b / a - 1, 4), "note": "one device: the two ranks share it, transfers are device-to-device copies"}))
