@@ -72,15 +72,20 @@ LSM_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, int range = (int)0x8
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, range, 0x00020000);
 }
 constexpr unsigned LSM_OOB_OFFSET = 0xC0000000u;
-template <class ST>
+// AUX = cache policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1); LSM_NT_STREAM (A/B switch) marks the
+// once-touched streams — ϕⁿ of the convex combination and the output — non-temporal
+#ifndef LSM_NT_STREAM
+#define LSM_NT_STREAM 0
+#endif
+template <class ST, int AUX = 0>
 LSM_DEV double ldg(const ST* base, unsigned boff, int range = (int)0x80000000u) {   // range 0: returns 0, no access
-    if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base, range), boff, 0, 0));
-    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base, range), boff, 0, 0));
+    if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base, range), boff, 0, AUX));
+    else return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(base, range), boff, 0, AUX));
 }
-template <class ST>
+template <class ST, int AUX = 0>
 LSM_DEV void stg(ST* base, unsigned boff, double v) {
-    if constexpr (sizeof(ST) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lsm_v2u, v), plane_rsrc(base), boff, 0, 0);
-    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), plane_rsrc(base), boff, 0, 0);
+    if constexpr (sizeof(ST) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lsm_v2u, v), plane_rsrc(base), boff, 0, AUX);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), plane_rsrc(base), boff, 0, AUX);
 }
 // byte load with an explicit range: range 0 (no array) returns 0 without touching memory
 LSM_DEV unsigned ldg_u8(const unsigned char* base, unsigned boff, int range) {
@@ -220,7 +225,7 @@ LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pr
     if constexpr (EIK == 1) op.s0 = ldg(uniform_ptr(a.s0 + io.plane_off), io.ocold);
     // always issued (a load inside a branch costs the loop its exact wait counts); when the base is ψ the
     // descriptor's range is 0: the load returns 0 and touches no memory
-    op.phin = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol,
+    op.phin = ldg<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol,
                   __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u));
     if (AK < 0 && a.out2 && a.out2_accum) op.out2 = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.out2) + io.plane_off), io.ocol);
 }
@@ -576,7 +581,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
 template <class ST, bool PLAIN>
 LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_out, double r_out2) {
     if (!on) return;
-    stg(uniform_ptr(reinterpret_cast<ST*>(a.out) + io.plane_off), io.ocol, r_out);
+    stg<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + io.plane_off), io.ocol, r_out);
     if (!PLAIN && a.out2) stg(uniform_ptr(reinterpret_cast<ST*>(a.out2) + io.plane_off), io.ocol, r_out2);
 }
 
@@ -872,9 +877,34 @@ struct TileCfg<2> { static constexpr int TX = LSM_TX2, TY = 1, MC = LSM_MC2; };
 template <>
 struct TileCfg<3> { static constexpr int TX = LSM_TX3, TY = LSM_TY3, MC = LSM_MC3; };
 
+// The light members of the family in 3-D — a single upwind / NormalMotion / Eikonal term: little arithmetic per byte —
+// run 8–14 % faster on a 64×8 tile (512 threads; halo 1.5 instead of 1.7-fold, twice the bytes per row) when the field
+// is dense (the narrow band's tile flags describe the standard 32×8 brick).  Measured: tools/terms_ab.sh, DESIGN.md §3.1.
+#ifndef LSM_WIDE_TILES
+#define LSM_WIDE_TILES 1
+#endif
+template <int NDIM, int ADV, int NM, int CURV, int EIK>
+constexpr bool wide_tile_combo() {
+    return LSM_WIDE_TILES && !LSM_STRICT && NDIM == 3 && !CURV && ADV != 2 && (ADV != 0) + (NM != 0) + (EIK != 0) == 1;
+}
+struct WideTile3 { static constexpr int TX = 64, TY = 8, MC = LSM_MC3; };
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK, class T>
+void launch_tiled(const StageArgs& a, hipStream_t s);
+
 template <int NDIM, int ADV, int NM, int CURV, int EIK>
 void launch_one(const StageArgs& a, hipStream_t s) {
-    using T = TileCfg<NDIM>;
+    if constexpr (wide_tile_combo<NDIM, ADV, NM, CURV, EIK>()) {
+        if (!a.mask && !a.tile_active && !a.tile_list && a.mc <= 0 && a.n[0] >= 64 && !a.out2) {
+            launch_tiled<NDIM, ADV, NM, CURV, EIK, WideTile3>(a, s);
+            return;
+        }
+    }
+    launch_tiled<NDIM, ADV, NM, CURV, EIK, TileCfg<NDIM>>(a, s);
+}
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK, class T>
+void launch_tiled(const StageArgs& a, hipStream_t s) {
     dim3 block(T::TX * T::TY);
     StageArgs b = a;
     b.nb[0] = (a.n[0] + T::TX - 1) / T::TX;
