@@ -503,7 +503,9 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             // does not queue behind the stages on the main stream (LSM_CFL_MAIN_STREAM=1 is the A/B switch).  A table is
             // waited for once, the first time it is seen (its upload was ordered on the main stream).
             static const bool main_env = getenv("LSM_CFL_MAIN_STREAM") != nullptr;
-            const bool side = !main_env && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD;
+            // Only while the coefficient cache is on: lsm_cfl_cache(h, 0) is how a caller says "tables may be rewritten in
+            // place between calls" (hooks), and such writes are ordered on the main stream only.
+            const bool side = !main_env && h->cfl_cache_on && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD;
             if (side && tm.coeff.kind == LSM_COEFF_SEPARABLE)
                 for (int c = 0; c < 3; ++c) {
                     const void* tp = tm.coeff.sep[c];
