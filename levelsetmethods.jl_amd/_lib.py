@@ -140,16 +140,18 @@ _SIGS = [
 EXPORTS = [s[0] for s in _SIGS]
 
 
+STAGE_KERNEL_SOURCES = ("stage_kernel.h", "stage_math.h", "stage_tu.hip", "lsm_internal.h", "Makefile")
+
+
 def source_hash():
-    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, include/lsm.h): ties a committed profile to the build
-    it was measured on (the GPU box has no .git)."""
+    """sha256 over the sources the fused stage kernels are compiled from (csrc/stage_kernel.h, stage_math.h,
+    stage_tu.hip, lsm_internal.h, Makefile): ties a committed profile of that kernel to the build it was measured on
+    (the GPU box has no .git)."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
-    for f in files:
+    for f in STAGE_KERNEL_SOURCES:
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "lsm.h"), "rb").read())
     return h.hexdigest()
 
 
