@@ -412,7 +412,10 @@ __device__ __forceinline__ void stage_rows(const BandArgs& a, int ap, int bx, in
                 const int k = k0 + u < cnt ? k0 + u : cnt - 1;
                 const long long q = (long long)readlane64(base, k) + xoff;
                 const bool ok = xok & (__builtin_amdgcn_readlane(rok, k) != 0) & (k0 + u < cnt);
-                f[u] = load(q, ok, readlane64(bin, k));
+                const u64 rowB = readlane64(bin, k);
+                // second pass: an x-line without a band node has nothing to fetch (wave-uniform: the row word is a scalar) —
+                // about half of the rows of a work tile's box; the kernel is bound by the latency of these row loads
+                f[u] = (Bin && rowB == 0) ? 0u : load(q, ok, rowB);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
