@@ -34,6 +34,7 @@ using namespace lsm;
 
 struct LsmHandle;
 static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work);
+static bool have_lists(const LsmHandle* h, const void* tiles, int mc);
 static const int MAXB = 4096;
 static std::string g_create_err;
 
@@ -573,7 +574,12 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
                     }
                 }
             }
-            if (cand) {
+            int nlisted = 0;
+            if (h->band_mask && N == 3 && a.tile_active && have_lists(h, h->band_tiles, h->band_mc))
+                nlisted = launch_cfl_band_list(a, h->d_act_list, h->nact, 1024, cs);   // one workgroup per active tile
+            if (nlisted > 0) {
+                nb = nlisted;
+            } else if (cand) {
                 CflArgs b = a;
                 b.cand = cand->d_cand;
                 launch_cfl_candidates(N, b, cand->count, cs);

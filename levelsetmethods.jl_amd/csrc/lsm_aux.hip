@@ -398,6 +398,84 @@ void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream
     else { if (adv) hipLaunchKernelGGL((cfl_cand_kernel<3, LSM_TERM_ADVECTION>), dim3(1), dim3(256), 0, s, a, count); else hipLaunchKernelGGL((cfl_cand_kernel<3, LSM_TERM_NORMAL_MOTION>), dim3(1), dim3(256), 0, s, a, count); }
 }
 
+// Narrow band in 3-D with the compact list of active tiles at hand (lsm_band_status): one workgroup per listed 32×8×tm
+// tile instead of a march over every column of the grid (at 768³ the column kernel spends 0.15 ms stepping over 221 k tile
+// flags to visit 3.7 M band nodes).  Exact divisions throughout: the band is small.  Same node formulas and the same
+// max-then-divide reduction as cfl_kernel, so Δt is bit-identical.
+template <int TKIND, int CKIND>
+__global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, const int* list, unsigned nlist) {
+    constexpr int NCOMP = TKIND == LSM_TERM_ADVECTION ? 3 : 1;
+    const CoeffArgs& c = a.coeff;
+    double best = 0.0;
+    int sawnan = 0;
+    const int lx = threadIdx.x % a.tx, ly = threadIdx.x / a.tx;     // the launcher checks tx·ty == 256
+    for (unsigned e = blockIdx.x; e < nlist; e += gridDim.x) {
+        const unsigned tile = (unsigned)list[e];
+        const int i0 = (int)(tile % a.nbx) * a.tx + lx, i1 = (int)((tile / a.nbx) % a.nby) * a.ty + ly;
+        const int mlo = (int)(tile / (a.nbx * a.nby)) * a.tm;
+        if (i0 >= a.n[0] || i1 >= a.n[1]) continue;
+        const int g0 = i0 + a.goff[0], g1 = i1 + a.goff[1];
+        const long long cbase = a.origin + i0 + i1 * a.s1;
+        for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) {
+            const long long q = cbase + m * a.s2;
+            if (!a.mask[q]) continue;
+            double u[3] = {0, 0, 0};
+            if constexpr (CKIND == LSM_COEFF_CONST) {
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) u[k] = c.v[k];
+            } else if constexpr (CKIND == LSM_COEFF_SEPARABLE) {
+                const int gm = a.gn[0] + a.gn[1] + a.goff[2] + m;
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) u[k] = ((c.sep[k][g0] * c.sep[k][a.gn[0] + g1]) * c.sep[k][gm]) * c.tfac;
+            } else if constexpr (CKIND == LSM_COEFF_ROTATION) {
+                u[0] = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
+                u[1] = c.v[0] * ((a.lc[0] + (double)g0 * a.h[0]) - c.v[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NCOMP; ++k) u[k] = c.f[k][q];
+            }
+            if (u[0] != u[0] || u[1] != u[1] || u[2] != u[2]) sawnan = 1;
+            double sv;
+            if constexpr (TKIND == LSM_TERM_ADVECTION) sv = (__builtin_fabs(u[0]) / a.h[0] + __builtin_fabs(u[1]) / a.h[1]) + __builtin_fabs(u[2]) / a.h[2];
+            else if constexpr (TKIND == LSM_TERM_NORMAL_MOTION) sv = (__builtin_fabs(u[0]) / a.h[0] + __builtin_fabs(u[0]) / a.h[1]) + __builtin_fabs(u[0]) / a.h[2];
+            else sv = __builtin_fabs(u[0]);
+            if (sv == sv) best = sv > best ? sv : best;
+        }
+    }
+    best = wave_max(best);
+    sawnan = __any(sawnan) ? 1 : 0;
+    __shared__ double smax[4];
+    __shared__ int snan[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { smax[wave] = best; snan[wave] = sawnan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = smax[0];
+        int f = snan[0];
+        for (int w = 1; w < 4; ++w) { m = smax[w] > m ? smax[w] : m; f |= snan[w]; }
+        a.partial[blockIdx.x] = m;
+        if (f) atomicOr(a.nanflag, 1);
+    }
+}
+template <int TKIND>
+static void launch_cfl_band_list_ck(const CflArgs& a, const int* list, unsigned nlist, unsigned grid, hipStream_t s) {
+    switch (a.coeff.kind) {
+    case LSM_COEFF_CONST: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_CONST>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
+    case LSM_COEFF_ROTATION: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_ROTATION>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
+    case LSM_COEFF_SEPARABLE: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_SEPARABLE>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
+    default: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_FIELD>), dim3(grid), dim3(256), 0, s, a, list, nlist);
+    }
+}
+// returns the number of partials written (0: not applicable — use launch_cfl)
+int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, int max_partials, hipStream_t s) {
+    if (!list || nlist == 0 || !a.mask || a.tx * a.ty != 256 || a.tm < 1) return 0;
+    const unsigned grid = nlist < (unsigned)max_partials ? nlist : (unsigned)max_partials;
+    if (a.term_kind == LSM_TERM_ADVECTION) launch_cfl_band_list_ck<LSM_TERM_ADVECTION>(a, list, nlist, grid, s);
+    else if (a.term_kind == LSM_TERM_NORMAL_MOTION) launch_cfl_band_list_ck<LSM_TERM_NORMAL_MOTION>(a, list, nlist, grid, s);
+    else launch_cfl_band_list_ck<LSM_TERM_CURVATURE>(a, list, nlist, grid, s);
+    return (int)grid;
+}
+
 static int cfl_chunks(int ndim, const int n[3]) {
     if (ndim == 1) return 1;
     int c = 4;

@@ -776,52 +776,79 @@ __global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsign
 // compact, ordered lists of the active tiles and of the work tiles (active or next to one), so that the
 // next launches cover those tiles only; counts[0..1] = list lengths, counts[2] = number of work tiles on a
 // face of the grid (0: no band node can sit within a tile of the boundary before the next update, so no
-// stencil reaches outside the grid).  One block: chunked exclusive scan, flags read 8 at a time.
+// stencil reaches outside the grid; zeroed by the launcher, accumulated here).
+// One workgroup per chunk of 8192 tiles (8 flags = one 64-bit word per thread, coalesced).  A chunk's offset into the
+// lists is the number of set flags before it, which the workgroup counts itself (one word per thread and preceding
+// chunk: 3 MB of reads in all at 768³) — no pass between workgroups, one launch.  (The first version was ONE workgroup
+// whose threads each walked a contiguous run of flags: 0.10 ms at 768³, every load its own cache line.)
+constexpr unsigned LISTS_CHUNK = 8192;
+__device__ __forceinline__ unsigned nz_bytes(unsigned long long w) {       // number of non-zero bytes of a word
+    w |= w >> 4; w |= w >> 2; w |= w >> 1;
+    return (unsigned)__builtin_popcountll(w & 0x0101010101010101ull);
+}
 __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsigned char* active, const unsigned char* work,
                                                           int* act_list, int* work_list, unsigned* counts) {
-    __shared__ unsigned sa[1024], sw[1024], sb[1024];
+    __shared__ unsigned red[2][16], wsum[2][16];
     const unsigned ntiles = a.nbx * a.nby * a.nbm;
-    const unsigned per = ((ntiles + blockDim.x - 1) / blockDim.x + 7u) & ~7u;      // multiple of 8: chunks stay word-aligned
-    const unsigned t0 = threadIdx.x * per < ntiles ? threadIdx.x * per : ntiles, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     const bool words = (((unsigned long long)active | (unsigned long long)work) & 7ull) == 0;
     auto flags8 = [&](const unsigned char* p, unsigned t) -> unsigned long long {   // flags of tiles t .. t+7 (t % 8 == 0)
+        if (t >= ntiles) return 0ull;
         if (words && t + 8 <= ntiles) return *(const unsigned long long*)(p + t);
         unsigned long long r = 0;
         for (unsigned k = 0; k < 8 && t + k < ntiles; ++k) r |= (unsigned long long)p[t + k] << (8 * k);
         return r;
     };
-    unsigned na = 0, nw = 0, nbd = 0;
-    for (unsigned t = t0; t < t1; t += 8) {
-        const unsigned long long fa = flags8(active, t), fw = flags8(work, t);
-        for (unsigned k = 0; k < 8; ++k) {
-            na += ((fa >> (8 * k)) & 0xff) ? 1 : 0;
-            if ((fw >> (8 * k)) & 0xff) {
-                ++nw;
-                const unsigned tt = t + k, bx = tt % a.nbx, by = (tt / a.nbx) % a.nby, bm = tt / (a.nbx * a.nby);
-                const bool face = bx == 0 || bx == a.nbx - 1 || (a.ndim == 3 && (by == 0 || by == a.nby - 1)) ||
-                                  (a.ndim >= 2 && (bm == 0 || bm == a.nbm - 1));
-                nbd += face ? 1 : 0;
-            }
-        }
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto wave_sum = [&](unsigned v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+    // offset of this chunk = set flags in the chunks before it
+    unsigned pa = 0, pw = 0;
+    for (unsigned cb = 0; cb < blockIdx.x; ++cb) {
+        const unsigned t = cb * LISTS_CHUNK + threadIdx.x * 8;
+        pa += nz_bytes(flags8(active, t));
+        pw += nz_bytes(flags8(work, t));
     }
-    sa[threadIdx.x] = na; sw[threadIdx.x] = nw; sb[threadIdx.x] = nbd;
+    pa = wave_sum(pa); pw = wave_sum(pw);
+    if (lane == 0) { red[0][wave] = pa; red[1][wave] = pw; }
+    // own chunk: one word per thread, exclusive scan over the workgroup (wave scan + 16 wave totals)
+    const unsigned t0 = blockIdx.x * LISTS_CHUNK + threadIdx.x * 8;
+    const unsigned long long fa = flags8(active, t0), fw = flags8(work, t0);
+    const unsigned na = nz_bytes(fa), nw = nz_bytes(fw);
+    unsigned ia = na, iw = nw;                                    // inclusive wave scans
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned va = __shfl_up(ia, off, 64), vw = __shfl_up(iw, off, 64);
+        if ((int)lane >= off) { ia += va; iw += vw; }
+    }
+    if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = iw; }
     __syncthreads();
-    for (unsigned off = 1; off < blockDim.x; off <<= 1) {      // inclusive Hillis-Steele scan
-        const bool on = threadIdx.x >= off;
-        const unsigned va = on ? sa[threadIdx.x - off] : 0, vw = on ? sw[threadIdx.x - off] : 0, vb = on ? sb[threadIdx.x - off] : 0;
-        __syncthreads();
-        sa[threadIdx.x] += va; sw[threadIdx.x] += vw; sb[threadIdx.x] += vb;
-        __syncthreads();
+    unsigned offa = 0, offw = 0, tota = 0, totw = 0;
+    for (unsigned w = 0; w < 16; ++w) {
+        offa += red[0][w]; offw += red[1][w];
+        if (w < wave) { offa += wsum[0][w]; offw += wsum[1][w]; }
+        tota += wsum[0][w]; totw += wsum[1][w];
     }
-    unsigned ia = sa[threadIdx.x] - na, iw = sw[threadIdx.x] - nw;
-    for (unsigned t = t0; t < t1; t += 8) {
-        const unsigned long long fa = flags8(active, t), fw = flags8(work, t);
-        for (unsigned k = 0; k < 8; ++k) {
-            if ((fa >> (8 * k)) & 0xff) act_list[ia++] = (int)(t + k);
-            if ((fw >> (8 * k)) & 0xff) work_list[iw++] = (int)(t + k);
+    ia = offa + ia - na; iw = offw + iw - nw;
+    unsigned nbd = 0;
+    for (unsigned k = 0; k < 8; ++k) {
+        if ((fa >> (8 * k)) & 0xff) act_list[ia++] = (int)(t0 + k);
+        if ((fw >> (8 * k)) & 0xff) {
+            work_list[iw++] = (int)(t0 + k);
+            const unsigned tt = t0 + k, bx = tt % a.nbx, by = (tt / a.nbx) % a.nby, bm = tt / (a.nbx * a.nby);
+            const bool face = bx == 0 || bx == a.nbx - 1 || (a.ndim == 3 && (by == 0 || by == a.nby - 1)) ||
+                              (a.ndim >= 2 && (bm == 0 || bm == a.nbm - 1));
+            nbd += face ? 1 : 0;
         }
     }
-    if (threadIdx.x == blockDim.x - 1) { counts[0] = sa[threadIdx.x]; counts[1] = sw[threadIdx.x]; counts[2] = sb[threadIdx.x]; }
+    nbd = wave_sum(nbd);
+    if (lane == 0 && nbd) atomicAdd(&counts[2], nbd);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        unsigned ba = 0, bw = 0;
+        for (unsigned w = 0; w < 16; ++w) { ba += red[0][w]; bw += red[1][w]; }
+        counts[0] = ba + tota;
+        counts[1] = bw + totw;
+    }
 }
 
 __global__ void __launch_bounds__(256) band_count_kernel(BandArgs a, const unsigned char* mask, unsigned long long* count) {
@@ -906,7 +933,9 @@ void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned c
 }
 void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list,
                        unsigned* counts, hipStream_t s) {
-    hipLaunchKernelGGL(band_lists_kernel, dim3(1), dim3(1024), 0, s, a, active, work, act_list, work_list, counts);
+    const unsigned ntiles = a.nbx * a.nby * a.nbm;
+    (void)hipMemsetAsync(counts + 2, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, act_list, work_list, counts);
 }
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s) {
     if (no_tiles(a)) return;

@@ -190,6 +190,7 @@ void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s);
 int cfl_blocks(int ndim, const int n[3]);
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s);
 void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream_t s);
+int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, int max_partials, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
                       int pass, hipStream_t s);
 void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const void* v, int f32,
