@@ -431,6 +431,45 @@ __device__ __forceinline__ void stage_rows(const BandArgs& a, int ap, int bx, in
     }
 }
 
+// The row words of a BYTE mask, eight mask bytes per lane: a lane takes piece p (bytes 8p .. 8p+7) of row r, so that one
+// wave instruction covers 64 / ceil(bx/8) rows (12 for the 40-node rows of a 32-wide tile with apron 4) instead of one —
+// the kernels that stage masks are bound by the latency of these loads, not by their bytes.  Unaligned 8-byte loads
+// (rows start at arbitrary byte offsets); bytes outside [0, n0) of the row or beyond the box are dropped; a row outside
+// the grid is empty.  mask == NULL: every in-grid node counts as set (update_band! from a dense field).
+typedef u64 u64_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ void stage_mask_rows8(const BandArgs& a, int ap, int bx, int by, int bm, int x0, int y0, int m0, u64* out,
+                                                 const unsigned char* mask) {
+    const int nrows = by * bm;
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) out[t] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int ppr = (bx + 7) >> 3, rpi = 64 / ppr;
+    const int p = lane % ppr, rl = lane / ppr;
+    const int gx0 = x0 - ap + 8 * p;
+    // bytes [lo, hi) of this lane's piece lie inside the row of the grid and inside the box
+    int lo = gx0 < 0 ? -gx0 : 0, hi = 8;
+    if (a.n[0] - gx0 < hi) hi = a.n[0] - gx0;
+    if (bx - 8 * p < hi) hi = bx - 8 * p;
+    const u64 keep = hi > lo ? ((~0ull >> (64 - 8 * (hi - lo))) << (8 * lo)) : 0ull;
+    const float rby = 1.0f / (float)by;
+    unsigned char* ob = reinterpret_cast<unsigned char*>(out);
+    for (int r0 = wv * rpi; r0 < nrows; r0 += nwv * rpi) {
+        const int row = r0 + rl;
+        if (rl >= rpi || row >= nrows || keep == 0) continue;
+        int lm = (int)((float)row * rby), ly = row - lm * by;
+        if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+        const int gy = y0 - ap + ly, gm = m0 - ap + lm;
+        if ((unsigned)gy >= (unsigned)a.n[1] || (unsigned)gm >= (unsigned)a.n[2]) continue;
+        u64 w = 0x0101010101010101ull;
+        if (mask) w = *reinterpret_cast<const u64_unaligned*>(mask + (a.origin + gy * a.s1 + gm * a.s2 + gx0));
+        w &= keep;
+        // non-zero bytes -> one bit each, gathered into the low byte
+        u64 t = ((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w;
+        t = (t >> 7) & 0x0101010101010101ull;
+        ob[row * 8 + p] = (unsigned char)((t * 0x0102040810204080ull) >> 56);
+    }
+}
+
 // update_band! for one 32×8×mc tile (see band_grow_kernel)
 __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void* v, const unsigned char* old_mask, int nl,
                                                          unsigned char* new_mask, unsigned char* tiles) {
@@ -444,11 +483,7 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
     extern __shared__ u64 w3[];
     u64 *B = w3, *LE = w3 + nrows, *GE = w3 + 2 * nrows, *S0 = w3 + 3 * nrows, *S1 = w3 + 4 * nrows;
     // pass 1: the old band's row words; tiles whose box holds no band node have no cut cell -> empty
-    u64* const out1[1] = {B};
-    stage_rows<GK, 1>(a, ap, bx, by, bm, x0, y0, m0, out1, nullptr, [&](long long q, bool ok, u64) -> unsigned {
-        const unsigned f = old_mask ? (unsigned)old_mask[q] : 1u;
-        return ok ? f : 0u;
-    });
+    stage_mask_rows8(a, ap, bx, by, bm, x0, y0, m0, B, old_mask);
     __syncthreads();
     // tile is 32 × 8 × tm; the block's 256-thread groups take planes pg, pg + npg, ...
     const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
