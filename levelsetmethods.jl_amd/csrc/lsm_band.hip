@@ -211,6 +211,19 @@ __global__ void __launch_bounds__(256) band_dilate_kernel(BandArgs a, const unsi
 
 __global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsigned char* in, unsigned char* out) {
     LSM_TILE_PROLOGUE(a)
+    if (ex_ % 8 == 0 && x0_ + ex_ <= nx_) {
+        // whole x-rows of the tile inside the grid: 8 mask bytes per access (unaligned), one access per thread and round
+        // instead of eight rounds of byte copies (the kernel is bound by the latency of its rounds)
+        typedef unsigned long long w8 __attribute__((aligned(1)));
+        const int ppr = ex_ / 8;
+        for (int e_ = threadIdx.x; e_ < ppr * ey_ * em_; e_ += blockDim.x) {
+            const int x = x0_ + 8 * (e_ % ppr), y = y0_ + (e_ / ppr) % ey_, m = m0_ + e_ / (ppr * ey_);
+            if (y >= ny_ || m >= nm_) continue;
+            const long long q = a.origin + x + y * sy_ + m * sm_;
+            *reinterpret_cast<w8*>(out + q) = *reinterpret_cast<const w8*>(in + q);
+        }
+        return;
+    }
     LSM_TILE_FOR(a, x, y, m, q) out[q] = in[q];
 }
 
@@ -555,7 +568,20 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
         u64* tmp = cur; cur = nxt; nxt = tmp;
     }
     int any = 0;
-    if (x < a.n[0] && y < a.n[1]) {
+    if (x0 + a.tx <= a.n[0]) {
+        // whole x-rows inside the grid: a thread expands 8 bits of a row word to 8 mask bytes and stores them at once
+        typedef u64 w8 __attribute__((aligned(1)));
+        const int ppr = a.tx / 8;                                  // 4 pieces per 32-node row
+        for (int e = threadIdx.x; e < ppr * a.ty * a.tm; e += blockDim.x) {
+            const int p = e % ppr, ry = (e / ppr) % a.ty, i = e / (ppr * a.ty);
+            if (y0 + ry >= a.n[1] || m0 + i >= a.n[2]) continue;
+            const u64 bits = (cur[(ry + ap) + by * (i + ap)] >> (8 * p + ap)) & 0xffull;
+            u64 w = (bits * 0x0101010101010101ull) & 0x8040201008040201ull;      // byte k = bit k (as 1 << k)
+            w = ((((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w) >> 7) & 0x0101010101010101ull;
+            *reinterpret_cast<w8*>(new_mask + (a.origin + x0 + 8 * p + (y0 + ry) * a.s1 + (m0 + i) * a.s2)) = w;
+            any |= bits ? 1 : 0;
+        }
+    } else if (x < a.n[0] && y < a.n[1]) {
         for (int i = pg; i < a.tm && m0 + i < a.n[2]; i += npg) {
             const unsigned char on = (unsigned char)((cur[(ty_ + ap) + by * (i + ap)] >> (tx_ + ap)) & 1ull);
             new_mask[a.origin + x + y * a.s1 + (m0 + i) * a.s2] = on;
@@ -602,11 +628,7 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
         }
         xkey[p] = k;
     }
-    u64* const outs[1] = {B};
-    stage_rows<GK, 1>(a, RL, bx, by, bm, x0, y0, m0, outs, nullptr, [&](long long q, bool ok, u64) -> unsigned {
-        const unsigned f = src_mask[q];
-        return ok ? f : 0u;
-    });
+    stage_mask_rows8(a, RL, bx, by, bm, x0, y0, m0, B, src_mask);
     __syncthreads();
     if (halo) {
         // what stencils centred on band nodes read: LSM_GHOST nodes along each axis and the 3^3 box
