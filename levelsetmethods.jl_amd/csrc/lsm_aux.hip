@@ -104,7 +104,9 @@ __device__ __forceinline__ double ghost_resolve(const GhostAllArgs& a, int I0, i
     }
 }
 
-template <int NDIM>
+// IT = the integer type of the ghost-node enumeration: unsigned (32-bit divisions; every grid whose ghost count fits —
+// 4.8 M at 512³) or long long.  With 64-bit divisions the index arithmetic, not the 120 MB the kernel moves, set its time.
+template <int NDIM, class IT>
 __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs a) {
     constexpr int G = LSM_GHOST;
     const int P0 = a.n[0] + 2 * G, P1 = NDIM > 1 ? a.n[1] + 2 * G : 1;
@@ -113,11 +115,13 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     const bool lastL = a.fill_last && a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.fill_last && a.kind[NDIM - 1][1] != LSM_BC_NONE;
     const int nlastg = (lastL ? G : 0) + (lastR ? G : 0);
     const int np = a.me - a.mb;   // planes (rows in 2-D) of the last dimension handled by regions B and C
-    long long nA, nB, nC;
+    const bool cL = true;
+    const int ncx = 2 * G;
+    IT nA, nB, nC;
     if (NDIM == 1) { nA = nlastg; nB = 0; nC = 0; }
-    else if (NDIM == 2) { nA = (long long)nlastg * P0; nB = 0; nC = (long long)np * 2 * G; }
-    else { nA = (long long)nlastg * P0 * P1; nB = (long long)np * 2 * G * P0; nC = (long long)np * a.n[1] * 2 * G; }
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    else if (NDIM == 2) { nA = (IT)nlastg * P0; nB = 0; nC = (IT)np * ncx; }
+    else { nA = (IT)nlastg * P0 * P1; nB = (IT)np * 2 * G * P0; nC = (IT)np * a.n[1] * ncx; }
+    const IT t = (IT)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nA + nB + nC) return;
     int I0 = 0, I1 = 0, I2 = 0;
     auto ghost_index = [&](int g, int n, bool left_on) {   // g-th ghost of a dim: left block first (if present)
@@ -127,19 +131,20 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     if (t < nA) {
         if (NDIM == 1) { I0 = ghost_index((int)t, a.n[0], lastL); }
         else if (NDIM == 2) { I0 = (int)(t % P0) - G; I1 = ghost_index((int)(t / P0), a.n[1], lastL); }
-        else { I0 = (int)(t % P0) - G; I1 = (int)((t / P0) % P1) - G; I2 = ghost_index((int)(t / ((long long)P0 * P1)), a.n[2], lastL); }
+        else { I0 = (int)(t % P0) - G; I1 = (int)((t / P0) % P1) - G; I2 = ghost_index((int)(t / ((IT)P0 * P1)), a.n[2], lastL); }
     } else if (t < nA + nB) {   // 3-D only
-        const long long u = t - nA;
+        const IT u = t - nA;
         I0 = (int)(u % P0) - G;
         const int g = (int)((u / P0) % (2 * G));
         I1 = g < G ? g - G : a.n[1] + (g - G);
-        I2 = a.mb + (int)(u / ((long long)P0 * 2 * G));
+        I2 = a.mb + (int)(u / ((IT)P0 * 2 * G));
     } else {
-        const long long u = t - nA - nB;
-        const int g = (int)(u % (2 * G));
-        I0 = g < G ? g - G : a.n[0] + (g - G);
-        if (NDIM == 2) { I1 = a.mb + (int)(u / (2 * G)); }
-        else { I1 = (int)((u / (2 * G)) % a.n[1]); I2 = a.mb + (int)(u / ((long long)2 * G * a.n[1])); }
+        const IT u = t - nA - nB;
+        const int g = (int)(u % (ncx > 0 ? ncx : 1));
+        I0 = ghost_index(g, a.n[0], cL);
+        const int nc1 = ncx > 0 ? ncx : 1;
+        if (NDIM == 2) { I1 = a.mb + (int)(u / nc1); }
+        else { I1 = (int)((u / nc1) % a.n[1]); I2 = a.mb + (int)(u / ((IT)nc1 * a.n[1])); }
     }
     const double val = ghost_resolve<NDIM - 1>(a, I0, I1, I2);
     st_val(a.v, a.origin + I0 + I1 * a.s1 + I2 * a.s2, a.f32, val);
@@ -151,14 +156,21 @@ void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
     const long long np = a.me - a.mb;
     long long total;
+    const int ncx = 2 * G;
     if (ndim == 1) total = nlastg;
-    else if (ndim == 2) total = nlastg * P0 + np * 2 * G;
-    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * 2 * G;
+    else if (ndim == 2) total = nlastg * P0 + np * ncx;
+    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * ncx;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (ndim == 1) hipLaunchKernelGGL(ghost_fill_all_kernel<1>, dim3(grid), dim3(256), 0, s, a);
-    else if (ndim == 2) hipLaunchKernelGGL(ghost_fill_all_kernel<2>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ghost_fill_all_kernel<3>, dim3(grid), dim3(256), 0, s, a);
+    const bool narrow = total < (1ll << 31) - 512;
+    if (ndim == 1) hipLaunchKernelGGL((ghost_fill_all_kernel<1, unsigned>), dim3(grid), dim3(256), 0, s, a);
+    else if (ndim == 2) {
+        if (narrow) hipLaunchKernelGGL((ghost_fill_all_kernel<2, unsigned>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ghost_fill_all_kernel<2, long long>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (narrow) hipLaunchKernelGGL((ghost_fill_all_kernel<3, unsigned>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ghost_fill_all_kernel<3, long long>), dim3(grid), dim3(256), 0, s, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
