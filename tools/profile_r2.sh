@@ -16,6 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $B > $OUT/pmc3.js
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- $B > $OUT/pmc4.json 2> $OUT/pmc4.err
 python3 tools/clock_probe.py 512 2.5 > $OUT/clock_probe.json 2> $OUT/clock_probe.err
 python3 tools/make_profile_summary.py $OUT $OUT/pmc_per_dispatch.json > $OUT/summary.log 2>&1
+mkdir -p profiles/r2 && cp $OUT/pmc_per_dispatch.json profiles/r2/pmc_per_dispatch.json   # the bench line below reads it (same build, same box)
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
 for c in 2 3 5; do python3 bench.py --config $c > $OUT/bench_config$c.json 2> $OUT/bench_config$c.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c3 -- python3 bench.py --config 3 --steps 4 > /dev/null 2> $OUT/trace_c3.err
