@@ -137,3 +137,44 @@ def test_local_group_driven_stage_by_stage_from_one_thread(lsm, periodic):
     assert np.array_equal(got, want), np.abs(got - want).max()
     for b in backs:
         b.close()
+
+
+@pytest.mark.parametrize("ndim,dtype,integ,world", [(2, "float64", "rk2", 3), (2, "float32", "rk3", 2), (3, "float32", "rk3", 3), (2, "float64", "fe", 4)])
+def test_local_groups_in_two_dimensions_and_float32(lsm, ndim, dtype, integ, world):
+    """The slab step of the library for the other storage type and dimension: 2-D slabs are rows, a "plane" is one padded
+    row; float32 planes travel as 4-byte elements.  Mixed terms (no WENO5) so that the 64x8 / 256x1 light kernels serve the
+    plane ranges too.  One thread per rank over an LSM_COMM_LOCAL group; bitwise against the single-device run."""
+    import threading
+    n = (40, 53) if ndim == 2 else (24, 20, 29)
+    grid = lsm.CartesianGrid((-1,) * ndim, (1,) * ndim, n)
+    dt = np.dtype(dtype)
+    ic = lsm.MeshField(lambda x: np.sqrt(sum((x[d] - 0.1 * d) ** 2 for d in range(ndim))) - 0.55, grid, dtype=dt)
+    I = {"rk3": lsm.RK3, "rk2": lsm.RK2, "fe": lsm.ForwardEuler}[integ]
+    bc = (lsm.ExtrapolationBC(2),) + (lsm.NeumannBC(),) * (ndim - 1)
+    mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.3), lsm.CurvatureTerm(-0.02), lsm.AdvectionTerm((0.5, -0.25, 0.4)[:ndim], lsm.Upwind())),
+                                           ic=ic, bc=bc, integrator=I(), **kw)
+    ref = mk()
+    lsm.integrate_(ref, 0.02)
+    want = ref.current_state().values()
+    assert want.dtype == dt
+    g = lsm.LocalGroup(world)
+    got, errs = [None] * world, []
+
+    def run(r):
+        try:
+            eq = mk(comm=g.rank(r))
+            lsm.integrate_(eq, 0.02)
+            got[r] = eq.current_state().values()
+        except BaseException:   # noqa: BLE001 - reported by the main thread
+            import traceback
+            errs.append((r, traceback.format_exc()))
+            g._barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    full = np.concatenate(got, axis=ndim - 1)
+    assert np.array_equal(full, want), np.abs(full.astype(np.float64) - want).max()
