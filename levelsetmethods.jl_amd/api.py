@@ -17,10 +17,25 @@ from . import _lib as L
 
 
 class CartesianGrid:
-    """CartesianGrid(lc, hc, n) — src/meshes.jl:1-5,34-42."""
+    """CartesianGrid(lc, hc, n) — src/meshes.jl:1-5,34-42 — or CartesianGrid(lc, hc, meshsize=h) — src/meshes.jl:69-83:
+    the cell count of each dimension is rounded UP, so the realised spacing is never coarser than `meshsize`."""
 
-    def __init__(self, lc, hc, n):
-        lc, hc, n = tuple(lc), tuple(hc), tuple(n)
+    def __init__(self, lc, hc, n=None, *, meshsize=None):
+        lc, hc = tuple(lc), tuple(hc)
+        if (n is None) == (meshsize is None):
+            raise ValueError("pass either the node counts n or meshsize")
+        if n is None:
+            if len(lc) != len(hc):
+                raise ValueError("lc and hc must have the same length")
+            h = (meshsize,) * len(lc) if isinstance(meshsize, (int, float)) else tuple(meshsize)
+            if len(h) != len(lc):
+                raise ValueError("meshsize must be a scalar or have one entry per dimension")
+            if not all(x > 0 for x in h):
+                raise ValueError("meshsize must be positive in every dimension")
+            if not all(b > a for a, b in zip(lc, hc)):
+                raise ValueError("hc must be strictly greater than lc in every dimension")
+            n = tuple(int(math.ceil((b - a) / x)) + 1 for a, b, x in zip(lc, hc, h))
+        n = tuple(n)
         if not (len(lc) == len(hc) == len(n)):
             raise ValueError("all arguments must have the same length")
         self.lc = tuple(float(x) for x in lc)

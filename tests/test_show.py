@@ -41,6 +41,16 @@ def test_grid_and_bc_show():
     assert repr(lsm.ExtrapolationBC(4)) == "Degree 4 extrapolation" and repr(lsm.SymmetryBC()) == "Symmetry"
 
 
+def test_grid_from_meshsize_doctest():
+    """src/meshes.jl:57-67: CartesianGrid((0, 0), (1, 1); meshsize = 0.3) has 5 × 5 nodes, h = 0.25 (cell count rounded up)."""
+    g = lsm.CartesianGrid((0, 0), (1, 1), meshsize=0.3)
+    assert lsm.show(g) == "CartesianGrid in ℝ²\n  ├─ domain:  [0.0, 1.0] × [0.0, 1.0]\n  ├─ nodes:   5 × 5\n  └─ spacing: h = (0.25, 0.25)"
+    assert lsm.CartesianGrid((0, 0), (1, 2), meshsize=(0.5, 0.3)).n == (3, 8)
+    for bad in (dict(meshsize=0.0), dict(meshsize=(0.1,)), dict(n=(3, 3), meshsize=0.1), dict()):
+        with pytest.raises(ValueError):
+            lsm.CartesianGrid((0, 0), (1, 1), **bad)
+
+
 def test_meshfield_show():
     grid = lsm.CartesianGrid((-1, -1), (1, 1), (5, 5))
     s = lsm.show(lsm.MeshField(lambda x: x[0] ** 2 + x[1] ** 2 - 0.5 ** 2, grid))           # :36-46
@@ -48,6 +58,8 @@ def test_meshfield_show():
     assert "├─ domain:  [-1.0, 1.0] × [-1.0, 1.0]" in s and "├─ nodes:   5 × 5" in s
     assert "├─ spacing: h = (0.5, 0.5)" in s and "bc:" not in s
     assert "├─ valtype: Float64" in s and "└─ values:  min = -0.25,  max = 1.75" in s
+    assert s == ("MeshField on CartesianGrid in ℝ²\n  ├─ domain:  [-1.0, 1.0] × [-1.0, 1.0]\n  ├─ nodes:   5 × 5\n  ├─ spacing: h = (0.5, 0.5)\n"
+                 "  ├─ valtype: Float64\n  └─ values:  min = -0.25,  max = 1.75")            # the doctest of src/meshfield.jl:192-206, whole
     s = lsm.show(lsm.MeshField(lambda x: (x[0], x[1]), grid))                              # :56-63
     assert "└─ valtype: SVector{2, Float64}" in s and "values" not in s and "bc:" not in s
 
