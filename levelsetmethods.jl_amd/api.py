@@ -984,7 +984,9 @@ class LevelSetEquation:
         # dense slabs on the HIP backend: the plane exchange and the Δt all-reduce run inside the library
         # (lsm_comm_attach_rccl / _local); torch.distributed only carries the RCCL unique id to the ranks
         self.lib_comm = False
-        if comm is not None and self.world > 1 and not isinstance(ic, NarrowBandMeshField) and hasattr(self.backend, "comm_attach_rccl"):
+        import os as _os
+        if (comm is not None and self.world > 1 and not isinstance(ic, NarrowBandMeshField) and hasattr(self.backend, "comm_attach_rccl")
+                and _os.environ.get("LSM_LIB_COMM", "1") != "0"):
             self._attach_library_comm()
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
         self.band = isinstance(ic, NarrowBandMeshField)
@@ -1088,9 +1090,30 @@ class LevelSetEquation:
             g.exchange(self.rank, None)            # nobody runs ahead of the attachment
         else:
             import torch.distributed as dist
-            box = [b.comm_unique_id() if self.rank == 0 else None]
+            # a rank whose library cannot open RCCL (or whose communicator does not come up) must not leave the others
+            # exchanging with nobody: the ranks agree, and the group as a whole falls back to the stage-by-stage exchange
+            # over torch.distributed (same planes, same order, same results — DESIGN.md §6) with a warning
+            err = None
+            try:
+                box = [b.comm_unique_id() if self.rank == 0 else None]
+            except L.LsmError as e:
+                box, err = [None], e
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.comm, 0), group=self.comm)
-            b.comm_attach_rccl(box[0], self.rank, self.world)
+            if box[0] is not None:
+                try:
+                    b.comm_attach_rccl(box[0], self.rank, self.world)
+                except L.LsmError as e:
+                    err = e
+            else:
+                err = err or L.LsmError("rank 0 could not create an RCCL unique id")
+            oks = self._all_gather_object(err is None)
+            if not all(oks):
+                if err is None:
+                    b.comm_detach()
+                import warnings
+                warnings.warn(f"libhiplsm's RCCL communicator is unavailable ({err or 'on another rank'}); "
+                              "exchanging ghost planes through torch.distributed instead")
+                return
         self.lib_comm = True
 
     def _all_gather_object(self, v):

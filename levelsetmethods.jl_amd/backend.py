@@ -167,6 +167,9 @@ class HipBackend:
             msgs = [b.lib.lsm_last_error(b.h) for b in backends]
             raise L.LsmError(f"lsm_comm_attach_local failed ({code}): " + "; ".join(m.decode() for m in msgs if m))
 
+    def comm_detach(self):
+        L.check(self.h, self.lib.lsm_comm_detach(self.h), "lsm_comm_detach")
+
     def comm_info(self):
         r, w, t = C.c_int(), C.c_int(), C.c_int()
         L.check(self.h, self.lib.lsm_comm_info(self.h, C.byref(r), C.byref(w), C.byref(t)), "lsm_comm_info")

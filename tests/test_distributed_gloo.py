@@ -157,3 +157,59 @@ def test_cfl_nan_on_one_rank_raises_everywhere():
     for p in procs:
         p.join(timeout=60)
     assert all("invalid time-step based on CFL condition" in got[r] for r in (0, 1)), got
+
+
+def _fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        import lsm_amd as lsm
+        from lsm_amd import _lib as L
+        from _oracle_backend import OracleBackend
+
+        class NoRccl(OracleBackend):
+            """a backend that offers the library communicator, but whose rank 1 cannot bring it up"""
+            detached = False
+
+            def comm_unique_id(self):
+                return b"\0" * L.COMM_ID_BYTES
+
+            def comm_attach_rccl(self, uid, r, w):
+                if r == 1:
+                    raise L.LsmError("librccl.so.1: cannot open shared object file")
+
+            def comm_detach(self):
+                self.detached = True
+
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            eq, grid, ic = _build(lsm, "3d_neumann_rk3", comm=dist.group.WORLD, backend_factory=lambda g, b, s: NoRccl(g, b, s))
+        lsm.integrate_(eq, 0.02)
+        full = eq.gather_state()
+        q.put((rank, eq.lib_comm, eq.backend.detached, [str(x.message) for x in w], full if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_to_fall_back_when_one_cannot_attach_the_library_communicator(orc):
+    """lsm_comm_attach_rccl failing on ONE rank: every rank warns, the ranks that did attach detach again, and the group
+    runs the stage-by-stage exchange over torch.distributed — with the same bits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not got[0][0] and not got[1][0]
+    assert got[0][1] and not got[1][1]                       # rank 0 had attached and let go again
+    assert all(any("torch.distributed instead" in m for m in got[r][2]) for r in (0, 1)), got
+    want, _, _ = _dense_oracle_run(orc, "3d_neumann_rk3")
+    assert np.array_equal(got[0][3], want)
