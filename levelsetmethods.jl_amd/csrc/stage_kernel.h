@@ -951,6 +951,10 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
         static const int mc_env = getenv("LSM_STAGE_MC") ? atoi(getenv("LSM_STAGE_MC")) : 0;
         if (mc_env > 0) mc = mc_env;
     }
+    if (a.mc <= 0 && NDIM == 2) {   // A/B switch: rows per march chunk in 2-D
+        static const int mc_env = getenv("LSM_STAGE_MC2") ? atoi(getenv("LSM_STAGE_MC2")) : 0;
+        if (mc_env > 0) mc = mc_env;
+    }
     // small grids: a workgroup marching 64 planes leaves most of the 256 CUs idle (48^3 = 12 workgroups, a serial walk
     // of 48 planes each).  Shorter chunks — down to 8 planes — until there are ~8 workgroups per CU; each chunk pays its
     // 2G+1 planes of prologue, which is why large grids keep the long march.

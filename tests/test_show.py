@@ -49,6 +49,17 @@ def test_grid_from_meshsize_doctest():
     for bad in (dict(meshsize=0.0), dict(meshsize=(0.1,)), dict(n=(3, 3), meshsize=0.1), dict()):
         with pytest.raises(ValueError):
             lsm.CartesianGrid((0, 0), (1, 1), **bad)
+    # test/test-meshes.jl:15-41, "meshsize constructor"
+    g = lsm.CartesianGrid((-1, -1), (1, 1), meshsize=0.5)                 # exact divisor: the spacing hits the request
+    assert g.n == (5, 5) and np.allclose(g.meshsize(), (0.5, 0.5))
+    assert tuple(g.getnode((0, 0))) == (-1.0, -1.0) and tuple(g.getnode((4, 4))) == (1.0, 1.0)   # corners unchanged
+    g = lsm.CartesianGrid((0, 0), (1, 1), meshsize=0.3)                   # ceil rule: never coarser than requested
+    assert g.n == (5, 5) and all(h <= 0.3 for h in g.meshsize()) and tuple(g.getnode((4, 4))) == (1.0, 1.0)
+    g = lsm.CartesianGrid((0, 0), (2, 1), meshsize=(0.4, 0.3))            # per dimension
+    assert g.n == (6, 5) and all(h <= m for h, m in zip(g.meshsize(), (0.4, 0.3)))
+    for lc, hc, ms in (((0, 0), (1, 1), -0.1), ((0, 0), (1, 1), (0.1,)), ((1, 1), (0, 0), 0.1)):
+        with pytest.raises(ValueError):
+            lsm.CartesianGrid(lc, hc, meshsize=ms)
 
 
 def test_meshfield_show():
