@@ -627,6 +627,14 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #ifndef LSM_ZROT
 #define LSM_ZROT 1
 #endif
+// A/B switches: the ring (and the unrolled plane loop) for every 3-D FAST kernel, not only the WENO5 ones; and PFX extra
+// planes of ψ in flight (ring of 2G+1+PFX entries: the newest PFX+1 are loads that have not been waited for yet)
+#ifndef LSM_ZROT_ALL
+#define LSM_ZROT_ALL 0
+#endif
+#ifndef LSM_PFX
+#define LSM_PFX 0
+#endif
 // build switches of the A/B experiments recorded in DESIGN.md §3.1 (tools/variants.sh): occupancy hint, and a
 // timing-only build without the per-plane barrier (its results are wrong)
 #ifdef LSM_EXP_NOBARRIER
@@ -645,7 +653,8 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
     constexpr int NSLOT = MARCH ? 2 * LEAD + 2 : 1;
     // the march line as a register ring with the plane loop unrolled 2G+1-fold: the WENO5 kernels in 3-D (7 moves a plane)
-    constexpr bool ZROT = LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2;
+    constexpr bool ZROT = LSM_ZROT && !LSM_STRICT && NDIM == 3 && (ADV == 2 || LSM_ZROT_ALL);
+    constexpr int PFX = (ZROT && ADV != 2) ? LSM_PFX : 0;
     constexpr int W = TX + 2 * G;
     constexpr int H = HAS_Y ? TY + 2 * G : 1;
     constexpr int HW = H * W;
@@ -758,9 +767,9 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
         // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
         node_store<ST, PLAIN>(a, io, active && (NOMASK || !a.mask || ldg_u8(uniform_ptr(a.mask + corner), ocold >> 3, (int)0x80000000u) != 0), r1, r2);
     } else {
-        double zl[2 * G + 1];
+        double zl[2 * G + 1 + PFX];
 #pragma unroll
-        for (int j = 0; j <= 2 * G; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
+        for (int j = 0; j <= 2 * G + PFX; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
 #pragma unroll
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
             const int slot = pl + LEAD;
@@ -780,7 +789,7 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
         long long po = corner + (long long)m0 * sm;     // plane m of the pointwise operands (ϕⁿ, outputs, mask, side arrays)
         unsigned mk_next = 0;
         if constexpr (!NOMASK) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
-        const ST* Pnx = plane(m0 + G);                  // plane m+G of ψ, advanced (and clamped) before each use
+        const ST* Pnx = plane(m0 + G + PFX);            // plane m+G+PFX of ψ, advanced (and clamped) before each use
         const ST* Pn = plane(m0 + LEAD);
         const int plast = nm + G - 1;
         const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
@@ -800,11 +809,11 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
 #endif
         // One plane of the march.  ROT > 0: the register line is a ring (see NodeView) and the loop below is unrolled
         // ROT-fold with the rotation Rc a compile-time constant of each copy.
-        constexpr int ROT = ZROT ? 2 * G + 1 : 0, RM = ROT > 0 ? ROT : 1;
+        constexpr int ROT = ZROT ? 2 * G + 1 + PFX : 0, RM = ROT > 0 ? ROT : 1;
         auto plane_iter = [&](auto Rc, int m) {
             constexpr int R = decltype(Rc)::value;
             // issue the next plane's loads early; they land in LDS after this plane's arithmetic
-            Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
+            Pnx = uniform_ptr(m + 1 + G + PFX <= plast ? Pnx + sm : Pnx);
             Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
             const double nxt = ldg(Pnx, ocol);
             double hn[HPT > 0 ? HPT : 1];
@@ -871,10 +880,11 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
                 step(std::integral_constant<int, 0>{});
                 step(std::integral_constant<int, 1>{});
                 step(std::integral_constant<int, 2>{});
-                step(std::integral_constant<int, 3>{});
-                step(std::integral_constant<int, 4>{});
+                if constexpr (ROT > 3) step(std::integral_constant<int, 3>{});
+                if constexpr (ROT > 4) step(std::integral_constant<int, 4>{});
                 if constexpr (ROT > 5) step(std::integral_constant<int, 5>{});
                 if constexpr (ROT > 6) step(std::integral_constant<int, 6>{});
+                if constexpr (ROT > 7) step(std::integral_constant<int, 7>{});
             }
         } else {
             for (int m = m0; m < m1; ++m) plane_iter(std::integral_constant<int, 0>{}, m);
