@@ -13,7 +13,8 @@ from .api import (AdvectionTerm, BoundaryCondition, CartesianGrid, CurvatureTerm
                   ROCNarrowBandMeshField, SeparableCoefficient,
                   SymmetryBC, TimeIntegrator, Upwind, WENO5, current_state, current_time, extend_along_normals_, integrate_, reinitialize_,
                   perimeter, volume, InterpolatedField, NewtonSDF, hausdorff_distance, SideField, curvature, curvature_field, gradient, gradient_field, normal, normal_field,
-                  vortex_deformation, show, LocalGroup)
+                  vortex_deformation, show, LocalGroup, nodeindices, cellindices, getnode, getcell, active_nodeindices, active_cellindices,
+                  update_band_)
 
 __all__ = [
     "AdvectionTerm", "BoundaryCondition", "CartesianGrid", "CurvatureTerm", "EikonalReinitializationTerm",
@@ -23,4 +24,5 @@ __all__ = [
     "SeparableCoefficient", "SymmetryBC", "TimeIntegrator", "Upwind", "WENO5", "current_state", "current_time",
     "integrate_", "vortex_deformation", "volume", "perimeter", "extend_along_normals_", "reinitialize_", "LsmError", "build",
     "InterpolatedField", "NewtonSDF", "hausdorff_distance", "SideField", "curvature", "curvature_field", "gradient", "gradient_field", "normal", "normal_field", "show", "LocalGroup",
+    "nodeindices", "cellindices", "getnode", "getcell", "active_nodeindices", "active_cellindices", "update_band_",
 ]

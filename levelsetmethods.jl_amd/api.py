@@ -66,6 +66,36 @@ class CartesianGrid:
         h = self.meshsize()
         return [self.lc[d] + np.arange(self.n[d], dtype=np.float64) * h[d] for d in range(self.ndim)]
 
+    def __len__(self):
+        return int(np.prod(self.n))
+
+    def nodeindices(self):
+        """All node indices (0-based tuples), first index fastest like CartesianIndices — src/meshes.jl:138."""
+        return _cartesian_indices(self.n)
+
+    def cellindices(self):
+        """All cell indices: cell I is bounded by nodes I and I+1, n[d]-1 cells per dimension — src/meshes.jl:147."""
+        return _cartesian_indices(tuple(k - 1 for k in self.n))
+
+    def compute_index(self, x):
+        """Index of the cell containing x, clamped to the grid — src/meshes.jl:155-169."""
+        h = self.meshsize()
+        return tuple(min(max(int(math.floor((x[d] - self.lc[d]) / h[d])), 0), self.n[d] - 2) for d in range(self.ndim))
+
+    def getcell(self, I):
+        """(lc, hc) of cell I, lc = node I, hc = lc + h — src/meshes.jl:183-197."""
+        I = tuple(I)
+        if not all(0 <= I[d] < self.n[d] - 1 for d in range(self.ndim)):
+            raise ValueError(f"{I} is not a valid cell index for this grid")
+        h = self.meshsize()
+        lc = tuple(self.lc[d] + float(I[d]) * h[d] for d in range(self.ndim))
+        return lc, tuple(lc[d] + h[d] for d in range(self.ndim))
+
+    def grid1d(self, dim=None):
+        """Node coordinates along `dim` as LinRange(lc, hc, n) does — src/meshes.jl:90-91."""
+        ax = [np.linspace(self.lc[d], self.hc[d], self.n[d]) for d in range(self.ndim)]
+        return tuple(ax) if dim is None else ax[dim]
+
     def _c(self):
         g = L.LsmGrid()
         g.ndim = self.ndim
@@ -80,6 +110,44 @@ class CartesianGrid:
         return "\n".join([f"CartesianGrid in ℝ{_superscript(self.ndim)}"] + _grid_fields(self))
 
     __repr__ = _show
+
+
+def _cartesian_indices(shape):
+    """index tuples of an array of `shape`, first index fastest (Julia's CartesianIndices order)"""
+    import itertools
+    return [tuple(reversed(t)) for t in itertools.product(*[range(k) for k in reversed(shape)])]
+
+
+def nodeindices(g):
+    return g.nodeindices()
+
+
+def cellindices(g):
+    return g.cellindices()
+
+
+def getnode(g, *I):
+    return g.getnode(I[0] if len(I) == 1 and not isinstance(I[0], int) else I)
+
+
+def getcell(g, *I):
+    return g.getcell(I[0] if len(I) == 1 and not isinstance(I[0], int) else I)
+
+
+def active_nodeindices(phi):
+    """active_nodeindices(ϕ) — src/meshfield.jl:134 (dense: every node) / :462 (band: the stored nodes)."""
+    return phi.active_nodeindices() if hasattr(phi, "active_nodeindices") else phi.mesh.nodeindices()
+
+
+def active_cellindices(phi):
+    return phi.active_cellindices() if hasattr(phi, "active_cellindices") else phi.mesh.cellindices()
+
+
+def update_band_(phi):
+    """update_band!(ϕ) — src/meshfield.jl:553 (dense: no-op) / :555-588 (band)."""
+    if isinstance(phi, LevelSetEquation):
+        return phi.update_band()
+    return phi.rebuild() if hasattr(phi, "rebuild") else phi
 
 
 # ----------------------------------------------------------------------------- boundaryconditions.jl

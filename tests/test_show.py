@@ -41,6 +41,29 @@ def test_grid_and_bc_show():
     assert repr(lsm.ExtrapolationBC(4)) == "Degree 4 extrapolation" and repr(lsm.SymmetryBC()) == "Symmetry"
 
 
+def test_grid_basic_ops():
+    """test/test-meshes.jl:5-13, and the index helpers of the export list (src/LevelSetMethods.jl:45-55) in 0-based form."""
+    nx, ny = 100, 50
+    a, b = (-1, 0), (1, 3)
+    grid = lsm.CartesianGrid(a, b, (nx, ny))
+    assert grid.size() == (nx, ny) and len(lsm.nodeindices(grid)) == nx * ny == len(grid)
+    assert lsm.getnode(grid, 0, 0) == (-1.0, 0.0) and lsm.getnode(grid, nx - 1, ny - 1) == (1.0, 3.0)
+    idx = lsm.nodeindices(lsm.CartesianGrid((0, 0), (1, 1), (3, 2)))
+    assert idx == [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (2, 1)]               # first index fastest, as CartesianIndices
+    cells = lsm.cellindices(grid)
+    assert len(cells) == (nx - 1) * (ny - 1) and cells[-1] == (nx - 2, ny - 2)    # src/meshes.jl:147
+    lo, hi = lsm.getcell(grid, nx - 2, ny - 2)                                   # :183-197: node I to node I+1
+    assert np.allclose(hi, (1.0, 3.0)) and np.allclose(np.subtract(hi, lo), grid.meshsize())
+    with pytest.raises(ValueError):
+        lsm.getcell(grid, nx - 1, 0)
+    with pytest.raises(ValueError):
+        lsm.getnode(grid, nx, 0)
+    assert grid.compute_index((-5.0, 0.01)) == (0, 0) and grid.compute_index((0.999, 9.0)) == (nx - 2, ny - 2)   # :155-169, clamped
+    assert np.array_equal(grid.grid1d(0), np.linspace(-1, 1, nx)) and len(grid.grid1d()) == 2
+    phi = lsm.MeshField(lambda x: x[0] + x[1], grid)
+    assert len(lsm.active_nodeindices(phi)) == nx * ny and lsm.update_band_(phi) is phi   # dense: all nodes, no-op (src/meshfield.jl:134,553)
+
+
 def test_grid_from_meshsize_doctest():
     """src/meshes.jl:57-67: CartesianGrid((0, 0), (1, 1); meshsize = 0.3) has 5 × 5 nodes, h = 0.25 (cell count rounded up)."""
     g = lsm.CartesianGrid((0, 0), (1, 1), meshsize=0.3)
