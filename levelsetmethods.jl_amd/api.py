@@ -632,6 +632,20 @@ class ROCNarrowBandMeshField(ROCMeshField):
             c._hlist, c._hcount = self._hlist.clone(), self._hcount.clone()
         return c
 
+    def copy_(self, src):
+        """copy!(dest, src) (src/meshfield.jl:282-292): the values AND the active set of `src` (the Dict copy! syncs keys);
+        dest keeps its own mesh, boundary conditions and nlayers."""
+        if not isinstance(src, ROCNarrowBandMeshField):
+            raise ValueError("copy! into a narrow-band field takes a narrow-band field")
+        self.backend.copy_(self.buf, src.buf)
+        self.mask.copy_(src.mask)
+        self.halo.copy_(src.halo)
+        self.tiles.copy_(src.tiles)
+        if src._hlist is not None:
+            self._hlist, self._hcount = src._hlist.clone(), src._hcount.clone()
+        self.ghosts_dirty = True
+        return self
+
     def __getitem__(self, I):
         """ϕ[I] (src/meshfield.jl:441-445,475-511): stored value on the band, affine extrapolant from the
         nearest band node elsewhere in the grid, boundary conditions outside the grid.  Slow scalar path."""
