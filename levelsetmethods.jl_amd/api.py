@@ -83,13 +83,13 @@ class CartesianGrid:
         return tuple(min(max(int(math.floor((x[d] - self.lc[d]) / h[d])), 0), self.n[d] - 2) for d in range(self.ndim))
 
     def getcell(self, I):
-        """(lc, hc) of cell I, lc = node I, hc = lc + h — src/meshes.jl:183-197."""
+        """CartesianCell of cell I: lc = node I, hc = lc + h — src/meshes.jl:183-197 (unpacks as `lc, hc = cell`)."""
         I = tuple(I)
         if not all(0 <= I[d] < self.n[d] - 1 for d in range(self.ndim)):
             raise ValueError(f"{I} is not a valid cell index for this grid")
         h = self.meshsize()
         lc = tuple(self.lc[d] + float(I[d]) * h[d] for d in range(self.ndim))
-        return lc, tuple(lc[d] + h[d] for d in range(self.ndim))
+        return CartesianCell(lc, tuple(lc[d] + h[d] for d in range(self.ndim)))
 
     def grid1d(self, dim=None):
         """Node coordinates along `dim` as LinRange(lc, hc, n) does — src/meshes.jl:90-91."""
@@ -108,6 +108,23 @@ class CartesianGrid:
     def _show(self):
         """src/meshes.jl:226-242."""
         return "\n".join([f"CartesianGrid in ℝ{_superscript(self.ndim)}"] + _grid_fields(self))
+
+    __repr__ = _show
+
+
+class CartesianCell:
+    """A cell of a CartesianGrid: the box between the nodes at `lc` and `hc` — src/meshes.jl:171-181."""
+
+    def __init__(self, lc, hc):
+        self.lc, self.hc = tuple(lc), tuple(hc)
+
+    def __iter__(self):
+        return iter((self.lc, self.hc))
+
+    def _show(self):
+        """src/meshes.jl:243-250"""
+        f = lambda c: "(" + ", ".join(_sig4(x) for x in c) + ")"
+        return f"CartesianCell in ℝ{_superscript(len(self.lc))}\n  ├─ lower corner: {f(self.lc)}\n  └─ upper corner: {f(self.hc)}"
 
     __repr__ = _show
 
@@ -357,6 +374,27 @@ class MeshField:
         m = MeshField(self.vals.copy(order="K"), self.mesh, dtype=self.vals.dtype)
         m.bcs = self.bcs
         return m
+
+    def copy_(self, src):
+        """copy!(dest, src) — src/meshfield.jl:282-292: the values of `src`; dest keeps its mesh and boundary conditions."""
+        v = src.values() if hasattr(src, "values") else np.asarray(src)
+        if v.shape != self.vals.shape:
+            raise ValueError("copy!: the fields have different sizes")
+        self.vals[...] = v
+        return self
+
+    def with_bc(self, bc):
+        """_add_boundary_conditions(ϕ, bc) — src/meshfield.jl:104-113: a field over the SAME values array with boundary conditions."""
+        m = MeshField.__new__(MeshField)
+        m.vals, m.mesh, m.bcs = self.vals, self.mesh, _normalize_bc(bc, self.mesh.ndim)
+        return m
+
+    @property
+    def ndim(self):
+        return self.mesh.ndim
+
+    def meshsize(self, dim=None):
+        return self.mesh.meshsize(dim)
 
     def __getitem__(self, I):
         """ϕ[I] with 0-based I; out-of-grid indices go through the boundary conditions
@@ -1630,13 +1668,13 @@ def normal(phi, I):
 
 
 class InterpolatedField:
-    """InterpolatedField(ϕ, order) (src/interpolation.jl:117-151): the piecewise polynomial interpolant of a dense device
-    field, evaluated on the device.  `itp(x)` for one point or an (npts, ndim) array; `gradient`, `hessian`,
+    """InterpolatedField(ϕ, order) (src/interpolation.jl:117-151): the piecewise polynomial interpolant of a device field
+    (dense, or a narrow band near its active nodes), evaluated on the device.  `itp(x)` for one point or an (npts, ndim) array; `gradient`, `hessian`,
     `value_and_gradient`, `value_gradient_hessian` as in the reference (:228-260)."""
 
     def __init__(self, phi, order=3):
-        if not isinstance(phi, ROCMeshField) or isinstance(phi, ROCNarrowBandMeshField):
-            raise ValueError("InterpolatedField wraps a dense device field (ROCMeshField)")
+        if not isinstance(phi, ROCMeshField):
+            raise ValueError("InterpolatedField wraps a device field (ROCMeshField / ROCNarrowBandMeshField)")
         if not 1 <= int(order) <= 5:
             raise ValueError("interpolation order must be in 1..5")
         self.phi, self.order = phi, int(order)
@@ -1647,6 +1685,10 @@ class InterpolatedField:
         pts = x[None, :] if single else x
         if pts.ndim != 2 or pts.shape[1] != self.phi.mesh.ndim:
             raise ValueError(f"points must have {self.phi.mesh.ndim} coordinates")
+        if isinstance(self.phi, ROCNarrowBandMeshField):
+            # a band field interpolates wherever the patch's stencil stays on band or halo nodes (test/test-narrow-band.jl:91-103):
+            # the halo holds the extrapolated values, exactly what the reference's nb[I] returns there
+            self.phi.prepare(self.phi.buf)
         v, g, H = self.phi.backend.interpolate(self.phi.buf, self.order, pts, grad, hess)
         self.phi.ghosts_dirty = False
         if single:

@@ -51,6 +51,16 @@ def test_derivatives_on_the_band_match_the_full_grid(lsm):
     assert lsm.curvature(probe, best) == pytest.approx(lsm.curvature(full, best), rel=1e-10)    # D2⁰ and the mixed D2
 
 
+def test_interpolation_on_a_band_matches_the_full_grid(lsm):
+    """test/test-narrow-band.jl:91-103: a wide band, the interpolation stencils of the query points stay in it."""
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (50, 50))
+    phi = lsm.MeshField(lambda x: x[0] ** 2 + 2 * x[1] ** 2 - 0.5, grid)
+    full = lsm.InterpolatedField(lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=phi, bc=lsm.ExtrapolationBC(2)).current_state(), 3)
+    nb = lsm.InterpolatedField(_band_eq(lsm, phi, 8, lsm.ExtrapolationBC(2)).current_state(), 3)
+    for x in ((0.5, 0.0), (0.0, 0.5), (0.3, 0.3)):
+        assert nb(np.array(x)) == pytest.approx(full(np.array(x)), rel=1e-12, abs=1e-14)
+
+
 def test_copy_into_a_band_takes_values_and_active_set(lsm):
     """test/test-narrow-band.jl:178-190"""
     grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (30, 30))

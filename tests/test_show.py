@@ -64,6 +64,32 @@ def test_grid_basic_ops():
     assert len(lsm.active_nodeindices(phi)) == nx * ny and lsm.update_band_(phi) is phi   # dense: all nodes, no-op (src/meshfield.jl:134,553)
 
 
+def test_cartesian_cell_show():
+    """test/test-show.jl:17-23"""
+    s = lsm.show(lsm.getcell(lsm.CartesianGrid((0, 0), (1, 1), (10, 4)), 0, 0))
+    assert s == "CartesianCell in ℝ²\n  ├─ lower corner: (0.0, 0.0)\n  └─ upper corner: (0.1111, 0.3333)"
+
+
+def test_meshfield_construction_bc_and_copy():
+    """test/test-meshfield.jl:7-42"""
+    grid = lsm.CartesianGrid((-1.0, -1.0), (1.0, 1.0), (10, 5))
+    f = lambda x: x[0] ** 2 + x[1] ** 2 - 0.5
+    phi = lsm.MeshField(f, grid)
+    assert phi.mesh is grid and isinstance(phi, lsm.MeshField) and not phi.has_boundary_conditions()
+    assert phi.ndim == 2 and phi.values().shape == (10, 5)
+    assert phi[2, 1] == pytest.approx(f(lsm.getnode(grid, 2, 1))) and phi.meshsize() == grid.meshsize()
+    g1 = lsm.CartesianGrid((0.0,), (1.0,), (5,))
+    p1 = lsm.MeshField(lambda x: x[0], g1)
+    p1bc = p1.with_bc(((lsm.NeumannBC(), lsm.NeumannBC()),))
+    assert not p1.has_boundary_conditions() and p1bc.has_boundary_conditions()
+    assert p1bc.values() is p1.values()                                  # the underlying data is aliased
+    assert p1bc[-2] == p1[0] and p1bc[6] == p1[4]
+    g2 = lsm.CartesianGrid((0.0, 0.0), (1.0, 1.0), (5, 5))
+    a, b = lsm.MeshField(lambda x: x[0] + x[1], g2), lsm.MeshField(lambda x: 0.0 * x[0], g2)
+    b.copy_(a)
+    assert np.array_equal(b.values(), a.values()) and b.values() is not a.values()   # copied, not aliased
+
+
 def test_grid_from_meshsize_doctest():
     """src/meshes.jl:57-67: CartesianGrid((0, 0), (1, 1); meshsize = 0.3) has 5 × 5 nodes, h = 0.25 (cell count rounded up)."""
     g = lsm.CartesianGrid((0, 0), (1, 1), meshsize=0.3)
