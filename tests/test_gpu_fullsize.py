@@ -47,6 +47,35 @@ def test_512_cubed_linear_field_advection_is_exact(lsm):
     del out, want
 
 
+def test_1024_cubed_whole_grid_on_one_device(lsm):
+    """BASELINE config 4's grid (1024³, 8 GiB per array: byte offsets beyond 2³², 1.1·10⁹ padded elements) as ONE slab:
+    the headline equation's CFL is the analytic one, and a linear field advected by a constant velocity through the fused
+    WENO5 + RK3 step stays linear — checked plane range by plane range on the host."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 48 * 2 ** 30:
+        pytest.skip("needs 48 GiB of free device memory")
+    n = 1024
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    a = (0.7, -0.4, 0.25)
+    u = (0.3, 0.9, -0.6)
+    ic = lsm.LazyMeshField(lambda x: a[0] * x[0] + a[1] * x[1] + a[2] * x[2] - 0.2, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(u, lsm.WENO5()),), ic=ic, bc=lsm.LinearExtrapolationBC(), integrator=lsm.RK3())
+    del ic
+    dt = 0.5 * eq.compute_cfl(0.0)
+    h = grid.meshsize(0)
+    assert dt == 0.5 * (1 / (abs(u[0]) / h + abs(u[1]) / h + abs(u[2]) / h))
+    eq._advance(0.0, dt)
+    out = eq.current_state().values()
+    x = grid.coords()
+    shift = dt * (u[0] * a[0] + u[1] * a[1] + u[2] * a[2])
+    worst = 0.0
+    for k0 in range(0, n, 64):
+        want = (a[0] * x[0])[:, None, None] + (a[1] * x[1])[None, :, None] + (a[2] * x[2][k0:k0 + 64])[None, None, :] - 0.2 - shift
+        worst = max(worst, float(np.abs(out[:, :, k0:k0 + 64] - want).max()))
+    assert worst <= 2e-13
+    del out
+
+
 def test_512_cubed_sdf_plane_is_eikonal_fixed_point_and_constant_field_is_inert(lsm):
     n = 512
     grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
