@@ -199,7 +199,10 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
  * contents are mutated in place between steps. */
 int lsm_cfl_cache(LsmHandle* h, int enable);
 
-/* ---- _advance! per integrator.  phi's ghosts are (re)filled on entry and valid on return.
+/* ---- _advance! per integrator.  phi's ghost layers are (re)filled on entry; on return of a whole-grid handle they are
+ *      STALE (the interior is the new state): every entry point that reads ghosts fills them itself, and a caller of
+ *      lsm_stage calls lsm_fill_ghosts first — one fill per step saved when steps follow each other.  (A slab returns
+ *      with its ghosts exchanged and valid, and expects them so on entry.)
  *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63).
  *      On a slab handle with a communicator attached these run the slab's step (see "multi-GPU" below). */
 int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1,

@@ -1294,6 +1294,8 @@ class LevelSetEquation:
                 if self._hook_error is not None:
                     raise self._hook_error
                 raise
+            if not self.lib_comm:
+                self.state.ghosts_dirty = True      # a whole-grid lsm_advance_* leaves ϕ's ghost layers stale (include/lsm.h)
             return
         # slab mode: stage by stage with ghost-plane exchange between stages
         fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)

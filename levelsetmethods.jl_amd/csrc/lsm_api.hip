@@ -334,6 +334,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     a.f32 = is_f32(h);
     a.stamp = h->d_stamp;
+    a.nbig = 0; a.mc_tail = 0;
 }
 
 static int check_coeff(LsmHandle* h, const LsmCoeff& c, int ncomp) {
@@ -689,7 +690,7 @@ int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, vo
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));
     LSM_HIP(h, hipMemcpyAsync(phi, buf1, esize(h) * (size_t)h->lay.total, hipMemcpyDeviceToDevice, h->stream));   // copy!(ϕ, dst)
-    return lsm_fill_ghosts(h, phi, 7, nullptr);
+    return LSM_OK;     // ϕ's ghost layers are stale now: whoever reads them next fills them (as this function did on entry)
 }
 
 // _advance!(::RK2) — src/timestepping.jl:143-164 (pred = buf1, corr = buf2; the final copy!(ϕ, corr)
@@ -704,8 +705,7 @@ int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, v
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc, nullptr));
     LSM_TRY(lsm_fill_ghosts(h, buf1, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
-    LSM_TRY(lsm_stage(h, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt, nullptr));
-    return lsm_fill_ghosts(h, phi, 7, nullptr);
+    return lsm_stage(h, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt, nullptr);
 }
 
 // _advance!(::RK3) — src/timestepping.jl:170-202 (stage 3 writes ϕ in place: it reads ϕ only pointwise)
@@ -722,8 +722,7 @@ int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, v
     LSM_TRY(lsm_stage(h, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt, nullptr));
     LSM_TRY(lsm_fill_ghosts(h, buf2, 7, nullptr));
     LSM_TRY(run_hook(h, hook, user, 2, buf2, tc + 0.5 * dt));
-    LSM_TRY(lsm_stage(h, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt, nullptr));
-    return lsm_fill_ghosts(h, phi, 7, nullptr);
+    return lsm_stage(h, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt, nullptr);
 }
 
 int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream) {
@@ -756,22 +755,30 @@ int lsm_debug_stamp(LsmHandle* h, int enable, double* clock_ghz, double* loop_us
     if (!h) return LSM_ERR_INVALID;
     LSM_HIP(h, hipSetDevice(h->device));
     if (enable) {
-        if (!h->d_stamp) LSM_HIP(h, hipMalloc((void**)&h->d_stamp, sizeof(unsigned long long) * 2 * 8192));
-        LSM_HIP(h, hipMemsetAsync(h->d_stamp, 0, sizeof(unsigned long long) * 2 * 8192, h->stream));
+        if (!h->d_stamp) LSM_HIP(h, hipMalloc((void**)&h->d_stamp, sizeof(unsigned long long) * 4 * 16384));
+        LSM_HIP(h, hipMemsetAsync(h->d_stamp, 0, sizeof(unsigned long long) * 4 * 16384, h->stream));
         return LSM_OK;
     }
     if (!h->d_stamp || !clock_ghz) return LSM_ERR_INVALID;
-    std::vector<unsigned long long> v(2 * 8192);
+    std::vector<unsigned long long> v(4 * 16384);
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     LSM_HIP(h, hipMemcpy(v.data(), h->d_stamp, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
     std::vector<double> clk, us;
-    for (int i = 0; i < 8192; ++i)
-        if (v[2 * i + 1]) { clk.push_back((double)v[2 * i] / (double)v[2 * i + 1] * 0.1); us.push_back((double)v[2 * i + 1] * 0.01); }
+    for (int i = 0; i < 16384; ++i)
+        if (v[4 * i + 3]) { const double rt = (double)(v[4 * i + 3] - v[4 * i + 2]); clk.push_back((double)v[4 * i] / rt * 0.1); us.push_back(rt * 0.01); }
     if (clk.empty()) return fail(h, LSM_ERR_INVALID, "lsm_debug_stamp: no stamps (no stage kernel ran since the stamps were armed)");
     std::sort(clk.begin(), clk.end());
     std::sort(us.begin(), us.end());
     *clock_ghz = clk[clk.size() / 2];
     if (loop_us) *loop_us = us[us.size() / 2];
+    return LSM_OK;
+}
+// the raw stamps of the last launch: 16384 x {Δs_memtime over the plane loop, s_memrealtime at kernel entry, at loop start, at loop end}
+int lsm_debug_stamp_raw(LsmHandle* h, unsigned long long* out) {
+    if (!h || !h->d_stamp || !out) return LSM_ERR_INVALID;
+    LSM_HIP(h, hipSetDevice(h->device));
+    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_HIP(h, hipMemcpy(out, h->d_stamp, sizeof(unsigned long long) * 4 * 16384, hipMemcpyDeviceToHost));
     return LSM_OK;
 }
 #endif

@@ -63,6 +63,11 @@ struct StageArgs {
     unsigned nb[3];    // tiles along x, y (3-D only) and march chunks — set by the launcher
     int mb, me;        // range [mb, me) of the march (last) dimension to update
     int mc;            // planes per march chunk (0 = the tile's compile-time default)
+    // graded tail (3-D dense launches; set by the launcher, 0 = off): the first nbig chunk layers have mc planes, the rest of
+    // [mb, me) is cut into chunks of mc_tail planes whose workgroups are dispatched LAST on every XCD — the launch drains
+    // over the duration of a short workgroup instead of a long one
+    unsigned nbig;
+    int mc_tail;
     const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)

@@ -629,6 +629,9 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #endif
 // A/B switches: the ring (and the unrolled plane loop) for every 3-D FAST kernel, not only the WENO5 ones; and PFX extra
 // planes of ψ in flight (ring of 2G+1+PFX entries: the newest PFX+1 are loads that have not been waited for yet)
+#ifndef LSM_STAGE_TAIL_DEFAULT
+#define LSM_STAGE_TAIL_DEFAULT 16  // planes per chunk of the graded tail (0 = off; LSM_STAGE_TAIL overrides at run time)
+#endif
 #ifndef LSM_ZROT_ALL
 #define LSM_ZROT_ALL 0
 #endif
@@ -642,9 +645,10 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #else
 #define LSM_BARRIER() __syncthreads()
 #endif
+// One tile (a 32×8 or 64×8 column of `mc` planes; a row segment in 2-D; 256 nodes in 1-D) of one stage: the body of the
+// stage kernels below.  `slot` only names the tile in the diagnostic build's stamp buffer.
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK, bool MASKED>
-__global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2 && AK >= 0 && !MASKED && !CURV && !NM) ? 5 : LSM_WAVES_PER_EU)
-    stage_kernel(const StageArgs a) {   // the plain dense WENO5 kernels sit two registers above the 5-waves-per-SIMD step: capped there
+__device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id, bool tail_tile, unsigned slot) {
     constexpr bool PLAIN = AK >= 0;                 // coefficient kinds, term order and the single output fixed at compile time
     constexpr bool NOMASK = PLAIN && !MASKED;       // ... and no band mask (MASKED: a plain variant over a narrow band)
     constexpr int CK = PLAIN ? (int)LSM_COEFF_CONST : -1;   // kind of the NormalMotion / curvature coefficients
@@ -667,14 +671,9 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     static_assert(!HAS_Y || TY > 1 || true, "");
     __shared__ double tile[NSLOT * HW];
 
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
-    // own L2.  Remap so that every XCD walks a CONTIGUOUS range of tiles (x fastest, then y, then
-    // march chunk): tiles sharing halo columns/rows then share an L2 (speed only, never correctness).
-    // Narrow band with a compact (ordered) tile list: the same dealing over the list instead of all tiles.
-    const unsigned ntiles = a.tile_list ? a.ntile_list : a.nb[0] * a.nb[1] * a.nb[2];
-    const unsigned per_xcd = (ntiles + 7u) / 8u;
-    unsigned tile_id = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
-    if (tile_id >= ntiles) return;   // whole workgroup leaves before any barrier
+#ifdef LSM_STAMP
+    const unsigned long long st_rb = __builtin_amdgcn_s_memrealtime();
+#endif
     if (a.tile_list) tile_id = (unsigned)a.tile_list[tile_id];
     else if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
     const unsigned tbx = tile_id % a.nb[0];
@@ -700,8 +699,9 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
     const unsigned ocole = (unsigned)(lxg + G) + (unsigned)(lyg + (HAS_Y ? G : 0)) * (unsigned)sy;         // elements
     const unsigned ocol = (unsigned)sizeof(ST) * ocole, ocold = 8u * ocole;                                // bytes
-    const int mc = a.mc > 0 ? a.mc : MC;
-    const int m0 = MARCH ? a.mb + (int)tbm * mc : 0;
+    const int mcl = a.mc > 0 ? a.mc : MC;
+    const int mc = tail_tile ? a.mc_tail : mcl;
+    const int m0 = MARCH ? (tail_tile ? a.mb + (int)a.nbig * mcl + (int)(tbm - a.nbig) * mc : a.mb + (int)tbm * mc) : 0;
     const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
@@ -892,11 +892,46 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
 #ifdef LSM_STAMP
         if (a.stamp && threadIdx.x == 0) {
             const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-            a.stamp[2 * (blockIdx.x % 8192u)] = st_t1 - st_t0;
-            a.stamp[2 * (blockIdx.x % 8192u) + 1] = st_r1 - st_r0;
+            a.stamp[4 * (slot % 16384u)] = st_t1 - st_t0;
+            a.stamp[4 * (slot % 16384u) + 1] = st_rb;        // absolute 100 MHz stamps: kernel entry, plane loop start, plane loop end —
+            a.stamp[4 * (slot % 16384u) + 2] = st_r0;        // the timeline of the launch (tools/timeline_probe.py)
+            a.stamp[4 * (slot % 16384u) + 3] = st_r1;
         }
 #endif
     }
+}
+
+// Tile order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2: every XCD walks a
+// CONTIGUOUS range of tiles (x fastest, then y, then march chunk), so tiles sharing halo columns / rows share an L2 (speed
+// only, never correctness).  Narrow band with a compact (ordered) tile list: the same dealing over the list.  With a graded
+// tail (StageArgs::mc_tail) an XCD's list is its share of the long chunks followed by its share of the short ones.
+struct TileOrder {
+    unsigned ntiles, nbigt, big_per, small_per;
+    __host__ __device__ explicit TileOrder(const StageArgs& a) {
+        ntiles = a.tile_list ? a.ntile_list : a.nb[0] * a.nb[1] * a.nb[2];
+        nbigt = a.mc_tail > 0 ? a.nb[0] * a.nb[1] * a.nbig : ntiles;
+        big_per = (nbigt + 7u) / 8u;
+        small_per = (ntiles - nbigt + 7u) / 8u;
+    }
+    __host__ __device__ unsigned per_xcd() const { return big_per + small_per; }
+    // entry j of XCD x's list: tile id (and whether it is a tail tile), or false when the list is shorter
+    __host__ __device__ bool entry(unsigned x, unsigned j, unsigned& id, bool& tail) const {
+        const unsigned nb = x * big_per < nbigt ? (nbigt - x * big_per < big_per ? nbigt - x * big_per : big_per) : 0u;
+        if (j < nb) { id = x * big_per + j; tail = false; return true; }
+        const unsigned js = j - nb, so = nbigt + x * small_per;
+        if (so + js < ntiles && js < small_per) { id = so + js; tail = true; return true; }
+        return false;
+    }
+};
+
+template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK, bool MASKED>
+__global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2 && AK >= 0 && !MASKED && !CURV && !NM) ? 5 : LSM_WAVES_PER_EU)
+    stage_kernel(const StageArgs a) {   // the plain dense WENO5 kernels sit two registers above the 5-waves-per-SIMD step: capped there
+    const TileOrder ord(a);
+    unsigned tile_id;
+    bool tail_tile;
+    if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail_tile)) return;   // whole workgroup leaves before any barrier
+    stage_tile<NDIM, ADV, NM, CURV, EIK, TX, TY, MC, ST, AK, MASKED>(a, tile_id, tail_tile, blockIdx.x);
 }
 
 template <int NDIM>
@@ -972,9 +1007,26 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
         while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
     b.mc = mc;
     b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
+    b.nbig = 0;
+    b.mc_tail = 0;
+    // graded tail: a launch ends with every workgroup slot finishing its last chunk at a different moment — on average half a
+    // chunk's duration of the whole chip is lost.  Cut the last layer into short chunks and run them last.
+    if (NDIM == 3 && a.mc <= 0 && !a.mask && !a.tile_list && !a.tile_active && b.nb[2] >= 4) {
+        static const int tail_env = getenv("LSM_STAGE_TAIL") ? atoi(getenv("LSM_STAGE_TAIL")) : LSM_STAGE_TAIL_DEFAULT;
+        if (tail_env > 0 && tail_env < mc) {
+            b.nbig = b.nb[2] - 1;
+            b.mc_tail = tail_env;
+            const int left = (a.me - a.mb) - (int)b.nbig * mc;
+            b.nb[2] = b.nbig + (unsigned)((left + tail_env - 1) / tail_env);
+        }
+    }
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
+    if (b.mc_tail > 0) {
+        const unsigned nbigt = b.nb[0] * b.nb[1] * b.nbig;
+        grid.x = 8u * ((nbigt + 7u) / 8u + (ntiles - nbigt + 7u) / 8u);
+    }
     // plain variant (see plane_tab): dense field, one output, terms in slot order, constant speed / curvature
     // coefficients, and a catalogued advection coefficient
 #if !LSM_STRICT
