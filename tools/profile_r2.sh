@@ -15,6 +15,9 @@ rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $B > $OUT/pmc3.json 2> $OUT/pmc3.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- $B > $OUT/pmc4.json 2> $OUT/pmc4.err
 python3 tools/clock_probe.py 512 2.5 > $OUT/clock_probe.json 2> $OUT/clock_probe.err
+python3 tools/timeline_probe.py 512 > $OUT/timeline_probe.json 2> $OUT/timeline_probe.err
+LSM_STAGE_TAIL=0 python3 tools/timeline_probe.py 512 > $OUT/timeline_probe_no_tail.json 2> $OUT/timeline_probe_no_tail.err
+(cd tools && python3 tail_probe.py && LSM_STAGE_TAIL=0 python3 tail_probe.py) > $OUT/tail_probe.jsonl 2> $OUT/tail_probe.err
 python3 tools/make_profile_summary.py $OUT $OUT/pmc_per_dispatch.json > $OUT/summary.log 2>&1
 mkdir -p profiles/r2 && cp $OUT/pmc_per_dispatch.json profiles/r2/pmc_per_dispatch.json   # the bench line below reads it (same build, same box)
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err

@@ -31,5 +31,5 @@ if __name__ == "__main__":
     x = np.array([r[0] for r in rows], float)
     y = np.array([r[1] for r in rows], float)
     a, b = np.polyfit(x, y, 1)
-    print(json.dumps({"mc": os.environ.get("LSM_STAGE_MC", "default"), "rows": [{"nz": r[0], "stage_ms": round(r[1], 4), "step_ms": round(r[2], 4)} for r in rows],
+    print(json.dumps({"mc": os.environ.get("LSM_STAGE_MC", "default"), "tail": os.environ.get("LSM_STAGE_TAIL", "default"), "rows": [{"nz": r[0], "stage_ms": round(r[1], 4), "step_ms": round(r[2], 4)} for r in rows],
                       "fit_ms_per_plane": a, "fit_intercept_ms": b}))
