@@ -767,20 +767,29 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices)
         node_store<ST, PLAIN>(a, io, active && (NOMASK || !a.mask || ldg_u8(uniform_ptr(a.mask + corner), ocold >> 3, (int)0x80000000u) != 0), r1, r2);
     } else {
+        // the prologue is a chain of memory round trips (≈12 µs of a workgroup's ≈165 on a busy chip): issue everything that
+        // does not depend on an earlier answer at once — the first plane's table entries (scalar loads), the march line and
+        // the halo elements of the first LDS planes — and only then wait and fill the LDS planes
+        PlaneTab pt;
+        plane_tab<NDIM, ADV, NM, CURV, AK>(a, m0 + a.goff[NDIM - 1], pt);
         double zl[2 * G + 1 + PFX];
 #pragma unroll
         for (int j = 0; j <= 2 * G + PFX; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
+        double hp[2 * LEAD + 1][HPT > 0 ? HPT : 1];
+#pragma unroll
+        for (int pl = -LEAD; pl <= LEAD; ++pl) {
+            const ST* P = plane(m0 + pl);
+#pragma unroll
+            for (int h = 0; h < HPT; ++h) hp[pl + LEAD][h] = ldg(P, hg[h]);   // lanes without a halo element: out-of-range offset, no access
+        }
 #pragma unroll
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
             const int slot = pl + LEAD;
             tile[slot * HW + lpos] = zl[G + pl];
-            const ST* P = plane(m0 + pl);
 #pragma unroll
             for (int h = 0; h < HPT; ++h)
-                if (hv[h]) tile[slot * HW + hl[h]] = ldg(P, hg[h]);
+                if (hv[h]) tile[slot * HW + hl[h]] = hp[slot][h];
         }
-        PlaneTab pt;
-        plane_tab<NDIM, ADV, NM, CURV, AK>(a, m0 + a.goff[NDIM - 1], pt);
         // narrow band: only band nodes are updated (src/timestepping.jl loops over active_nodeindices).  The mask byte
         // of a plane is fetched one plane ahead, unconditionally: without a mask the descriptor's range is 0 and the
         // load returns 0 without an access (a load inside a branch would cost the loop its exact wait counts).
@@ -1003,7 +1012,7 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     // small grids: a workgroup marching 64 planes leaves most of the 256 CUs idle (48^3 = 12 workgroups, a serial walk
     // of 48 planes each).  Shorter chunks — down to 8 planes — until there are ~8 workgroups per CU; each chunk pays its
     // 2G+1 planes of prologue, which is why large grids keep the long march.
-    if (a.mc <= 0 && NDIM == 3 && !a.mask)
+    if (a.mc <= 0 && NDIM == 3 && !a.mask && !(getenv("LSM_STAGE_MC") && atoi(getenv("LSM_STAGE_MC")) > 0))
         while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
     b.mc = mc;
     b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;

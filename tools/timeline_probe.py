@@ -56,6 +56,7 @@ out = {
     "concurrency_every_50us": [int(c) for c in conc[::5]],
     "finish_spread_us_of_last_1280": round(float(en[np.argsort(en)[-1280:]].min()), 1),
     "loop_us_by_start_order (deciles)": [round(float(d.mean()), 1) for d in np.array_split(dur[order], 10)],
+    "clock_ghz_by_start_order (deciles)": [round(float(c.mean()), 3) for c in np.array_split((raw[ok, 0].astype(np.float64) / (dur * 100.0) * 0.1)[order], 10)],
     "per_xcd_end_us": [round(float(en[blk % 8 == x].max()), 1) for x in range(8)],
 }
 print(json.dumps(out))
