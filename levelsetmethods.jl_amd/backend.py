@@ -324,11 +324,10 @@ class HipBackend:
 
     def mask_to_host(self, mask):
         """Boolean (local) interior of a mask, Fortran order."""
-        g = [int(self.lay.g[d]) for d in range(self.ndim)]
-        shape = tuple(int(self.lay.n[d]) + 2 * g[d] for d in range(self.ndim))
-        a = mask.cpu().numpy().reshape(shape, order="F")
-        sl = tuple(slice(g[d], g[d] + int(self.lay.n[d])) for d in range(self.ndim))
-        return a[sl].astype(bool)
+        flat = mask.cpu().numpy()
+        n = tuple(int(self.lay.n[d]) for d in range(self.ndim))
+        strides = tuple(int(self.lay.stride[d]) * flat.itemsize for d in range(self.ndim))   # the library's layout: pitch and origin are its own
+        return np.lib.stride_tricks.as_strided(flat[int(self.lay.origin):], shape=n, strides=strides).astype(bool)
 
     def volume_local(self, t):
         out = C.c_double()

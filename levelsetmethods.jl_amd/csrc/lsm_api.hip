@@ -129,6 +129,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     }
     long long s = 1;
     h->lay.origin = 0;
+    static const bool align_rows = !(getenv("LSM_LAYOUT_ALIGN") && getenv("LSM_LAYOUT_ALIGN")[0] == '0');   // A/B switch
     for (int d = 0; d < 3; ++d) {
         h->nloc[d] = (int)grid->n[d];
         h->goff[d] = 0;
@@ -137,8 +138,18 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
         h->lay.n[d] = h->nloc[d];
         h->lay.g[d] = d < N ? LSM_GHOST : 0;
         h->lay.stride[d] = s;
-        h->lay.origin += h->lay.g[d] * s;
-        s *= h->lay.n[d] + 2 * h->lay.g[d];
+        if (d == 0 && N >= 2 && align_rows) {
+            // rows start on a 64-byte boundary: interior node 0 of every row sits ALIGN elements into its pitch (the ghosts
+            // fill the end of the line before it) and the pitch is a multiple of ALIGN — a wave's 32 x 8-byte row segment is
+            // then four whole lines instead of five pieces, and the ghost nodes of a row end share one line
+            const long long A = dtype == LSM_DTYPE_F32 ? 16 : 8;
+            const long long lead = (LSM_GHOST + A - 1) / A * A;
+            h->lay.origin += lead;
+            s = (lead + h->lay.n[d] + h->lay.g[d] + A - 1) / A * A;
+        } else {
+            h->lay.origin += h->lay.g[d] * s;
+            s *= h->lay.n[d] + 2 * h->lay.g[d];
+        }
     }
     h->lay.total = s;
     h->dxmin = 0;

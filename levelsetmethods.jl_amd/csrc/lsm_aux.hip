@@ -150,7 +150,98 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     st_val(a.v, a.origin + I0 + I1 * a.s1 + I2 * a.s2, a.f32, val);
 }
 
+// Row-based form of the same fill (2-D and 3-D): a block is a 256-wide piece of ONE row of ghost nodes, found from
+// blockIdx with compares and a division by 6 — no division by a runtime extent in any lane (the flat enumeration above spends
+// most of its 40 µs at 512³ on them).  blockIdx.y = line:
+//   (A) the ghost planes of the last dimension: nlastg x P1 rows of P0 nodes (the padded row, corners included),
+//   (B) 3-D: the 2G ghost rows of dimension 1 of every plane mb..me-1, P0 nodes each,
+//   (C) the 2G ghost nodes at the ends of the interior rows: one line per plane (3-D) or one line in all (2-D); its blocks
+//       walk the rows, 42 rows x 6 nodes at a time.
+// COPY: every face that is resolved copies ONE node (periodic wrap, symmetry mirror, degree-0 extrapolation = NeumannBC):
+// the nested sums collapse to 0.0 + 1.0·ϕ[source] (the "+ 0.0" is the reference's `acc = 0; acc += w·value`: it turns -0.0
+// into +0.0 and nothing else), one load per ghost node; bit-identical to the flat kernel, which keeps the weighted faces.
+template <int D>
+__device__ __forceinline__ int ghost_copy_source(const GhostAllArgs& a, int i) {
+    const int n = a.n[D];
+    if (i >= 0 && i < n) return i;
+    const int side = i < 0 ? 0 : 1;
+    const int k = side == 0 ? -i : i - (n - 1);
+    const int kind = side ? a.kind[D][1] : a.kind[D][0];
+    if (kind == LSM_BC_PERIODIC) return side == 0 ? (n - 1) - k : k;
+    if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : n - 1;      // degree 0
+    return side == 0 ? k : (n - 1) - k;                                  // symmetry
+}
+
+template <int NDIM, bool COPY>
+__global__ void __launch_bounds__(256) ghost_rows_kernel(const GhostAllArgs a) {
+    constexpr int G = LSM_GHOST;
+    const int P0 = a.n[0] + 2 * G, P1 = NDIM == 3 ? a.n[1] + 2 * G : 1;
+    const int nl = a.n[NDIM - 1];
+    const bool lastL = a.fill_last && a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.fill_last && a.kind[NDIM - 1][1] != LSM_BC_NONE;
+    const int nlastg = (lastL ? G : 0) + (lastR ? G : 0);
+    const int np = a.me - a.mb;
+    const int nA = nlastg * P1, nB = NDIM == 3 ? np * 2 * G : 0;
+    auto put = [&](int I0, int I1, int I2) {
+        static_assert(COPY, "the row form serves copy-type faces");
+        const int s0 = ghost_copy_source<0>(a, I0), s1 = ghost_copy_source<1>(a, I1), s2 = NDIM == 3 ? ghost_copy_source<2>(a, I2) : 0;
+        const double val = 0.0 + 1.0 * ld_val(a.v, a.origin + s0 + s1 * a.s1 + s2 * a.s2, a.f32);
+        st_val(a.v, a.origin + I0 + I1 * a.s1 + I2 * a.s2, a.f32, val);
+    };
+    int line = (int)blockIdx.y;
+    if (line < nA + nB) {
+        int I1 = 0, I2 = 0;
+        if (line < nA) {
+            int gz = 0;
+            while (line >= P1) { line -= P1; ++gz; }                     // nlastg <= 6 turns of a scalar loop
+            const int il = (lastL && gz < G) ? gz - G : nl + (gz - (lastL ? G : 0));
+            if (NDIM == 3) { I1 = line - G; I2 = il; } else { I1 = il; }
+        } else {
+            const int l = line - nA, z = l / (2 * G), g = l % (2 * G);
+            I1 = g < G ? g - G : a.n[1] + (g - G);
+            I2 = a.mb + z;
+        }
+        for (int x = (int)blockIdx.x * 256 + (int)threadIdx.x; x < P0; x += 256 * (int)gridDim.x) put(x - G, I1, I2);
+    } else {
+        const int l = line - nA - nB;                                    // 3-D: plane; 2-D: 0
+        const int nrows = NDIM == 3 ? a.n[1] : np;
+        const int g = (int)threadIdx.x % (2 * G);
+        const int I0 = g < G ? g - G : a.n[0] + (g - G);
+        if ((int)threadIdx.x >= 42 * 2 * G) return;
+        for (int r = (int)blockIdx.x * 42 + (int)threadIdx.x / (2 * G); r < nrows; r += 42 * (int)gridDim.x) {
+            if (NDIM == 3) put(I0, r, a.mb + l); else put(I0, a.mb + r, 0);
+        }
+    }
+}
+
+static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
+    if (ndim < 2) return false;
+    static const bool off = getenv("LSM_GHOST_FLAT") != nullptr;          // A/B switch: the flat enumeration
+    if (off) return false;
+    const int G = LSM_GHOST;
+    const long long P0 = a.n[0] + 2 * G, P1 = ndim == 3 ? a.n[1] + 2 * G : 1;
+    const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
+    const long long np = a.me - a.mb;
+    const long long lines = nlastg * P1 + (ndim == 3 ? np * 2 * G + np : (np > 0 ? 1 : 0));
+    if (lines <= 0) return true;
+    if (lines > 65535) return false;
+    bool copy = true;
+    for (int d = 0; d < ndim; ++d)
+        for (int sd = 0; sd < 2; ++sd) {
+            const int k = a.kind[d][sd];
+            if (k == LSM_BC_NONE) continue;
+            if (k == LSM_BC_EXTRAPOLATION && a.degree[d][sd] != 0) copy = false;
+        }
+    // weighted faces (extrapolation of degree >= 1) stay with the flat kernel: the nested sums inlined into both loops of the
+    // row form cost 166 registers and spills (289 µs against 75 µs at 512³ with ExtrapolationBC(2))
+    if (!copy) return false;
+    const dim3 grid((unsigned)((P0 + 255) / 256), (unsigned)lines);
+    if (ndim == 2) hipLaunchKernelGGL((ghost_rows_kernel<2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ghost_rows_kernel<3, true>), grid, dim3(256), 0, s, a);
+    return true;
+}
+
 void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
+    if (ghost_rows_launch(ndim, a, s)) return;
     const int G = LSM_GHOST;
     const long long P0 = a.n[0] + 2 * G, P1 = ndim > 1 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;

@@ -38,7 +38,7 @@ BCS = ["periodic", "neumann", ("extrapolation", 2), "symmetry",
        [("neumann", ("extrapolation", 3)), "periodic", ("symmetry", "linear")]]
 
 
-@pytest.mark.parametrize("shape", [(37,), (23, 19), (13, 11, 9)])
+@pytest.mark.parametrize("shape", [(37,), (23, 19), (13, 11, 9), (300, 50), (270, 45, 5)])   # rows longer than a block, more than 42 rows
 @pytest.mark.parametrize("bcspec", BCS, ids=[str(b) for b in BCS])
 def test_ghost_fill_bitwise(hip, orc, shape, bcspec):
     nd = len(shape)
@@ -46,11 +46,16 @@ def test_ghost_fill_bitwise(hip, orc, shape, bcspec):
         bcspec = bcspec[:nd]
     c = hip.Case(shape, bcspec)
     phi = _rand_field(shape, 1, smooth=False)
+    # signed zeros on the faces: the reference's `acc = 0; acc += w·value` turns a copied -0.0 into +0.0 — bit patterns below
+    phi[(0,) * nd] = -0.0
+    phi[tuple(n - 1 for n in shape)] = -0.0
+    phi[(0,) + tuple(n // 2 for n in shape[1:])] = -0.0
     want = c.pad(phi)
     t = c.to_dev(np.nan_to_num(c.pad(phi, fill=False), nan=-7.0))
     c.be.fill_ghosts(t)
     got = c.to_host(t)
     assert np.array_equal(got, want)
+    assert np.array_equal(np.ascontiguousarray(got).view(np.int64), np.ascontiguousarray(want).view(np.int64))
 
 
 SINGLE = {
