@@ -191,8 +191,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->ch_result, sizeof(double) * 2, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_w, sizeof(h->w));
     if (e == hipSuccess) e = hipMemcpy(h->d_w, h->w, sizeof(h->w), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 2);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 2, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 8);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 8, hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string m = std::string("lsm_create: ") + hipGetErrorString(e);
         delete h;
@@ -1008,7 +1008,7 @@ int lsm_band_tile_count(LsmHandle* h, int mc, int64_t* ntiles) {
 // `visit`: the tiles to cover (from lsm_band_update); NULL = the band's own work tiles
 // `interior`: 1 = no stencil of the band reaches outside the grid (known by the caller), 0 = unknown / it may, -1 = ask the lists
 static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc, void* halo_list,
-                          int64_t halo_cap, void* halo_count, const BandArgs* visit, int interior_hint) {
+                          int64_t halo_cap, void* halo_count, const BandArgs* visit, int interior_hint, bool halo_cleared = false) {
     if (!h || !vals || !mask || !halo_mask || !tiles || mc < 1) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
     BandArgs a = band_args(h, mc, nullptr);
@@ -1022,7 +1022,11 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
         a.work = h->d_work;
     }
     const int N = h->grid.ndim;
-    LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
+    // nothing reads the halo mask outside the tiles visited here: clear those (0.5 % of a 768³ grid) instead of every byte
+    static const bool full_clear = getenv("LSM_BAND_FULL_CLEAR") != nullptr;   // A/B switch
+    if (halo_cleared && visit) {}                                   // lsm_band_update's copy pass cleared the visited tiles
+    else if ((a.list || a.work) && !full_clear) launch_band_zero(a, (unsigned char*)halo_mask, h->stream);
+    else LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
     BandBcArgs bc;
     for (int d = 0; d < 3; ++d)
         for (int sd = 0; sd < 2; ++sd) { bc.kind[d][sd] = d < N ? h->bc[d][sd].kind : LSM_BC_NONE; bc.degree[d][sd] = d < N ? h->bc[d][sd].degree : 0; }
@@ -1090,13 +1094,15 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (!from_dense)
         launch_band_extrapolate(a, A, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds, vals,
                                 vals, h->d_miss, nullptr, nullptr, 0, h->stream);
-    launch_band_copy(a, A, (unsigned char*)mask, h->stream);   // the old band lies inside the visited tiles
+    static const bool full_clear_env = getenv("LSM_BAND_FULL_CLEAR") != nullptr;
+    const bool clear_with_copy = listed && !full_clear_env;    // the halo pass below visits the same listed tiles
+    launch_band_copy(a, A, (unsigned char*)mask, clear_with_copy ? (unsigned char*)halo_mask : nullptr, h->stream);   // the old band lies inside the visited tiles
     if (!fused) launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
     LSM_HIP(h, hipGetLastError());
     // halo of the new band: over the same (old) work tiles when they are listed, else over the new band's
     const int interior = listed && h->nface == 0 ? 1 : 0;   // the new band lies in the old work tiles: none on a face
     h->lists_host_valid = false;                             // from here on the lists describe the previous band
-    LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior));
+    LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior, clear_with_copy));
     // compact lists of the new band's tiles for the launches that follow lsm_band_status
     BandArgs full = band_args(h, mc, nullptr);
     launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->stream);
@@ -1197,15 +1203,14 @@ int lsm_band_missed(LsmHandle* h, int* missed) {
 int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* missed) {
     if (!h || !halo_count || !count || !missed) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
-    unsigned c = 0;
-    LSM_HIP(h, hipMemcpyAsync(&c, halo_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    unsigned lc[3] = {0, 0, 0};
-    if (h->lists_tiles) LSM_HIP(h, hipMemcpyAsync(lc, h->d_lcounts, sizeof(lc), hipMemcpyDeviceToHost, h->stream));
+    // one gather kernel and ONE copy into pinned memory instead of three small copies into pageable memory (a host round trip each)
+    launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->d_result + 2, h->stream);
+    LSM_HIP(h, hipMemcpyAsync(h->h_result + 2, h->d_result + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     LSM_HIP(h, hipStreamSynchronize(h->stream));
-    if (h->lists_tiles) { h->nact = lc[0]; h->nwork = lc[1]; h->nface = lc[2]; h->lists_host_valid = true; }
+    *missed = (int)h->h_result[3];
+    if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->lists_host_valid = true; }
     if (*missed) LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
-    *count = (int64_t)c;
+    *count = (int64_t)h->h_result[2];
     return LSM_OK;
 }
 

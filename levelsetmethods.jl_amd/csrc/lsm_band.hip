@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(256) band_dilate_kernel(BandArgs a, const unsi
     }
 }
 
-__global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsigned char* in, unsigned char* out) {
+// out := in on the visited tiles; `zero` (may be NULL) is cleared on the same tiles in the same pass (the halo mask of the update)
+__global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsigned char* in, unsigned char* out, unsigned char* zero) {
     LSM_TILE_PROLOGUE(a)
     if (ex_ % 8 == 0 && x0_ + ex_ <= nx_) {
         // whole x-rows of the tile inside the grid: 8 mask bytes per access (unaligned), one access per thread and round
@@ -221,10 +222,39 @@ __global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsign
             if (y >= ny_ || m >= nm_) continue;
             const long long q = a.origin + x + y * sy_ + m * sm_;
             *reinterpret_cast<w8*>(out + q) = *reinterpret_cast<const w8*>(in + q);
+            if (zero) *reinterpret_cast<w8*>(zero + q) = 0ull;
         }
         return;
     }
-    LSM_TILE_FOR(a, x, y, m, q) out[q] = in[q];
+    LSM_TILE_FOR(a, x, y, m, q) { out[q] = in[q]; if (zero) zero[q] = 0; }
+}
+
+// zero a byte mask on the visited tiles only (the halo mask of a band update: nothing reads it outside the work tiles)
+__global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned char* out) {
+    LSM_TILE_PROLOGUE(a)
+    if (ex_ % 8 == 0 && x0_ + ex_ <= nx_) {
+        typedef unsigned long long w8 __attribute__((aligned(1)));
+        const int ppr = ex_ / 8;
+        for (int e_ = threadIdx.x; e_ < ppr * ey_ * em_; e_ += blockDim.x) {
+            const int x = x0_ + 8 * (e_ % ppr), y = y0_ + (e_ / ppr) % ey_, m = m0_ + e_ / (ppr * ey_);
+            if (y >= ny_ || m >= nm_) continue;
+            *reinterpret_cast<w8*>(out + (a.origin + x + y * sy_ + m * sm_)) = 0ull;
+        }
+        return;
+    }
+    LSM_TILE_FOR(a, x, y, m, q) out[q] = 0;
+}
+
+// the numbers lsm_band_status hands to the host, gathered into one pinned-memory copy: {halo entries wanted, search misses,
+// active tiles, work tiles, face tiles}
+__global__ void band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out) {
+    if (threadIdx.x == 0) {
+        out[0] = (double)halo_count[0];
+        out[1] = (double)miss[0];
+        out[2] = lcounts ? (double)lcounts[0] : 0.0;
+        out[3] = lcounts ? (double)lcounts[1] : 0.0;
+        out[4] = lcounts ? (double)lcounts[2] : 0.0;
+    }
 }
 
 // _nearest_band_node continued in global memory: ring entries [r0, nring) in order, bounds-checked
@@ -946,9 +976,16 @@ void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old
     hipLaunchKernelGGL(band_grow_kernel, tile_grid(a), dim3(256), (size_t)box_bytes(a, nl + 1), s, a, v, old_mask, nl, new_mask, tiles);
 }
 bool band_grow_fits(const BandArgs& a, int nl) { return fast3(a, nl + 1, 5) || box_bytes(a, nl + 1) <= LSM_BAND_LDS; }
-void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s) {
+void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s) {
     if (no_tiles(a)) return;
-    hipLaunchKernelGGL(band_copy_kernel, tile_grid(a), dim3(256), 0, s, a, in, out);
+    hipLaunchKernelGGL(band_copy_kernel, tile_grid(a), dim3(256), 0, s, a, in, out, zero);
+}
+void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s) {
+    if (no_tiles(a)) return;
+    hipLaunchKernelGGL(band_zero_kernel, tile_grid(a), dim3(256), 0, s, a, out);
+}
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, out);
 }
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,

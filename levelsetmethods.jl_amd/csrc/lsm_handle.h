@@ -45,8 +45,8 @@ struct LsmHandle {
     bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
-    double* d_result;    // 2 doubles
-    double* h_result;    // pinned, 2 doubles
+    double* d_result;    // 8 doubles: [0..1] reductions, [2..6] lsm_band_status
+    double* h_result;    // pinned, 8 doubles
     std::string err;
     bool cfl_cache_on;
     std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients

@@ -133,7 +133,7 @@ struct BandArgs {
     int f32;                     // the value arrays hold float
     int force_bytes;             // A/B switch (LSM_BAND_BYTES at lsm_create): byte-mask kernels in 3-D too
 };
-void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
+void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s);
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
@@ -145,6 +145,8 @@ struct BandEntry {          // a halo node and its nearest band node (16 bytes)
     int rel;                // padded index of the nearest band node minus q
     signed char d[4];       // I - P per dimension
 };
+void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s);
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s);
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
