@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     if (NDIM == 1) { nA = nlastg; nB = 0; nC = 0; }
     else if (NDIM == 2) { nA = (IT)nlastg * P0; nB = 0; nC = (IT)np * ncx; }
     else { nA = (IT)nlastg * P0 * P1; nB = (IT)np * 2 * G * P0; nC = (IT)np * a.n[1] * ncx; }
+    if (a.skip_x && NDIM > 1) nC = 0;
     const IT t = (IT)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nA + nB + nC) return;
     int I0 = 0, I1 = 0, I2 = 0;
@@ -221,7 +222,7 @@ static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const long long P0 = a.n[0] + 2 * G, P1 = ndim == 3 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
     const long long np = a.me - a.mb;
-    const long long lines = nlastg * P1 + (ndim == 3 ? np * 2 * G + np : (np > 0 ? 1 : 0));
+    const long long lines = nlastg * P1 + (ndim == 3 ? np * 2 * G + (a.skip_x ? 0 : np) : (np > 0 && !a.skip_x ? 1 : 0));
     if (lines <= 0) return true;
     if (lines > 65535) return false;
     bool copy = true;
@@ -248,9 +249,10 @@ void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const long long np = a.me - a.mb;
     long long total;
     const int ncx = 2 * G;
+    const long long ncxs = a.skip_x ? 0 : ncx;
     if (ndim == 1) total = nlastg;
-    else if (ndim == 2) total = nlastg * P0 + np * ncx;
-    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * ncx;
+    else if (ndim == 2) total = nlastg * P0 + np * ncxs;
+    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * ncxs;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + 255) / 256);
     const bool narrow = total < (1ll << 31) - 512;

@@ -68,6 +68,11 @@ struct StageArgs {
     // over the duration of a short workgroup instead of a long one
     unsigned nbig;
     int mc_tail;
+    // x ghosts resolved by the loads themselves (set by the whole-grid lsm_advance_* in FAST mode when both x faces copy ONE
+    // node: periodic / symmetry / degree-0 extrapolation): a load of a node with x outside [0, n0) goes to the node the boundary
+    // condition copies instead, and the ghost fill before the stage skips the x faces.  xkind[side] = LSM_BC_* of the x faces.
+    int xredirect;
+    int xkind[2];
     const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
@@ -98,6 +103,7 @@ struct GhostAllArgs {
     int f32;
     int mb, me;        // planes [mb, me) of the last dimension whose lower-dimension ghosts are filled
     int fill_last;     // also fill the (physical) ghosts of the last dimension
+    int skip_x;        // leave the ghost nodes at the ends of the interior rows alone (StageArgs::xredirect: nobody reads them)
 };
 
 struct CflArgs {

@@ -692,7 +692,15 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     // inactive threads of a partial tile still feed the tile: they load their own (ghost) position
     // while it lies inside the padded array; coefficient lookups use the interior-clamped index.
     const int cx = gx < nx ? gx : nx - 1, cy = gy < ny ? gy : ny - 1;
-    const int lxg = gx < nx + G ? gx : nx + G - 1;
+    // StageArgs::xredirect: the node a load of x-index i (possibly a ghost) is served from
+    auto xsrc = [&](int i) {
+        if (!a.xredirect || (i >= 0 && i < nx)) return i;
+        const int side = i < 0 ? 0 : 1, k = side == 0 ? -i : i - (nx - 1), kind = a.xkind[side];
+        if (kind == LSM_BC_PERIODIC) return side == 0 ? (nx - 1) - k : k;
+        if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : nx - 1;
+        return side == 0 ? k : (nx - 1) - k;
+    };
+    const int lxg = xsrc(gx < nx + G ? gx : nx + G - 1);
     const int lyg = HAS_Y ? (gy < ny + G ? gy : ny + G - 1) : 0;
     // unsigned in-plane offset from the plane's lowest (ghost) corner: with a wave-uniform base this
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
@@ -727,7 +735,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
             ly = row < G ? row : row + TY;
         }
         int X = bx0 - G + lx;
-        X = X > nx + G - 1 ? nx + G - 1 : X;
+        X = xsrc(X > nx + G - 1 ? nx + G - 1 : X);
         int Y = 0;
         if (HAS_Y) {
             Y = by0 - G + ly;
