@@ -204,8 +204,8 @@ int lsm_cfl_cache(LsmHandle* h, int enable);
  *      lsm_stage calls lsm_fill_ghosts first — one fill per step saved when steps follow each other.  (A slab returns
  *      with its ghost PLANES exchanged and valid, and expects them so on entry.)  In LSM_MODE_FAST without a hook, when both
  *      faces of dimension 1 copy one node (periodic, symmetry, degree-0 extrapolation = NeumannBC), the stage kernels of
- *      these calls resolve the ghosts of dimension 1 in their loads and the fills inside the step leave the row ends alone:
- *      do not read those ghost nodes afterwards without an lsm_fill_ghosts of your own.
+ *      these calls resolve the ghosts of dimension 1 in their loads and the fills inside the step leave the row ends alone
+ *      (likewise dimension 2 of a 3-D grid): do not read those ghost nodes afterwards without an lsm_fill_ghosts of your own.
  *      hook may be NULL (the reference's default no-op update_func, src/levelsetterms.jl:63).
  *      On a slab handle with a communicator attached these run the slab's step (see "multi-GPU" below). */
 int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, void* buf1,

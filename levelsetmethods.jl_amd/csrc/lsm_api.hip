@@ -114,6 +114,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->comm = nullptr;
     h->d_stamp = nullptr;
     h->xredirect = false;
+    h->yredirect = false;
     h->cfl_cache_on = true;
     h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
@@ -280,7 +281,7 @@ int lsm_download_f64(LsmHandle* h, const void* dev_padded, void* host_dense) {
     return copy_interior(h, (void*)dev_padded, host_dense, false, sizeof(double));
 }
 
-static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s, bool skip_x = false) {
+static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s, bool skip_x = false, bool skip_y = false) {
     const int N = h->grid.ndim;
     GhostAllArgs a;
     for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
@@ -291,6 +292,7 @@ static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill
     a.v = field; a.f32 = is_f32(h);
     a.mb = mb; a.me = me; a.fill_last = fill_last;
     a.skip_x = skip_x ? 1 : 0;
+    a.skip_y = skip_y && N == 3 ? 1 : 0;
     launch_ghost_fill_all(N, a, s);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -324,7 +326,7 @@ int lsm_fill_ghosts_planes(LsmHandle* h, void* field, int64_t m_begin, int64_t m
     const int N = h->grid.ndim;
     if (m_begin < 0 || m_end > h->nloc[N - 1] || m_begin > m_end) return fail(h, LSM_ERR_INVALID, "lsm_fill_ghosts_planes: bad plane range");
     // inside a step whose stage kernels resolve x ghosts in their loads (h->xredirect, see XRedirect) the row ends are left alone
-    return fill_ghosts_fused(h, field, (int)m_begin, (int)m_end, fill_last, stream ? (hipStream_t)stream : h->stream, h->xredirect);
+    return fill_ghosts_fused(h, field, (int)m_begin, (int)m_end, fill_last, stream ? (hipStream_t)stream : h->stream, h->xredirect, h->yredirect);
 }
 
 static void fill_coeff(const LsmCoeff& c, double t, CoeffArgs& o) {
@@ -349,6 +351,8 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.f32 = is_f32(h);
     a.xredirect = h->xredirect ? 1 : 0;
     a.xkind[0] = h->bc[0][0].kind; a.xkind[1] = h->bc[0][1].kind;
+    a.yredirect = h->yredirect ? 1 : 0;
+    a.ykind[0] = h->bc[1][0].kind; a.ykind[1] = h->bc[1][1].kind;
     a.stamp = h->d_stamp;
     a.nbig = 0; a.mc_tail = 0;
 }
@@ -654,17 +658,19 @@ struct XRedirect {
     bool on;
     XRedirect(LsmHandle* h_, LsmStageHook hook) : h(h_), on(false) {
         static const bool off = getenv("LSM_XREDIRECT") && getenv("LSM_XREDIRECT")[0] == '0';
-        auto copies = [&](int sd) {
-            const int k = h->bc[0][sd].kind;
-            return k == LSM_BC_PERIODIC || k == LSM_BC_SYMMETRY || (k == LSM_BC_EXTRAPOLATION && h->bc[0][sd].degree == 0);
+        auto copies = [&](int d, int sd) {
+            const int k = h->bc[d][sd].kind;
+            return k == LSM_BC_PERIODIC || k == LSM_BC_SYMMETRY || (k == LSM_BC_EXTRAPOLATION && h->bc[d][sd].degree == 0);
         };
-        on = !off && !hook && h->mode != LSM_MODE_STRICT && h->grid.ndim >= 2 && h->nloc[0] >= 2 * LSM_GHOST + 2 && copies(0) && copies(1);
+        on = !off && !hook && h->mode != LSM_MODE_STRICT && h->grid.ndim >= 2 && h->nloc[0] >= 2 * LSM_GHOST + 2 && copies(0, 0) && copies(0, 1);
         h->xredirect = on;
+        // dimension 2 of a 3-D grid likewise (in 2-D it is the march axis: its ghost rows stay in memory)
+        h->yredirect = on && h->grid.ndim == 3 && h->nloc[1] >= 2 * LSM_GHOST + 2 && copies(1, 0) && copies(1, 1);
     }
-    ~XRedirect() { h->xredirect = false; }
+    ~XRedirect() { h->xredirect = false; h->yredirect = false; }
     int fill(void* field) const {
         if (!on) return lsm_fill_ghosts(h, field, 7, nullptr);
-        return fill_ghosts_fused(h, field, 0, h->nloc[h->grid.ndim - 1], 1, h->stream, true);
+        return fill_ghosts_fused(h, field, 0, h->nloc[h->grid.ndim - 1], 1, h->stream, true, h->yredirect);
     }
 };
 
@@ -681,7 +687,7 @@ static int stage_slab(LsmHandle* h, const LsmTerm* terms, int nterms, const void
     const int B = LSM_GHOST + 1;                 // +1: the periodic wrap sends planes shifted by one node
     if (!lsm_comm_overlap(h) || N < 2 || nloc < 2 * B + 1) {
         LSM_TRY(lsm_stage(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, nullptr));
-        if (h->xredirect) LSM_TRY(fill_ghosts_fused(h, out, 0, nloc, 1, h->stream, true));
+        if (h->xredirect) LSM_TRY(fill_ghosts_fused(h, out, 0, nloc, 1, h->stream, true, h->yredirect));
         else LSM_TRY(lsm_fill_ghosts(h, out, 7, nullptr));
         return lsm_halo_exchange(h, out);
     }

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs 
     else if (NDIM == 2) { nA = (IT)nlastg * P0; nB = 0; nC = (IT)np * ncx; }
     else { nA = (IT)nlastg * P0 * P1; nB = (IT)np * 2 * G * P0; nC = (IT)np * a.n[1] * ncx; }
     if (a.skip_x && NDIM > 1) nC = 0;
+    if (a.skip_y && NDIM == 3) nB = 0;
     const IT t = (IT)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nA + nB + nC) return;
     int I0 = 0, I1 = 0, I2 = 0;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(256) ghost_rows_kernel(const GhostAllArgs a) {
     const bool lastL = a.fill_last && a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.fill_last && a.kind[NDIM - 1][1] != LSM_BC_NONE;
     const int nlastg = (lastL ? G : 0) + (lastR ? G : 0);
     const int np = a.me - a.mb;
-    const int nA = nlastg * P1, nB = NDIM == 3 ? np * 2 * G : 0;
+    const int nA = nlastg * P1, nB = NDIM == 3 && !a.skip_y ? np * 2 * G : 0;
     auto put = [&](int I0, int I1, int I2) {
         static_assert(COPY, "the row form serves copy-type faces");
         const int s0 = ghost_copy_source<0>(a, I0), s1 = ghost_copy_source<1>(a, I1), s2 = NDIM == 3 ? ghost_copy_source<2>(a, I2) : 0;
@@ -222,7 +223,7 @@ static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const long long P0 = a.n[0] + 2 * G, P1 = ndim == 3 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
     const long long np = a.me - a.mb;
-    const long long lines = nlastg * P1 + (ndim == 3 ? np * 2 * G + (a.skip_x ? 0 : np) : (np > 0 && !a.skip_x ? 1 : 0));
+    const long long lines = nlastg * P1 + (ndim == 3 ? (a.skip_y ? 0 : np * 2 * G) + (a.skip_x ? 0 : np) : (np > 0 && !a.skip_x ? 1 : 0));
     if (lines <= 0) return true;
     if (lines > 65535) return false;
     bool copy = true;
@@ -252,7 +253,7 @@ void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
     const long long ncxs = a.skip_x ? 0 : ncx;
     if (ndim == 1) total = nlastg;
     else if (ndim == 2) total = nlastg * P0 + np * ncxs;
-    else total = nlastg * P0 * P1 + np * 2 * G * P0 + np * a.n[1] * ncxs;
+    else total = nlastg * P0 * P1 + (a.skip_y ? 0 : np * 2 * G * P0) + np * a.n[1] * ncxs;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + 255) / 256);
     const bool narrow = total < (1ll << 31) - 512;

@@ -73,6 +73,8 @@ struct StageArgs {
     // condition copies instead, and the ghost fill before the stage skips the x faces.  xkind[side] = LSM_BC_* of the x faces.
     int xredirect;
     int xkind[2];
+    int yredirect;     // the same for dimension 2 of a 3-D grid (the tile's y): its ghost rows are skipped by the fills as well
+    int ykind[2];
     const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
@@ -104,6 +106,7 @@ struct GhostAllArgs {
     int mb, me;        // planes [mb, me) of the last dimension whose lower-dimension ghosts are filled
     int fill_last;     // also fill the (physical) ghosts of the last dimension
     int skip_x;        // leave the ghost nodes at the ends of the interior rows alone (StageArgs::xredirect: nobody reads them)
+    int skip_y;        // 3-D: leave the ghost rows of dimension 2 of the interior planes alone (StageArgs::yredirect)
 };
 
 struct CflArgs {

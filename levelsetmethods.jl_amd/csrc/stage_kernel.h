@@ -700,8 +700,15 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : nx - 1;
         return side == 0 ? k : (nx - 1) - k;
     };
+    auto ysrc = [&](int i) {
+        if (!HAS_Y || !a.yredirect || (i >= 0 && i < ny)) return i;
+        const int side = i < 0 ? 0 : 1, k = side == 0 ? -i : i - (ny - 1), kind = a.ykind[side];
+        if (kind == LSM_BC_PERIODIC) return side == 0 ? (ny - 1) - k : k;
+        if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : ny - 1;
+        return side == 0 ? k : (ny - 1) - k;
+    };
     const int lxg = xsrc(gx < nx + G ? gx : nx + G - 1);
-    const int lyg = HAS_Y ? (gy < ny + G ? gy : ny + G - 1) : 0;
+    const int lyg = HAS_Y ? ysrc(gy < ny + G ? gy : ny + G - 1) : 0;
     // unsigned in-plane offset from the plane's lowest (ghost) corner: with a wave-uniform base this
     // selects the SGPR-base + 32-bit-VGPR-offset addressing mode (no 64-bit vector address arithmetic)
     const long long corner = a.origin - G - (HAS_Y ? (long long)G * sy : 0);
@@ -739,7 +746,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         int Y = 0;
         if (HAS_Y) {
             Y = by0 - G + ly;
-            Y = Y > ny + G - 1 ? ny + G - 1 : Y;
+            Y = ysrc(Y > ny + G - 1 ? ny + G - 1 : Y);
         }
         hl[h] = ly * W + lx;
         hg[h] = (unsigned)sizeof(ST) * ((unsigned)(X + G) + (unsigned)(Y + (HAS_Y ? G : 0)) * (unsigned)sy);   // bytes
