@@ -268,7 +268,14 @@ INTEG = {"fe": 0, "rk2": 1, "rk3": 2}
 
 @pytest.mark.parametrize("mode", ["strict", "fast"])
 @pytest.mark.parametrize("integ", ["fe", "rk2", "rk3"])
-@pytest.mark.parametrize("shape,bcspec", [((64,), "periodic"), ((33, 30), ("extrapolation", 2)), ((21, 19, 17), "neumann")])
+@pytest.mark.parametrize("shape,bcspec", [
+    ((64,), "periodic"), ((33, 30), ("extrapolation", 2)), ((21, 19, 17), "neumann"),
+    # FAST steps serve the ghosts of copy-type x / y faces from the loads (include/lsm.h): every kind, per face, with partial tiles
+    ((70, 20), "neumann"), ((45, 33), "periodic"), ((40, 18, 12), "periodic"), ((37, 21, 9), "symmetry"),
+    ((36, 17, 11), [("neumann", "symmetry"), "periodic", ("extrapolation", 2)]),      # x and y from the loads, z weighted
+    ((36, 17, 11), [("extrapolation", 2), ("symmetry", "neumann"), "neumann"]),         # x weighted: nothing redirected
+    ((67, 13, 10), ["periodic", ("extrapolation", 3), "symmetry"]),                     # x only
+], ids=lambda v: str(v).replace(" ", ""))
 def test_advance_matches_literal_reference_loop(hip, orc, mode, integ, shape, bcspec):
     """lsm_advance_* (fused stages, in-place final stage, materialised ghosts) == the literal
     term-by-term _advance! of the oracle (dense arrays, recursive ghost resolution)."""
