@@ -692,21 +692,20 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     // inactive threads of a partial tile still feed the tile: they load their own (ghost) position
     // while it lies inside the padded array; coefficient lookups use the interior-clamped index.
     const int cx = gx < nx ? gx : nx - 1, cy = gy < ny ? gy : ny - 1;
-    // StageArgs::xredirect: the node a load of x-index i (possibly a ghost) is served from
-    auto xsrc = [&](int i) {
-        if (!a.xredirect || (i >= 0 && i < nx)) return i;
-        const int side = i < 0 ? 0 : 1, k = side == 0 ? -i : i - (nx - 1), kind = a.xkind[side];
-        if (kind == LSM_BC_PERIODIC) return side == 0 ? (nx - 1) - k : k;
-        if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : nx - 1;
-        return side == 0 ? k : (nx - 1) - k;
+    // StageArgs::xredirect / yredirect: the node a load of index i (possibly a ghost) is served from.  Only tiles that reach
+    // past a face take the map (a scalar branch); the kinds are read into scalars first (indexing the argument block with a
+    // per-lane side would loop over the lanes).
+    const int xk0 = a.xkind[0], xk1 = a.xkind[1], yk0 = a.ykind[0], yk1 = a.ykind[1];
+    const bool xmap = a.xredirect && (bx0 < G || bx0 + TX + G > nx);
+    const bool ymap = HAS_Y && a.yredirect && (by0 < G || by0 + TY + G > ny);
+    auto bsrc = [](int i, int n, int k0, int k1) {
+        const bool left = i < 0;
+        const int k = left ? -i : i - (n - 1), kind = left ? k0 : k1;
+        const int per = left ? (n - 1) - k : k, ext = left ? 0 : n - 1, sym = left ? k : (n - 1) - k;
+        return kind == LSM_BC_PERIODIC ? per : (kind == LSM_BC_EXTRAPOLATION ? ext : sym);
     };
-    auto ysrc = [&](int i) {
-        if (!HAS_Y || !a.yredirect || (i >= 0 && i < ny)) return i;
-        const int side = i < 0 ? 0 : 1, k = side == 0 ? -i : i - (ny - 1), kind = a.ykind[side];
-        if (kind == LSM_BC_PERIODIC) return side == 0 ? (ny - 1) - k : k;
-        if (kind == LSM_BC_EXTRAPOLATION) return side == 0 ? 0 : ny - 1;
-        return side == 0 ? k : (ny - 1) - k;
-    };
+    auto xsrc = [&](int i) { return (!xmap || (i >= 0 && i < nx)) ? i : bsrc(i, nx, xk0, xk1); };
+    auto ysrc = [&](int i) { return (!ymap || (i >= 0 && i < ny)) ? i : bsrc(i, ny, yk0, yk1); };
     const int lxg = xsrc(gx < nx + G ? gx : nx + G - 1);
     const int lyg = HAS_Y ? ysrc(gy < ny + G ? gy : ny + G - 1) : 0;
     // unsigned in-plane offset from the plane's lowest (ghost) corner: with a wave-uniform base this
