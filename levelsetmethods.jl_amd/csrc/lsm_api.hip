@@ -113,6 +113,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->prof = false; h->ev_used = 0;
     h->comm = nullptr;
     h->d_stamp = nullptr;
+    h->d_tail_ctr = nullptr; h->tail_ticket = 0;
     h->xredirect = false;
     h->yredirect = false;
     h->cfl_cache_on = true;
@@ -184,6 +185,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     h->own_stream = true;
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_partial, sizeof(double) * 2 * MAXB);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_tail_ctr, 64);
+    if (e == hipSuccess) e = hipMemset(h->d_tail_ctr, 0, 64);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_flag, sizeof(int));
     h->cfl_stream = nullptr; h->c_partial = h->c_result = h->ch_result = nullptr; h->c_flag = nullptr;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cfl_stream, hipStreamNonBlocking);
@@ -209,6 +212,7 @@ void lsm_destroy(LsmHandle* h) {
     (void)lsm_comm_detach(h);
     (void)hipSetDevice(h->device);
     if (h->d_stamp) (void)hipFree(h->d_stamp);
+    if (h->d_tail_ctr) (void)hipFree(h->d_tail_ctr);
     (void)hipStreamSynchronize(h->stream);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
@@ -349,6 +353,8 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     a.f32 = is_f32(h);
+    a.tail_ctr = h->d_tail_ctr; a.tail_base = 0; a.tail_wgs = 0;
+    a.tail_ticket_host = const_cast<unsigned*>(&h->tail_ticket);
     a.xredirect = h->xredirect ? 1 : 0;
     a.xkind[0] = h->bc[0][0].kind; a.xkind[1] = h->bc[0][1].kind;
     a.yredirect = h->yredirect ? 1 : 0;

@@ -65,6 +65,8 @@ struct LsmHandle {
     size_t ev_used;
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
+    unsigned* d_tail_ctr;          // ticket counter of the dynamic tail (never reset: launches pass their base)
+    unsigned tail_ticket;          // host: next base
     bool xredirect;                // set around the stages of a whole-grid lsm_advance_*: x ghosts are resolved by the stage kernel's loads
     unsigned long long* d_stamp;   // diagnostic build (-DLSM_STAMP): 8192 x {Δs_memtime, Δs_memrealtime, start, end} of the stage kernel's workgroups
 };

@@ -71,6 +71,13 @@ struct StageArgs {
     // x ghosts resolved by the loads themselves (set by the whole-grid lsm_advance_* in FAST mode when both x faces copy ONE
     // node: periodic / symmetry / degree-0 extrapolation): a load of a node with x outside [0, n0) goes to the node the boundary
     // condition copies instead, and the ghost fill before the stage skips the x faces.  xkind[side] = LSM_BC_* of the x faces.
+    // dynamic tail (set by the launcher when the graded tail is on and the handle lends its counter): the workgroups behind
+    // the long chunks take the short chunks in the order they START, through one ticket counter — the eight XCDs get equal
+    // numbers of workgroups from the hardware but do not run at the same speed; 30 % spare tail workgroups let the faster
+    // ones take more of the tail.  ticket = atomicAdd(tail_ctr, 1) - tail_base; tickets past the last short chunk leave.
+    unsigned* tail_ctr;
+    unsigned tail_base, tail_wgs;
+    unsigned* tail_ticket_host;        // host side: the handle's running ticket base (advanced by tail_wgs per launch)
     int xredirect;
     int xkind[2];
     int yredirect;     // the same for dimension 2 of a 3-D grid (the tile's y): its ghost rows are skipped by the fills as well

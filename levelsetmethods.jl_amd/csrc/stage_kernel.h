@@ -629,6 +629,9 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #endif
 // A/B switches: the ring (and the unrolled plane loop) for every 3-D FAST kernel, not only the WENO5 ones; and PFX extra
 // planes of ψ in flight (ring of 2G+1+PFX entries: the newest PFX+1 are loads that have not been waited for yet)
+#ifndef LSM_STAGE_TAIL_DYN_DEFAULT
+#define LSM_STAGE_TAIL_DYN_DEFAULT 25 // dynamic tail: % of spare tail workgroups (0 = off; LSM_STAGE_TAIL_DYN overrides at run time)
+#endif
 #ifndef LSM_STAGE_TAIL_DEFAULT
 #define LSM_STAGE_TAIL_DEFAULT 16  // planes per chunk of the graded tail (0 = off; LSM_STAGE_TAIL overrides at run time)
 #endif
@@ -953,7 +956,17 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     const TileOrder ord(a);
     unsigned tile_id;
     bool tail_tile;
-    if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail_tile)) return;   // whole workgroup leaves before any barrier
+    if (NDIM == 3 && !MASKED && a.tail_wgs && blockIdx.x >= 8u * ord.big_per) {      // dynamic tail (StageArgs::tail_ctr)
+        __shared__ unsigned s_ticket;
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.tail_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.tail_base;
+        __syncthreads();
+        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
+        if (t >= ord.ntiles - ord.nbigt) return;
+        tile_id = ord.nbigt + t;
+        tail_tile = true;
+    } else if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail_tile)) {
+        return;   // whole workgroup leaves before any barrier
+    }
     stage_tile<NDIM, ADV, NM, CURV, EIK, TX, TY, MC, ST, AK, MASKED>(a, tile_id, tail_tile, blockIdx.x);
 }
 
@@ -1046,9 +1059,18 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
+    b.tail_wgs = 0;
     if (b.mc_tail > 0) {
         const unsigned nbigt = b.nb[0] * b.nb[1] * b.nbig;
         grid.x = 8u * ((nbigt + 7u) / 8u + (ntiles - nbigt + 7u) / 8u);
+        static const int dyn_env = getenv("LSM_STAGE_TAIL_DYN") ? atoi(getenv("LSM_STAGE_TAIL_DYN")) : LSM_STAGE_TAIL_DYN_DEFAULT;
+        if (dyn_env > 0 && a.tail_ctr && a.tail_ticket_host && nbigt % 8u == 0) {
+            const unsigned ntail = ntiles - nbigt;
+            b.tail_wgs = ((ntail + ntail * (unsigned)dyn_env / 100u) + 7u) / 8u * 8u;      // dyn_env % spare workgroups
+            b.tail_base = *a.tail_ticket_host;
+            *a.tail_ticket_host += b.tail_wgs;
+            grid.x = nbigt + b.tail_wgs;
+        }
     }
     // plain variant (see plane_tab): dense field, one output, terms in slot order, constant speed / curvature
     // coefficients, and a catalogued advection coefficient
