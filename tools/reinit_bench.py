@@ -13,7 +13,7 @@ import torch
 import lsm_amd as lsm
 
 
-def run(n, band, reps=3):
+def run(n, band, reps=8):
     grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
     f = lambda x: (x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.25          # not a distance function
     vals = lsm.LazyMeshField(f, grid).local_values(None)

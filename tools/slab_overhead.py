@@ -24,7 +24,7 @@ import lsm_amd as lsm
 def run_whole(n, steps):
     eq, _, _ = bench.build_equation(lsm, n, None, 0, "fast")
     tc = 0.0
-    for _ in range(2):
+    for _ in range(12):          # out of the device's idle power state (≈50 ms of load)
         tc = bench.one_step(eq, tc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -44,7 +44,7 @@ def run_slabs(n, steps, overlap, world=2):
             eq, _, _ = bench.build_equation(lsm, n, g.rank(r), 0, "fast")
             eq.backend.comm_set_overlap(overlap)
             tc = 0.0
-            for _ in range(2):
+            for _ in range(12):
                 tc = bench.one_step(eq, tc)
             torch.cuda.synchronize()
             bar.wait()
