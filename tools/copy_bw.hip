@@ -27,7 +27,7 @@ template <class F>
 double time_ms(F f, int reps = 20) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) f();
+    for (int i = 0; i < 200; ++i) f();   // ≈70 ms of load first: the device leaves its idle power state
     (void)hipEventRecord(e0);
     for (int i = 0; i < reps; ++i) f();
     (void)hipEventRecord(e1);
