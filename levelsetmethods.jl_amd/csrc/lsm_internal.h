@@ -68,6 +68,7 @@ struct StageArgs {
     // over the duration of a short workgroup instead of a long one
     unsigned nbig;
     int mc_tail;
+    int yfast;         // dense 3-D launches: the tiles of a chunk layer are numbered y-fastest (set by the launcher)
     // x ghosts resolved by the loads themselves (set by the whole-grid lsm_advance_* in FAST mode when both x faces copy ONE
     // node: periodic / symmetry / degree-0 extrapolation): a load of a node with x outside [0, n0) goes to the node the boundary
     // condition copies instead, and the ghost fill before the stage skips the x faces.  xkind[side] = LSM_BC_* of the x faces.

@@ -629,6 +629,9 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #endif
 // A/B switches: the ring (and the unrolled plane loop) for every 3-D FAST kernel, not only the WENO5 ones; and PFX extra
 // planes of ψ in flight (ring of 2G+1+PFX entries: the newest PFX+1 are loads that have not been waited for yet)
+#ifndef LSM_STAGE_YFAST_DEFAULT
+#define LSM_STAGE_YFAST_DEFAULT 0     // dense 3-D launches: tiles of a layer numbered y-fastest (LSM_STAGE_YFAST overrides at run time)
+#endif
 #ifndef LSM_STAGE_TAIL_DYN_DEFAULT
 #define LSM_STAGE_TAIL_DYN_DEFAULT 25 // dynamic tail: % of spare tail workgroups (0 = off; LSM_STAGE_TAIL_DYN overrides at run time)
 #endif
@@ -679,9 +682,20 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
 #endif
     if (a.tile_list) tile_id = (unsigned)a.tile_list[tile_id];
     else if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
-    const unsigned tbx = tile_id % a.nb[0];
-    const unsigned tby = (tile_id / a.nb[0]) % a.nb[1];
+    // dense 3-D launches number the tiles of a layer y-fastest (StageArgs::yfast): workgroups dispatched one after the other are
+    // then y-neighbours — they start together, march in phase and find each other's rows (6 of the 14 a tile loads per plane)
+    // in the XCD's L2.  Band tile flags and lists keep the x-fastest numbering.
+    const int yf = NDIM == 3 ? a.yfast : 0;
+    unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1];
     const unsigned tbm = tile_id / (a.nb[0] * a.nb[1]);
+    if (yf == 1) {
+        tbx = (tile_id / a.nb[1]) % a.nb[0];
+        tby = tile_id % a.nb[1];
+    } else if (yf >= 2) {            // blocks of yf x yf tiles (extents divisible by yf: checked by the launcher)
+        const unsigned B = (unsigned)yf, inl = tile_id % (a.nb[0] * a.nb[1]), blk = inl / (B * B), w = inl % (B * B), bpr = a.nb[0] / B;
+        tbx = (blk % bpr) * B + w % B;
+        tby = (blk / bpr) * B + w / B;
+    }
 
     const int tid = threadIdx.x;
     const int tx = tid % TX, ty = tid / TX;
@@ -1059,6 +1073,11 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
+    {
+        static const int yfast_env = getenv("LSM_STAGE_YFAST") ? atoi(getenv("LSM_STAGE_YFAST")) : LSM_STAGE_YFAST_DEFAULT;
+        b.yfast = (NDIM == 3 && yfast_env && !a.mask && !a.tile_list && !a.tile_active) ? yfast_env : 0;
+        if (b.yfast >= 2 && (b.nb[0] % (unsigned)b.yfast || b.nb[1] % (unsigned)b.yfast)) b.yfast = 0;
+    }
     b.tail_wgs = 0;
     if (b.mc_tail > 0) {
         const unsigned nbigt = b.nb[0] * b.nb[1] * b.nbig;
