@@ -37,7 +37,9 @@ enum {
     LSM_OK = 0,
     LSM_ERR_INVALID = -1,    /* bad argument / unsupported combination */
     LSM_ERR_HIP = -2,        /* a HIP runtime call failed */
-    LSM_ERR_NO_DEVICE = -3
+    LSM_ERR_NO_DEVICE = -3,
+    LSM_ERR_COMM = -4        /* multi-GPU: a peer rank left / aborted / did not answer in time, or RCCL failed; the
+                                communicator stays failed (lsm_comm_detach + a new attach to go on) */
 };
 
 /* CartesianGrid (src/meshes.jl:1-5): lower/upper corner and node counts of the GLOBAL grid.
@@ -252,6 +254,27 @@ int lsm_halo_start(LsmHandle* h, void* field);
 int lsm_halo_wait(LsmHandle* h);
 int lsm_halo_exchange(LsmHandle* h, void* field);                    /* start + wait */
 int lsm_allreduce_dt(LsmHandle* h, double* dt /* in: local, out: global */);   /* synchronous */
+/* Failure: no call above blocks for ever.  When a rank leaves its group (lsm_comm_detach / lsm_destroy), calls lsm_comm_abort,
+ * or does not show up within LSM_COMM_TIMEOUT_MS (environment, default 60000), every unfinished wait of the other ranks —
+ * lsm_halo_wait, lsm_allreduce_dt, the slab lsm_advance_* — returns LSM_ERR_COMM, and so does every later call on that
+ * communicator.  lsm_comm_abort may be called from any thread (e.g. by the rank whose update hook threw). */
+int lsm_comm_abort(LsmHandle* h);
+
+/* Slab-decomposed NarrowBandMeshField (BASELINE config 5's decomposition).  The band's operations reach farther across a slab
+ * interface than a stencil does (nearest band node within 6 nodes, its slope neighbour, the stencil's 3:
+ * src/meshfield.jl:481-530), so every rank creates its slab `overlap` planes larger towards each neighbouring rank (>= 10;
+ * LsmSlab.lo / n describe the EXTENDED slab); the extra planes are ordinary planes of the slab, computed redundantly — right
+ * on the owned planes — and refreshed from their owners:
+ *   lsm_band_overlap_config  declares the overlap depth (after attaching the communicator)
+ *   lsm_band_overlap_mask    after every lsm_band_update: the overlap planes of the byte mask from their owners (whole planes),
+ *                            after which both sides list the band nodes of the exchanged planes in index order (no index
+ *                            travels).  Synchronous.  Follow with lsm_band_overlap_values(vals), lsm_band_retile,
+ *                            lsm_band_status, lsm_band_halo.
+ *   lsm_band_overlap_values  after every stage (lsm_advance_band_* does it itself): the values of those band nodes, packed —
+ *                            ~0.4 MB instead of 48 MB per direction at 768^3.  The handle's stream waits; no host sync with RCCL. */
+int lsm_band_overlap_config(LsmHandle* h, int64_t overlap);
+int lsm_band_overlap_mask(LsmHandle* h, void* mask);
+int lsm_band_overlap_values(LsmHandle* h, void* field);
 
 /* ---- EikonalReinitializationTerm(ϕ₀) constructor map: S0 = v/sqrt(v^2+Δx^2) (src/levelsetterms.jl:217-221) */
 int lsm_eikonal_sign(LsmHandle* h, const void* phi0, void* s0_out, void* stream);
@@ -383,6 +406,31 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
                    const void* tiles, int mc, void* stream);
 int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask,
                          const void* tiles, int mc, double t, double* dt_out);
+
+/* ---- _advance!(integrator, ϕ::NarrowBandMeshField, buffers, terms, tc, Δt): the reference steps a band with the same
+ *      _advance! as a dense field (src/timestepping.jl:128-137,143-164,170-202), its node loop running over
+ *      active_nodeindices (src/meshfield.jl:330-333) and its stencil reads outside the band answered by
+ *      _extrapolate_to_ghost (:481-511).  Here: per stage lsm_band_prepare on the stage input, then lsm_stage_band; the
+ *      integrator's combinations as in lsm_advance_*.  LsmBand names what lsm_band_update maintains for the field (all
+ *      caller-owned device buffers).  phi / buf1 / buf2 are padded value arrays; their off-band entries are scratch (buffers
+ *      need no initialisation).  The hook runs before each stage with the PREPARED stage input, stream synchronised.  On a
+ *      slab with lsm_band_overlap_config the overlap planes of every stage result are refreshed from their owners
+ *      (lsm_band_overlap_values).  Follow an accepted step with lsm_band_update (update_band!, src/timestepping.jl:115). */
+typedef struct LsmBand {
+    void* mask;                   /* byte mask of the active nodes (LsmLayout.total bytes) */
+    void* tiles;                  /* per-tile activity flags (lsm_band_tile_count bytes) */
+    int32_t mc;                   /* planes per tile along the last dimension */
+    int32_t _pad;
+    void* halo_list;              /* lsm_band_update / lsm_band_halo: (halo node, nearest band node) entries, 16 bytes each */
+    int64_t halo_cap;
+    void* halo_count;             /* device uint32 */
+} LsmBand;
+int lsm_advance_band_fe(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1,
+                        double tc, double dt, LsmStageHook hook, void* user);
+int lsm_advance_band_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1, void* buf2,
+                         double tc, double dt, LsmStageHook hook, void* user);
+int lsm_advance_band_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1, void* buf2,
+                         double tc, double dt, LsmStageHook hook, void* user);
 
 /* ---- reinitialize!(ϕ; order = 3, upsample = 2, maxiters = 20, xtol, ftol) (src/reinitializer.jl:12-42):
  *      every active node (every node when mask == NULL, the band nodes otherwise) is overwritten with

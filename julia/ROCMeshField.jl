@@ -220,7 +220,8 @@ _coeff(f::ROCMeshField, ϕ, t, K) = LsmCoeff(3, 0, 1.0, (0.0, 0.0, 0.0, 0.0), (P
 _coeff(fs::Tuple{Vararg{ROCMeshField}}, ϕ, t, K) =
     LsmCoeff(3, 0, 1.0, (0.0, 0.0, 0.0, 0.0), _pad3(map(f -> Ptr{Cvoid}(pointer(_f64(f, ϕ))), fs), C_NULL), _NOSEP)
 # a closure f(x, t) -> Number | SVector: K components sampled at the local nodes, uploaded into arrays that live as long as ϕ's handle
-function _coeff(f::Function, ϕ::ROCMeshField{N}, t, K) where {N}
+function _coeff(f::Function, ϕ, t, K)      # ϕ::ROCField (dense or band: both carry mesh, h, samples)
+    N = length(ϕ.mesh.n)
     arrs = get!(() -> [AMDGPU.zeros(Float64, ϕ.h.layout.total) for _ in 1:K], ϕ.samples, objectid(f))
     nloc = ntuple(d -> Int(ϕ.h.layout.n[d]), N)
     off = ntuple(d -> d == N ? ϕ.h.lo : 0, N)                   # a slab's nodes sit at global indices lo+1 : lo+n
@@ -238,7 +239,7 @@ function _coeff(f::Function, ϕ::ROCMeshField{N}, t, K) where {N}
 end
 _needs_sampling(c) = c isa Function
 
-_term(t::LSM.AdvectionTerm, ϕ::ROCMeshField{N}, tt) where {N} = LsmTerm(0, LSM.scheme(t) isa LSM.WENO5 ? 1 : 0, _coeff(LSM.velocity(t), ϕ, tt, N), C_NULL)
+_term(t::LSM.AdvectionTerm, ϕ, tt) = LsmTerm(0, LSM.scheme(t) isa LSM.WENO5 ? 1 : 0, _coeff(LSM.velocity(t), ϕ, tt, length(ϕ.mesh.n)), C_NULL)
 _term(t::LSM.NormalMotionTerm, ϕ, tt) = LsmTerm(1, 0, _coeff(LSM.speed(t), ϕ, tt, 1), C_NULL)
 _term(t::LSM.CurvatureTerm, ϕ, tt) = LsmTerm(2, 0, _coeff(LSM.coefficient(t), ϕ, tt, 1), C_NULL)
 _term(t::LSM.EikonalReinitializationTerm{Nothing}, ϕ, tt) = LsmTerm(3, 0, _coeff(0.0, ϕ, tt, 1), C_NULL)
@@ -454,41 +455,131 @@ function LSM.reinitialize!(ϕ::ROCMeshField; order = 3, upsample = 2, maxiters =
     return ϕ
 end
 
-# NarrowBandMeshField on the device (src/meshfield.jl:314-588): dense padded values + byte masks.
-const BAND_MC = 8
+# ---- NarrowBandMeshField on the device (src/meshfield.jl:314-588): dense padded values + byte masks --------------------
+# The reference steps a band field with the SAME _advance! / compute_cfl / update_band! sequence as a dense one
+# (src/timestepping.jl:101-122,126-202; src/meshfield.jl:555-588); the methods below are that sequence for a device band.
+const BAND_MC = 8             # planes per tile along the last dimension
+const BAND_OVERLAP = 10       # planes of each neighbouring rank a slab of a band holds (include/lsm.h, lsm_band_overlap_config)
 mutable struct ROCNarrowBandMeshField{N, T, B, S} <: LSM.AbstractMeshField{N, T, S}
-    buf::ROCVector{S}; mesh::CartesianGrid{N, T}; bcs::B; h::Handle
+    buf::ROCVector{S}
+    mesh::LSM.CartesianGrid{N, T}
+    bcs::B
+    h::Handle
+    samples::Dict{UInt, Vector{ROCVector{Float64}}}
     nlayers::Int
-    mask::ROCVector{UInt8}; halo::ROCVector{UInt8}; tiles::ROCVector{UInt8}
+    mask::ROCVector{UInt8}
+    halo::ROCVector{UInt8}
+    tiles::ROCVector{UInt8}
     scratch::NTuple{2, ROCVector{UInt8}}
-    hlist::ROCVector{Int64}; hcount::ROCVector{UInt32}     # (halo node -> nearest band node) entries, 2 Int64 each
+    hlist::ROCVector{Int64}       # (halo node -> nearest band node) entries, 2 Int64 each
+    hcount::ROCVector{UInt32}
+    own::Tuple{Int, Int}          # (first local plane, count) of the planes this rank owns; the rest are overlap planes
+end
+const ROCField = Union{ROCMeshField, ROCNarrowBandMeshField}
+
+function _tile_count(h::Handle)
+    n = Ref{Int64}()
+    _check(h.ptr, ccall((:lsm_band_tile_count, libhiplsm), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), h.ptr, BAND_MC, n), "lsm_band_tile_count")
+    return Int(n[])
+end
+function _empty_band(buf::ROCVector{S}, mesh::LSM.CartesianGrid{N, T}, bcs, h, nlayers, own) where {N, T, S}
+    total = h.layout.total
+    bytes() = AMDGPU.zeros(UInt8, total)
+    return ROCNarrowBandMeshField{N, T, typeof(bcs), S}(buf, mesh, bcs, h, Dict{UInt, Vector{ROCVector{Float64}}}(), nlayers, bytes(), bytes(),
+        AMDGPU.zeros(UInt8, _tile_count(h)), (bytes(), bytes()), ROCVector{Int64}(undef, 2 * (1 << 16)), AMDGPU.zeros(UInt32, 1), own)
 end
 
-# update_band!(ϕ) (src/timestepping.jl:115)
-function LSM.update_band!(ϕ::ROCNarrowBandMeshField; from_dense = false)
-    while true
-        _check(ϕ.h.ptr, ccall((:lsm_band_update, libhiplsm), Cint,
-            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
-            ϕ.h.ptr, pointer(ϕ.buf), pointer(ϕ.mask), from_dense, ϕ.nlayers, pointer(ϕ.scratch[1]), pointer(ϕ.scratch[2]),
-            pointer(ϕ.halo), pointer(ϕ.tiles), BAND_MC, pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount)), "lsm_band_update")
-        want, missed = Ref{Int64}(), Ref{Cint}()
-        _check(ϕ.h.ptr, ccall((:lsm_band_status, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}, Ref{Cint}),
-            ϕ.h.ptr, pointer(ϕ.hcount), want, missed), "lsm_band_status")
-        missed[] != 0 && throw(ArgumentError("index is more than $(LSM._BAND_SEARCH_RADIUS) nodes from the band"))   # src/meshfield.jl:499-500
-        want[] <= length(ϕ.hlist) ÷ 2 && return ϕ
-        ϕ.hlist = ROCVector{Int64}(undef, 4 * want[])       # list too short: grow it, derive the halo again
-        from_dense = false
+# NarrowBandMeshField(ϕ; nlayers) (src/meshfield.jl:411-440) on the device.  slab = (lo, n, rank, world): the OWNED planes;
+# the handle's slab is extended by BAND_OVERLAP planes of each neighbour (attach a communicator, then band_overlap!).
+function ROCNarrowBandMeshField(nb::LSM.NarrowBandMeshField{N, T}; strict = false, slab = nothing) where {N, T}
+    bcs = LSM.boundary_conditions(nb)
+    any(bc -> bc isa LSM.PeriodicBC, Iterators.flatten(bcs)) && throw(ArgumentError("PeriodicBC is not supported on a NarrowBandMeshField"))
+    dense = LSM.MeshField(nb)                      # every node: the band is re-derived on the device (from_dense)
+    S = eltype(values(dense))
+    ext, own = slab, (0, LSM.mesh(nb).n[N])
+    if slab !== nothing
+        lo, n, rank, world = slab
+        wlo, whi = rank > 0 ? BAND_OVERLAP : 0, rank < world - 1 ? BAND_OVERLAP : 0
+        ext, own = (lo - wlo, n + wlo + whi, rank, world), (wlo, n)
     end
+    h = Handle(LSM.mesh(nb), bcs, S; strict, slab = ext)
+    ϕ = _empty_band(AMDGPU.zeros(S, h.layout.total), LSM.mesh(nb), bcs, h, nb.nlayers, own)
+    _check(h.ptr, ccall((:lsm_upload, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, pointer(ϕ.buf), _local(values(dense), ext)), "lsm_upload")
+    slab === nothing && LSM.update_band!(ϕ; from_dense = true)     # a slab builds its band in band_overlap!, once attached
+    return ϕ
+end
+# after attach_rccl! / attach_local! on the band fields of all ranks: declare the overlap, build the band, take the overlap
+# planes from their owners
+function band_overlap!(ϕ::ROCNarrowBandMeshField)
+    _check(ϕ.h.ptr, ccall((:lsm_band_overlap_config, libhiplsm), Cint, (Ptr{Cvoid}, Int64), ϕ.h.ptr, BAND_OVERLAP), "lsm_band_overlap_config")
+    return LSM.update_band!(ϕ; from_dense = true)
+end
+attach_rccl!(ϕ::ROCNarrowBandMeshField, id::Vector{UInt8}) =
+    (_check(ϕ.h.ptr, ccall((:lsm_comm_attach_rccl, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), ϕ.h.ptr, id, ϕ.h.rank, ϕ.h.world), "lsm_comm_attach_rccl"); band_overlap!(ϕ))
+# a rank whose hook threw: the other ranks' exchanges return LSM_ERR_COMM instead of waiting for it
+comm_abort!(ϕ::ROCField) = _check(ϕ.h.ptr, ccall((:lsm_comm_abort, libhiplsm), Cint, (Ptr{Cvoid},), ϕ.h.ptr), "lsm_comm_abort")
+
+# a copy shares the handle; the band set travels with it (the Dict copy of src/meshfield.jl:420-423)
+function Base.copy(ϕ::ROCNarrowBandMeshField{N, T, B, S}) where {N, T, B, S}
+    return ROCNarrowBandMeshField{N, T, B, S}(copy(ϕ.buf), ϕ.mesh, ϕ.bcs, ϕ.h, ϕ.samples, ϕ.nlayers, copy(ϕ.mask), copy(ϕ.halo), copy(ϕ.tiles),
+        (similar(ϕ.mask), similar(ϕ.mask)), copy(ϕ.hlist), copy(ϕ.hcount), ϕ.own)
+end
+function Base.copy!(dst::ROCNarrowBandMeshField, src::ROCNarrowBandMeshField)      # src/meshfield.jl:282-292: values AND keys
+    copyto!(dst.buf, src.buf); copyto!(dst.mask, src.mask); copyto!(dst.halo, src.halo); copyto!(dst.tiles, src.tiles)
+    dst.hlist = copy(src.hlist); copyto!(dst.hcount, src.hcount)
+    return dst
+end
+function Base.values(ϕ::ROCNarrowBandMeshField{N, T, B, S}) where {N, T, B, S}
+    out = Array{S, N}(undef, ntuple(d -> Int(ϕ.h.layout.n[d]), N))
+    _check(ϕ.h.ptr, ccall((:lsm_download, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), ϕ.h.ptr, pointer(ϕ.buf), out), "lsm_download")
+    return out
 end
 
-# one stage input made readable by stencils, then the band-restricted stage (what _advance! loops over)
-function _band_stage!(ϕ::ROCNarrowBandMeshField, ts, psi, phin, out, out2, mode, cdt, cdt2, t)
-    _check(ϕ.h.ptr, ccall((:lsm_band_prepare, libhiplsm), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
-        ϕ.h.ptr, psi, pointer(ϕ.mask), pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount), pointer(ϕ.tiles), BAND_MC), "lsm_band_prepare")
-    _check(ϕ.h.ptr, ccall((:lsm_stage_band, libhiplsm), Cint,
-        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}),
-        ϕ.h.ptr, ts, length(ts), psi, phin, out, out2, mode, cdt, cdt2, t, pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, C_NULL), "lsm_stage_band")
+struct LsmBand
+    mask::Ptr{Cvoid}
+    tiles::Ptr{Cvoid}
+    mc::Int32
+    _pad::Int32
+    halo_list::Ptr{Cvoid}
+    halo_cap::Int64
+    halo_count::Ptr{Cvoid}
+end
+_band(ϕ::ROCNarrowBandMeshField) = Ref(LsmBand(pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, 0, pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount)))
+
+function _band_status(ϕ::ROCNarrowBandMeshField)
+    want, missed = Ref{Int64}(), Ref{Cint}()
+    _check(ϕ.h.ptr, ccall((:lsm_band_status, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}, Ref{Cint}),
+        ϕ.h.ptr, pointer(ϕ.hcount), want, missed), "lsm_band_status")
+    missed[] != 0 && throw(ArgumentError("index is more than $(LSM._BAND_SEARCH_RADIUS) nodes from the band"))   # src/meshfield.jl:499-500
+    return Int(want[])
+end
+_band_halo(ϕ::ROCNarrowBandMeshField) = _check(ϕ.h.ptr, ccall((:lsm_band_halo, libhiplsm), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+    ϕ.h.ptr, pointer(ϕ.buf), pointer(ϕ.mask), pointer(ϕ.halo), pointer(ϕ.tiles), BAND_MC, pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount)), "lsm_band_halo")
+
+# update_band!(ϕ) (src/timestepping.jl:115, src/meshfield.jl:555-588)
+function LSM.update_band!(ϕ::ROCNarrowBandMeshField; from_dense = false)
+    _check(ϕ.h.ptr, ccall((:lsm_band_update, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+        ϕ.h.ptr, pointer(ϕ.buf), pointer(ϕ.mask), from_dense, ϕ.nlayers, pointer(ϕ.scratch[1]), pointer(ϕ.scratch[2]),
+        pointer(ϕ.halo), pointer(ϕ.tiles), BAND_MC, pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount)), "lsm_band_update")
+    want = _band_status(ϕ)
+    if ϕ.h.world > 1
+        # slab: band set and new values are right only away from the cut faces — the overlap planes come from their owners
+        # (mask as whole planes, then only the band nodes' values), and tiles / lists / halo are re-derived from the full mask
+        _check(ϕ.h.ptr, ccall((:lsm_band_overlap_mask, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ϕ.h.ptr, pointer(ϕ.mask)), "lsm_band_overlap_mask")
+        _check(ϕ.h.ptr, ccall((:lsm_band_overlap_values, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ϕ.h.ptr, pointer(ϕ.buf)), "lsm_band_overlap_values")
+        _check(ϕ.h.ptr, ccall((:lsm_band_retile, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), ϕ.h.ptr, pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC), "lsm_band_retile")
+        _band_status(ϕ)
+        _band_halo(ϕ)
+        want = _band_status(ϕ)
+    end
+    while want > length(ϕ.hlist) ÷ 2               # list too short: grow it, derive the halo again
+        ϕ.hlist = ROCVector{Int64}(undef, 4 * want)
+        _band_halo(ϕ)
+        want = _band_status(ϕ)
+    end
+    return ϕ
 end
 
 function LSM.compute_cfl(terms, ϕ::ROCNarrowBandMeshField, t)
@@ -497,9 +588,53 @@ function LSM.compute_cfl(terms, ϕ::ROCNarrowBandMeshField, t)
     _check(ϕ.h.ptr, ccall((:lsm_compute_cfl_band, libhiplsm), Cint,
         (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ref{Float64}),
         ϕ.h.ptr, ts, length(ts), pointer(ϕ.buf), pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, t, dt), "lsm_compute_cfl_band")
+    ϕ.h.world > 1 && _check(ϕ.h.ptr, ccall((:lsm_allreduce_dt, libhiplsm), Cint, (Ptr{Cvoid}, Ref{Float64}), ϕ.h.ptr, dt), "lsm_allreduce_dt")
     Δt = dt[]
     Δt > 0 || throw(ArgumentError("invalid time-step based on CFL condition: Δt = $Δt (check for NaN/Inf in velocity or speed)"))
     return Δt
+end
+
+# buffers: value arrays only — their off-band entries are scratch, the band set is ϕ's (src/timestepping.jl:126,141,168 copy ϕ)
+_value_buffer(ϕ::ROCNarrowBandMeshField{N, T, B, S}) where {N, T, B, S} = ROCMeshField{N, T, B, S}(similar(ϕ.buf), ϕ.mesh, ϕ.bcs, ϕ.h, ϕ.samples)
+LSM._alloc_buffers(::LSM.ForwardEuler, ϕ::ROCNarrowBandMeshField) = (_value_buffer(ϕ),)
+LSM._alloc_buffers(::Union{LSM.RK2, LSM.RK3}, ϕ::ROCNarrowBandMeshField) = (_value_buffer(ϕ), _value_buffer(ϕ))
+
+# _advance! on a band (src/timestepping.jl:128-202 over active_nodeindices): lsm_advance_band_* prepares every stage input
+# (band halo by affine extrapolation, src/meshfield.jl:481-511, then the boundary ghosts), runs the band-restricted stages and,
+# on a slab, refreshes the overlap planes of every stage result
+function LSM._advance!(::LSM.ForwardEuler, ϕ::ROCNarrowBandMeshField, (dst,), terms, tc, Δt)
+    ts = [_term(term, ϕ, tc) for term in terms]
+    hook, band = _hook(terms, (ϕ,)), _band(ϕ)
+    GC.@preserve hook _check(ϕ.h.ptr, ccall((:lsm_advance_band_fe, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ref{LsmBand}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.h.ptr, ts, length(ts), band, pointer(ϕ.buf), pointer(dst.buf), tc, Δt, hook, C_NULL), "lsm_advance_band_fe")
+    return ϕ
+end
+function LSM._advance!(::LSM.RK2, ϕ::ROCNarrowBandMeshField, (pred, corr), terms, tc, Δt)
+    ts = [_term(term, ϕ, tc) for term in terms]
+    hook, band = _hook(terms, (ϕ, pred)), _band(ϕ)
+    GC.@preserve hook _check(ϕ.h.ptr, ccall((:lsm_advance_band_rk2, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ref{LsmBand}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.h.ptr, ts, length(ts), band, pointer(ϕ.buf), pointer(pred.buf), pointer(corr.buf), tc, Δt, hook, C_NULL), "lsm_advance_band_rk2")
+    return ϕ
+end
+function LSM._advance!(::LSM.RK3, ϕ::ROCNarrowBandMeshField, (buf1, buf2), terms, tc, Δt)
+    ts = [_term(term, ϕ, tc) for term in terms]
+    hook, band = _hook(terms, (ϕ, buf1, buf2)), _band(ϕ)
+    GC.@preserve hook _check(ϕ.h.ptr, ccall((:lsm_advance_band_rk3, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ref{LsmBand}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+        ϕ.h.ptr, ts, length(ts), band, pointer(ϕ.buf), pointer(buf1.buf), pointer(buf2.buf), tc, Δt, hook, C_NULL), "lsm_advance_band_rk3")
+    return ϕ
+end
+
+# one stage by hand (a driver of its own): the stage input made readable by stencils, then the band-restricted stage
+function _band_stage!(ϕ::ROCNarrowBandMeshField, ts, psi, phin, out, out2, mode, cdt, cdt2, t)
+    _check(ϕ.h.ptr, ccall((:lsm_band_prepare, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+        ϕ.h.ptr, psi, pointer(ϕ.mask), pointer(ϕ.hlist), length(ϕ.hlist) ÷ 2, pointer(ϕ.hcount), pointer(ϕ.tiles), BAND_MC), "lsm_band_prepare")
+    _check(ϕ.h.ptr, ccall((:lsm_stage_band, libhiplsm), Cint,
+        (Ptr{Cvoid}, Ptr{LsmTerm}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}),
+        ϕ.h.ptr, ts, length(ts), psi, phin, out, out2, mode, cdt, cdt2, t, pointer(ϕ.mask), pointer(ϕ.tiles), BAND_MC, C_NULL), "lsm_stage_band")
 end
 
 # usage (drop-in):

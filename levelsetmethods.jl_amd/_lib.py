@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 GHOST = 3
 MAX_TERMS = 8
-OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_COMM = 0, -1, -2, -3, -4
 BC_PERIODIC, BC_EXTRAPOLATION, BC_SYMMETRY, BC_NONE = 0, 1, 2, 3
 TERM_ADVECTION, TERM_NORMAL_MOTION, TERM_CURVATURE, TERM_EIKONAL = 0, 1, 2, 3
 SCHEME_UPWIND, SCHEME_WENO5 = 0, 1
@@ -55,6 +55,11 @@ class LsmCoeff(C.Structure):
 
 class LsmTerm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("scheme", C.c_int32), ("coeff", LsmCoeff), ("s0", C.c_void_p)]
+
+
+class LsmBand(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("tiles", C.c_void_p), ("mc", C.c_int32), ("_pad", C.c_int32), ("halo_list", C.c_void_p),
+                ("halo_cap", C.c_int64), ("halo_count", C.c_void_p)]
 
 
 BcArray = (LsmBc * 2) * 3
@@ -98,6 +103,16 @@ _SIGS = [
     ("lsm_halo_wait", C.c_int, [_H]),
     ("lsm_halo_exchange", C.c_int, [_H, C.c_void_p]),
     ("lsm_allreduce_dt", C.c_int, [_H, C.POINTER(C.c_double)]),
+    ("lsm_comm_abort", C.c_int, [_H]),
+    ("lsm_band_overlap_config", C.c_int, [_H, C.c_int64]),
+    ("lsm_band_overlap_mask", C.c_int, [_H, C.c_void_p]),
+    ("lsm_band_overlap_values", C.c_int, [_H, C.c_void_p]),
+    ("lsm_advance_band_fe", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.POINTER(LsmBand), C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                      StageHook, C.c_void_p]),
+    ("lsm_advance_band_rk2", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.POINTER(LsmBand), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                       C.c_double, StageHook, C.c_void_p]),
+    ("lsm_advance_band_rk3", C.c_int, [_H, C.POINTER(LsmTerm), C.c_int, C.POINTER(LsmBand), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                       C.c_double, StageHook, C.c_void_p]),
     ("lsm_eikonal_sign", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("lsm_extrema", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("lsm_check_range", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -191,7 +206,11 @@ class LsmError(RuntimeError):
     pass
 
 
+class LsmCommError(LsmError):
+    """LSM_ERR_COMM: a peer rank left, aborted or did not answer in time; the communicator stays failed."""
+
+
 def check(handle, code, what=""):
     if code != OK:
         msg = lib().lsm_last_error(handle)
-        raise LsmError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+        raise (LsmCommError if code == ERR_COMM else LsmError)(f"{what} failed ({code}): {msg.decode() if msg else ''}")

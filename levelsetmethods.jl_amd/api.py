@@ -993,11 +993,19 @@ class LocalGroup:
         self.world = int(world)
         self._barrier = threading.Barrier(self.world)
         self._slots = [None] * self.world
+        self._backends = []
 
     def rank(self, r):
         if not 0 <= r < self.world:
             raise ValueError("rank out of range")
         return _LocalRank(self, int(r))
+
+    def abort(self):
+        """A rank has failed: nobody may keep waiting for it — neither at this object's barrier nor inside the library
+        (lsm_comm_abort: the exchanges and the Δt all-reduce of the other ranks return LSM_ERR_COMM)."""
+        self._barrier.abort()
+        for b in self._backends:
+            b.comm_abort()
 
     def exchange(self, r, v):
         """all_gather_object among the ranks' threads."""
@@ -1021,8 +1029,8 @@ class LevelSetEquation:
     """LevelSetEquation(; terms, integrator = RK2(), ic, bc = nothing, t = 0) — src/levelsetequation.jl:59-78.
 
     Extra keywords of this implementation: mode ('fast' | 'strict' arithmetic), device, and
-    `comm` (a torch.distributed process group: the grid is then split into slabs of the last
-    dimension, one per rank, with ghost-plane exchange over RCCL)."""
+    `comm` (a torch.distributed process group, or a rank of an in-process LocalGroup: the grid is then split into
+    slabs of the last dimension, one per rank, with the ghost-plane exchange inside the library — RCCL or peer copies)."""
 
     def __init__(self, *, terms, ic, integrator=None, bc=None, t=0, mode="fast", device=0, comm=None, backend_factory=None):
         if isinstance(terms, LevelSetTerm):
@@ -1066,8 +1074,6 @@ class LevelSetEquation:
                 # every rank raises the same error (a rank failing alone would leave the others in their next collective):
                 # the periodic wrap sends planes shifted by one node, and a SymmetryBC end face reads LSM_GHOST planes inwards
                 raise ValueError(f"a slab needs at least {L.GHOST + 1} planes: {nl} planes over {self.world} ranks leave {min(counts)}")
-            if isinstance(ic, NarrowBandMeshField) and self.world > 1 and isinstance(comm, _LocalRank):
-                raise ValueError("a slab-decomposed NarrowBandMeshField needs a torch.distributed group (its sparse plane exchange runs there)")
             if isinstance(ic, NarrowBandMeshField) and self.world > 1:
                 # a band needs its neighbours' mask AND values up to 7 planes deep (nearest band node within 6, its
                 # slope neighbour) plus the stencil reach: every rank keeps BAND_OVERLAP planes of its neighbours as
@@ -1106,9 +1112,15 @@ class LevelSetEquation:
         # (lsm_comm_attach_rccl / _local); torch.distributed only carries the RCCL unique id to the ranks
         self.lib_comm = False
         import os as _os
-        if (comm is not None and self.world > 1 and not isinstance(ic, NarrowBandMeshField) and hasattr(self.backend, "comm_attach_rccl")
-                and _os.environ.get("LSM_LIB_COMM", "1") != "0"):
+        band_slab = isinstance(ic, NarrowBandMeshField) and comm is not None and self.world > 1
+        if (comm is not None and self.world > 1 and hasattr(self.backend, "comm_attach_rccl")
+                and (band_slab or _os.environ.get("LSM_LIB_COMM", "1") != "0")):
             self._attach_library_comm()
+        if band_slab:
+            # the overlap planes of a band travel inside the library only (lsm_band_overlap_mask / _values)
+            if not self.lib_comm:
+                raise ValueError("a slab-decomposed NarrowBandMeshField needs the library's communicator (lsm_comm_attach_rccl / _local)")
+            self.backend.band_overlap_config(self.BAND_OVERLAP)
         # copy `ic` so the equation owns its state (src/levelsetequation.jl:67-76)
         self.band = isinstance(ic, NarrowBandMeshField)
         if self.band:
@@ -1172,6 +1184,10 @@ class LevelSetEquation:
         if not hasattr(self.backend, "check_range"):
             return
         ok, m = self.backend.check_range(self.state.buf)
+        if self.comm is not None and self.world > 1:
+            # every rank raises or none does: a rank failing alone would leave the others in their next exchange
+            parts = self._all_gather_object((ok, m))
+            ok, m = all(p[0] for p in parts), max(p[1] for p in parts)
         if not ok:
             raise ValueError(f"max|ϕ| = {m:.3g} is outside the domain of the FAST arithmetic mode (differences between neighbouring nodes "
                              f"must stay below 1e35: max|ϕ| <= {L.FAST_MAX_ABS:g}); rescale the field or build the equation with mode=\"strict\"")
@@ -1208,6 +1224,7 @@ class LevelSetEquation:
             backs = g.exchange(self.rank, b)
             if self.rank == 0:
                 type(b).comm_attach_local(backs)
+                g._backends = list(backs)
             g.exchange(self.rank, None)            # nobody runs ahead of the attachment
         else:
             import torch.distributed as dist
@@ -1292,6 +1309,8 @@ class LevelSetEquation:
             try:
                 b.advance_single(name, arr, n, phi, b1, b2, tc, dt, hook)
             except L.LsmError:
+                if self.lib_comm:
+                    b.comm_abort()      # the other ranks get LSM_ERR_COMM instead of waiting for this one
                 if self._hook_error is not None:
                     raise self._hook_error
                 raise
@@ -1322,9 +1341,39 @@ class LevelSetEquation:
             self._stage_slab(T(), n, b2, phi, phi, None, L.BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt)
 
     def _advance_band(self, tc, dt, b1, b2):
-        """_advance! on a NarrowBandMeshField: the same stages, looping over active nodes only
-        (src/timestepping.jl:128-202 with active_nodeindices = the band).  Every stage input is made
-        readable first: band halo by affine extrapolation, then the boundary-condition ghosts."""
+        """_advance! on a NarrowBandMeshField: lsm_advance_band_fe/rk2/rk3 (include/lsm.h) — the same stages, looping over
+        active nodes only (src/timestepping.jl:128-202 with active_nodeindices = the band); every stage input is made
+        readable first (band halo by affine extrapolation, then the boundary-condition ghosts) and, on a slab, the overlap
+        planes of every stage result come from their owners."""
+        b, st = self.backend, self.state
+        if os.environ.get("LSM_BAND_PY") == "1":      # the stage-by-stage sequence through lsm_band_prepare / lsm_stage_band (tests)
+            return self._advance_band_py(tc, dt, b1, b2)
+        hook = None
+        if self._needs_hook():
+            def cb(_user, stage, field_ptr, t_stage):
+                try:
+                    fld = st if stage == 0 else ROCMeshField(b, self.mesh_, self.bcs, b1 if stage == 1 else b2)
+                    self._update_terms(fld, t_stage)
+                    return 0
+                except Exception as e:   # surface python errors as an aborted step
+                    self._hook_error = e
+                    return 1
+            hook = L.StageHook(cb)
+            self._hook_keep = hook
+        self._hook_error = None
+        band_c = b.band_c(st.mask, st.tiles, st.MC, st._hlist, st._hcount)
+        try:
+            b.advance_band(self.integrator.name, _terms_c(self.terms), len(self.terms), band_c, st.buf, b1, b2, tc, dt, hook)
+        except L.LsmError:
+            if self.lib_comm:
+                b.comm_abort()
+            if self._hook_error is not None:
+                raise self._hook_error
+            raise
+        st.ghosts_dirty = True
+
+    def _advance_band_py(self, tc, dt, b1, b2):
+        """The same step driven stage by stage from here (what lsm_advance_band_* does inside the library)."""
         b, st = self.backend, self.state
         n = len(self.terms)
         phi = st.buf
@@ -1334,7 +1383,7 @@ class LevelSetEquation:
                                                                       st.mask, st.tiles, st.MC)
         fld = lambda buf: ROCMeshField(b, self.mesh_, self.bcs, buf)
         slabbed = self.comm is not None and self.world > 1
-        sync = (lambda buf: self._overlap_refresh(buf)) if slabbed else (lambda buf: None)   # stencil inputs: owners' values
+        sync = (lambda buf: b.band_overlap_values(buf)) if slabbed else (lambda buf: None)   # stencil inputs: owners' values
         st.prepare(phi)
         self._update_terms(st, tc)
         if name == "fe":
@@ -1369,74 +1418,15 @@ class LevelSetEquation:
 
     def _band_sync_after_update(self):
         """Slab of a band: the band set and the values of newly active nodes are only right away from the cut faces;
-        take both from the owners on the overlap planes, then re-derive tiles, lists and the halo from the full mask."""
-        st = self.state
-        self._sparse = None
-        self._overlap_refresh(st.mask)                 # full planes of mask bytes
-        self._sparse = self._overlap_indices(st.mask)  # from here on only the band nodes of those planes travel
-        self._overlap_refresh(st.buf)
-        st.backend.band_retile(st.mask, st.tiles, st.MC)
-        st.backend.band_status(st._hcount)
-        st.backend.band_halo(st.buf, st.mask, st.halo, st.tiles, st.MC, st._hlist, st._hcount)
+        take both from the owners on the overlap planes (lsm_band_overlap_mask: whole planes of mask bytes, after which
+        only the band nodes' values travel), then re-derive tiles, lists and the halo from the full mask."""
+        st, b = self.state, self.backend
+        b.band_overlap_mask(st.mask)
+        b.band_overlap_values(st.buf)
+        b.band_retile(st.mask, st.tiles, st.MC)
+        b.band_status(st._hcount)
+        b.band_halo(st.buf, st.mask, st.halo, st.tiles, st.MC, st._hlist, st._hcount)
         st._check_halo()
-
-    def _overlap_ranges(self):
-        """(neighbour, planes I send, planes I receive) per direction, local plane indices"""
-        W = self.BAND_OVERLAP
-        wlo, own_n = self.own
-        out = []
-        if self.rank < self.world - 1:
-            out.append((self.rank + 1, (wlo + own_n - W, wlo + own_n), (wlo + own_n, wlo + own_n + W)))
-        if self.rank > 0:
-            out.append((self.rank - 1, (wlo, wlo + W), (0, W)))
-        return out
-
-    def _plane_view(self, buf, k0, k1):
-        N = self.mesh_.ndim
-        sl = int(self.backend.lay.stride[N - 1])
-        return buf[(k0 + L.GHOST) * sl:(k1 + L.GHOST) * sl]
-
-    def _overlap_indices(self, mask):
-        """Positions of the band nodes inside the exchanged plane ranges.  Sender and receiver hold the same mask on
-        those planes, so both enumerate the same nodes in the same (index) order: no index needs to travel."""
-        import torch
-        idx = {}
-        for peer, snd, rcv in self._overlap_ranges():
-            idx[peer] = (torch.nonzero(self._plane_view(mask, *snd)).flatten(), torch.nonzero(self._plane_view(mask, *rcv)).flatten())
-        return idx
-
-    def _overlap_refresh(self, buf):
-        """Overwrite the overlap planes of `buf` with the owners' data (RCCL point-to-point): whole planes for the
-        mask, only the band nodes' values otherwise."""
-        import torch
-        import torch.distributed as dist
-        sparse = self._sparse if buf.dtype != torch.uint8 else None
-        ops, post = [], []
-        # op order [send up, recv dn, send dn, recv up]: messages between a pair of ranks match in posting order
-        rng = {peer: (snd, rcv) for peer, snd, rcv in self._overlap_ranges()}
-        up, dn = self.rank + 1, self.rank - 1
-        for peer, what in ((up, "send"), (dn, "recv"), (dn, "send"), (up, "recv")):
-            if peer not in rng:
-                continue
-            snd, rcv = rng[peer]
-            if sparse is None:
-                t = self._plane_view(buf, *(snd if what == "send" else rcv))
-            else:
-                si, ri = sparse[peer]
-                if what == "send":
-                    if si.numel() == 0:
-                        continue
-                    t = self._plane_view(buf, *snd).index_select(0, si)
-                else:
-                    if ri.numel() == 0:
-                        continue
-                    t = torch.empty(ri.numel(), dtype=buf.dtype, device=buf.device)
-                    post.append((self._plane_view(buf, *rcv), ri, t))
-            ops.append(dist.P2POp(dist.isend if what == "send" else dist.irecv, t, peer, group=self.comm))
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
-        for view, ri, t in post:
-            view.index_copy_(0, ri, t)
 
     def _stage_slab(self, arr, n, psi, phin, out, out2, mode, cdt, cdt2, t):
         """One stage of a slab followed by its ghost resolution.  With overlap, the G+1 planes next to
@@ -1803,7 +1793,7 @@ def reinitialize_(phi, order=3, upsample=2, maxiters=20, xtol=None, ftol=None):
     if eq is not None and eq.comm is not None and eq.world > 1:
         if not band:
             raise ValueError("reinitialize! of a slab-decomposed dense field is not supported")
-        eq._overlap_refresh(phi.buf)     # the neighbours' planes: their owners' values
+        eq.backend.band_overlap_values(phi.buf)     # the neighbours' planes: their owners' values
         nfail = nfar = 0                 # counted on the extended slab, cut faces included: not meaningful per rank
     if nfar:
         warnings.warn(f"reinitialize!: no interface sample was found ({nfar} nodes left unchanged)")

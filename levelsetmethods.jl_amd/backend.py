@@ -1,7 +1,7 @@
 """HipBackend — device memory (torch tensors as plain HBM buffers), streams and the calls into
 libhiplsm.so.  torch is plumbing here: allocation, the current HIP stream, and — in slab mode — the bootstrap
-of the library's own RCCL communicator (the ghost-plane exchange and the Δt all-reduce of a dense slab run
-inside the library; only the slab-decomposed narrow band still moves its planes with torch.distributed).
+of the library's own RCCL communicator (the ghost-plane exchange, the Δt all-reduce and the overlap planes of a
+slab-decomposed narrow band all run inside the library).
 
 The interface (layout / alloc / upload / download / fill_ghosts / stage / compute_cfl_local /
 advance_single / eikonal_sign / extrema / table) is the seam the host logic in api.py talks to.
@@ -192,6 +192,20 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_allreduce_dt(self.h, C.byref(v)), "lsm_allreduce_dt")
         return v.value
 
+    def comm_abort(self):
+        """Fail this rank's communicator (LOCAL: the whole group): peers blocked in an exchange get LSM_ERR_COMM."""
+        if getattr(self, "h", None):
+            self.lib.lsm_comm_abort(self.h)
+
+    def band_overlap_config(self, overlap):
+        L.check(self.h, self.lib.lsm_band_overlap_config(self.h, int(overlap)), "lsm_band_overlap_config")
+
+    def band_overlap_mask(self, mask):
+        L.check(self.h, self.lib.lsm_band_overlap_mask(self.h, self.ptr(mask)), "lsm_band_overlap_mask")
+
+    def band_overlap_values(self, t):
+        L.check(self.h, self.lib.lsm_band_overlap_values(self.h, self.ptr(t)), "lsm_band_overlap_values")
+
     def eikonal_sign(self, phi0, s0):
         L.check(self.h, self.lib.lsm_eikonal_sign(self.h, self.ptr(phi0), self.ptr(s0), None), "lsm_eikonal_sign")
 
@@ -315,6 +329,20 @@ class HipBackend:
     def stage_band(self, terms_c, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, mask, tiles, mc):
         L.check(self.h, self.lib.lsm_stage_band(self.h, terms_c, nterms, self.ptr(psi), self.ptr(phin), self.ptr(out), self.ptr(out2),
                                                 base_mode, cdt, cdt2, t, self.ptr(mask), self.ptr(tiles), int(mc), None), "lsm_stage_band")
+
+    def band_c(self, mask, tiles, mc, hlist, hcount):
+        """LsmBand: what lsm_band_update maintains for a field, as lsm_advance_band_* takes it."""
+        return L.LsmBand(self.ptr(mask), self.ptr(tiles), int(mc), 0, self.ptr(hlist), hlist.numel() // 2, self.ptr(hcount))
+
+    def advance_band(self, which, terms_c, nterms, band_c, phi, b1, b2, tc, dt, hook):
+        cb = hook if hook is not None else C.cast(None, L.StageHook)
+        if which == "fe":
+            code = self.lib.lsm_advance_band_fe(self.h, terms_c, nterms, C.byref(band_c), self.ptr(phi), self.ptr(b1), tc, dt, cb, None)
+        elif which == "rk2":
+            code = self.lib.lsm_advance_band_rk2(self.h, terms_c, nterms, C.byref(band_c), self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
+        else:
+            code = self.lib.lsm_advance_band_rk3(self.h, terms_c, nterms, C.byref(band_c), self.ptr(phi), self.ptr(b1), self.ptr(b2), tc, dt, cb, None)
+        L.check(self.h, code, f"lsm_advance_band_{which}")
 
     def compute_cfl_band(self, terms_c, nterms, phi, mask, t, tiles=None, mc=0):
         dt = C.c_double(0.0)

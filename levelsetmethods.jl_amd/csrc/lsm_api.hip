@@ -185,8 +185,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     h->own_stream = true;
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_partial, sizeof(double) * 2 * MAXB);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_tail_ctr, 64);
-    if (e == hipSuccess) e = hipMemset(h->d_tail_ctr, 0, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_tail_ctr, LSM_TAIL_SLOTS * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->d_tail_ctr, 0, LSM_TAIL_SLOTS * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_flag, sizeof(int));
     h->cfl_stream = nullptr; h->c_partial = h->c_result = h->ch_result = nullptr; h->c_flag = nullptr;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->cfl_stream, hipStreamNonBlocking);
@@ -353,8 +353,9 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     a.f32 = is_f32(h);
-    a.tail_ctr = h->d_tail_ctr; a.tail_base = 0; a.tail_wgs = 0;
-    a.tail_ticket_host = const_cast<unsigned*>(&h->tail_ticket);
+    a.tail_ctr = nullptr; a.tail_wgs = 0;
+    a.tail_ring = h->d_tail_ctr;          // stage_impl withdraws it from launches on a caller's stream
+    a.tail_slot_host = const_cast<unsigned*>(&h->tail_ticket);
     a.xredirect = h->xredirect ? 1 : 0;
     a.xkind[0] = h->bc[0][0].kind; a.xkind[1] = h->bc[0][1].kind;
     a.yredirect = h->yredirect ? 1 : 0;
@@ -406,6 +407,9 @@ static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void
         Combo c{0, 0, 0, 0};
         StageArgs a;
         base_args(h, a);
+        // the dynamic tail's counters are ordered by the handle's own stream: a launch on any other stream (which may run
+        // concurrently with one of ours) takes the static tail
+        if (s != h->stream) a.tail_ring = nullptr;
         int cnt = 0;
         while (i < nterms && cnt < NSLOTS) {
             const LsmTerm& tm = terms[i];
@@ -994,6 +998,8 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.list = nullptr; a.nlist = 0;
     a.f32 = is_f32(h);
     a.force_bytes = h->band_bytes ? 1 : 0;
+    static const int band_exp = getenv("LSM_BAND_EXP") ? atoi(getenv("LSM_BAND_EXP")) : 0;
+    a.exp = band_exp;
     return a;
 }
 
@@ -1286,6 +1292,69 @@ int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const v
     h->cfl_cache_on = keep;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
     return r;
+}
+
+// _advance!(integrator, ϕ::NarrowBandMeshField, buffers, terms, tc, Δt) — src/timestepping.jl:128-137,143-164,170-202 with
+// active_nodeindices = the band (src/meshfield.jl:330-333): the stages of the dense step restricted to the band nodes.  Every
+// stage input is made readable first (lsm_band_prepare: off-band stencil nodes by affine extrapolation from the band,
+// src/meshfield.jl:481-511, then the boundary-condition ghosts).  On a slab with lsm_band_overlap_config the overlap planes
+// of every stage result are refreshed from their owners.  Off-band entries of phi / buf1 / buf2 are scratch.
+static int band_check(LsmHandle* h, const LsmBand* b, const char* what) {
+    if (!b || !b->mask || !b->tiles || !b->halo_list || !b->halo_count || b->mc < 1)
+        return fail(h, LSM_ERR_INVALID, std::string(what) + ": incomplete LsmBand (mask, tiles, mc, halo_list, halo_count)");
+    return LSM_OK;
+}
+static int band_stage(LsmHandle* h, const LsmBand* b, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out,
+                      void* out2, int base_mode, double cdt, double cdt2, double t) {
+    return lsm_stage_band(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, b->mask, b->tiles, b->mc, nullptr);
+}
+static int band_ready(LsmHandle* h, const LsmBand* b, void* field, bool refresh) {
+    if (refresh && lsm_comm_band_overlap(h) > 0) LSM_TRY(lsm_band_overlap_values(h, field));
+    return lsm_band_prepare(h, field, b->mask, b->halo_list, b->halo_cap, b->halo_count, b->tiles, b->mc);
+}
+static int advance_band(LsmHandle* h, int integ, const LsmTerm* terms, int nterms, const LsmBand* b, void* phi, void* buf1, void* buf2,
+                        double tc, double dt, LsmStageHook hook, void* user) {
+    if (!h || !phi || !buf1 || (integ > 0 && !buf2)) return h ? fail(h, LSM_ERR_INVALID, "lsm_advance_band: null argument") : LSM_ERR_INVALID;
+    LSM_TRY(band_check(h, b, "lsm_advance_band"));
+    const bool slabbed = lsm_comm_band_overlap(h) > 0;
+    if (!slabbed) LSM_TRY(check_single_device(h));
+    LSM_TRY(band_ready(h, b, phi, false));
+    LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
+    if (integ == 0) {           // ForwardEuler: dst = copy of ϕ, updated on the band, copied back (:128-137) — only band entries matter
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
+        BandArgs a = band_args(h, b->mc, nullptr);
+        if (have_lists(h, b->tiles, b->mc)) { a.list = h->d_act_list; a.nlist = h->nact; }
+        else a.work = (const unsigned char*)b->tiles;
+        launch_band_copy_values(a, (const unsigned char*)b->mask, buf1, phi, h->stream);
+        LSM_HIP(h, hipGetLastError());
+    } else if (integ == 1) {    // RK2 (:143-164)
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc));
+        LSM_TRY(band_ready(h, b, buf1, true));
+        LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt));
+    } else {                    // RK3 (:170-202)
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
+        LSM_TRY(band_ready(h, b, buf1, true));
+        LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt));
+        LSM_TRY(band_ready(h, b, buf2, true));
+        LSM_TRY(run_hook(h, hook, user, 2, buf2, tc + 0.5 * dt));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt));
+    }
+    if (slabbed) LSM_TRY(lsm_band_overlap_values(h, phi));
+    return LSM_OK;
+}
+int lsm_advance_band_fe(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1, double tc, double dt,
+                        LsmStageHook hook, void* user) {
+    return advance_band(h, 0, terms, nterms, band, phi, buf1, nullptr, tc, dt, hook, user);
+}
+int lsm_advance_band_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1, void* buf2, double tc,
+                         double dt, LsmStageHook hook, void* user) {
+    return advance_band(h, 1, terms, nterms, band, phi, buf1, buf2, tc, dt, hook, user);
+}
+int lsm_advance_band_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, const LsmBand* band, void* phi, void* buf1, void* buf2, double tc,
+                         double dt, LsmStageHook hook, void* user) {
+    return advance_band(h, 2, terms, nterms, band, phi, buf1, buf2, tc, dt, hook, user);
 }
 
 // reinitialize!(ϕ; order, upsample, maxiters, xtol, ftol) — src/reinitializer.jl:12-42.  `phi` must be readable by

@@ -229,6 +229,13 @@ __global__ void __launch_bounds__(256) band_copy_kernel(BandArgs a, const unsign
     LSM_TILE_FOR(a, x, y, m, q) { out[q] = in[q]; if (zero) zero[q] = 0; }
 }
 
+// dst := src at the band nodes of the visited tiles (the copy!(ϕ, dst) that ends a ForwardEuler step on a band: only band entries matter)
+__global__ void __launch_bounds__(256) band_copy_values_kernel(BandArgs a, const unsigned char* mask, const void* src, void* dst) {
+    LSM_TILE_PROLOGUE(a)
+    LSM_TILE_FOR(a, x, y, m, q)
+        if (mask[q]) st_val(dst, q, a.f32, ld_val(src, q, a.f32));
+}
+
 // zero a byte mask on the visited tiles only (the halo mask of a band update: nothing reads it outside the work tiles)
 __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned char* out) {
     LSM_TILE_PROLOGUE(a)
@@ -541,9 +548,12 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
             return;
         }
     }
+    // timing experiments (LSM_BAND_EXP; wrong results): 1 = no value pass, 2 = stop after the mask pass, 4 = no mask output
+    if (a.exp & 2) return;
     // pass 2: values of the band nodes -> (<= 0) and (>= 0) row words
     u64* const out2[2] = {LE, GE};
-    stage_rows<GK, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, B, [&](long long q, bool, u64 rowB) -> unsigned {
+    if (a.exp & 1) { for (int t = threadIdx.x; t < nrows; t += blockDim.x) { LE[t] = B[t] & 0x5555555555555555ull; GE[t] = B[t] & 0xaaaaaaaaaaaaaaaaull; } }
+    else stage_rows<GK, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, B, [&](long long q, bool, u64 rowB) -> unsigned {
         const bool on = (rowB >> (threadIdx.x & 63)) & 1ull;
         const double xv = ld_val(v, on ? q : a.origin, a.f32);
         return on ? ((xv <= 0.0 ? 1u : 0u) | (xv >= 0.0 ? 2u : 0u)) : 0u;
@@ -598,6 +608,7 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
         u64* tmp = cur; cur = nxt; nxt = tmp;
     }
     int any = 0;
+    if (a.exp & 4) { if (threadIdx.x == 0) tiles[tile] = 1; return; }
     if (x0 + a.tx <= a.n[0]) {
         // whole x-rows inside the grid: a thread expands 8 bits of a row word to 8 mask bytes and stores them at once
         typedef u64 w8 __attribute__((aligned(1)));
@@ -660,6 +671,7 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
     }
     stage_mask_rows8(a, RL, bx, by, bm, x0, y0, m0, B, src_mask);
     __syncthreads();
+    if (a.exp & 8) return;
     if (halo) {
         // what stencils centred on band nodes read: LSM_GHOST nodes along each axis and the 3^3 box
         for (int t = threadIdx.x; t < a.ty * a.tm; t += blockDim.x) {
@@ -700,6 +712,7 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
                     want = false;
                 }
             }
+            if (a.exp & 16) want = false;
             if (want) {
                 const int I[3] = {x, y, m};
                 int P[3] = {0, 0, 0};
@@ -979,6 +992,10 @@ bool band_grow_fits(const BandArgs& a, int nl) { return fast3(a, nl + 1, 5) || b
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s) {
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_copy_kernel, tile_grid(a), dim3(256), 0, s, a, in, out, zero);
+}
+void launch_band_copy_values(const BandArgs& a, const unsigned char* mask, const void* src, void* dst, hipStream_t s) {
+    if (no_tiles(a)) return;
+    hipLaunchKernelGGL(band_copy_values_kernel, tile_grid(a), dim3(256), 0, s, a, mask, src, dst);
 }
 void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s) {
     if (no_tiles(a)) return;

@@ -1,23 +1,38 @@
 // lsm_comm.hip — multi-GPU side of the C ABI (include/lsm.h, "multi-GPU" section): slab decomposition of the last
 // dimension, exchange of LSM_GHOST full padded planes with the neighbouring ranks after every stage, Δt all-reduce
-// (the loop bodies served are src/timestepping.jl:128-137,143-164,170-202 and src/levelsetterms.jl:22-28).
+// (the loop bodies served are src/timestepping.jl:128-137,143-164,170-202 and src/levelsetterms.jl:22-28),
+// and the overlap planes of a slab-decomposed NarrowBandMeshField (mask as whole planes of bytes, values sparse).
 //
 // Two transports behind the same entry points:
 //   RCCL   one process per GPU.  librccl is opened at run time (dlopen): the library has no link-time dependency on it
-//          and says so loudly when it is missing.  Planes travel as grouped ncclSend/ncclRecv on a stream of the
+//          and says so loudly when it is missing.  Messages travel as grouped ncclSend/ncclRecv on a stream of the
 //          communicator's own, ordered against the handle's stream by events, so that the interior update of a stage
 //          overlaps the exchange of its boundary planes.
 //   LOCAL  every rank is a handle of ONE process (one host thread per rank, or one thread driving all ranks stage by
-//          stage).  The rank that posts last enqueues the whole group's plane copies (peer copies between the handles'
-//          buffers); a rank's stream then waits for the copies into its own ghost planes AND for its neighbours' copies
-//          out of its boundary planes — whatever it launches next may overwrite them.
+//          stage).  The rank that posts last enqueues the whole group's copies (peer copies between the ranks'
+//          buffers); a rank's stream then waits for the copies into its own buffers AND for its neighbours' copies
+//          out of its buffers — whatever it launches next may overwrite them.
+//
+// Every exchange is the same four messages: [send up, recv from down, send down, recv from up] — contiguous device
+// buffers (plane ranges in place, or packed values).
+//
+// Failure model.  No blocking call here hangs for ever: every wait of the LOCAL transport and the host wait of
+// lsm_allreduce_dt end with LSM_ERR_COMM when a peer has left the group (lsm_comm_detach / lsm_destroy), when any rank
+// has called lsm_comm_abort, or after LSM_COMM_TIMEOUT_MS (default 60000) without progress — a call that is already
+// complete still succeeds.  The LOCAL group owns the per-rank exchange streams and events (ref-counted, indexed by
+// rank): they outlive a rank's handle, so a rank that has finished its last exchange may be destroyed while a slower
+// neighbour is still ordering its stream behind that exchange's events, and no rank ever dereferences another rank's
+// handle.  A communicator that has failed stays failed: every later call on it returns LSM_ERR_COMM.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "lsm_handle.h"
 
@@ -29,6 +44,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -60,19 +76,36 @@ Rccl& rccl() {
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     });
     return r;
 }
 
+// one exchange = four contiguous device buffers (byte counts; a NULL / 0 message is skipped on both sides)
+struct Msg {
+    void* send_up = nullptr; size_t n_send_up = 0;
+    void* recv_dn = nullptr; size_t n_recv_dn = 0;
+    void* send_dn = nullptr; size_t n_send_dn = 0;
+    void* recv_up = nullptr; size_t n_recv_up = 0;
+};
+
 // ---- LOCAL transport: state shared by the handles of one in-process group --------------------------------------------
+// what the group keeps of rank r: everything a PEER touches
+struct LocalRank {
+    bool present = false;                     // false once the rank has detached
+    int device = 0;
+    int up = -1, dn = -1;
+    hipStream_t stream = nullptr;             // the rank's exchange stream
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    Msg msg;                                  // the exchange being posted
+};
 struct LocalGroup {
     int world = 0;
-    std::vector<LsmHandle*> handles;
+    std::vector<LocalRank> ranks;
     std::mutex mu;
     std::condition_variable cv;
     unsigned long long posted_seq = 0;        // exchanges whose copies have been enqueued (by the last rank to post)
-    std::vector<unsigned long long> seq;      // per rank: exchanges posted
-    std::vector<void*> field;                 // per rank: field of the exchange being posted
     int nposted = 0;
     // Δt all-reduce
     std::vector<double> red;
@@ -80,7 +113,14 @@ struct LocalGroup {
     unsigned long long red_gen = 0;
     double red_result = 0.0;
     int refs = 0;
+    bool failed = false;                      // a rank left, aborted or timed out: every unfinished wait returns LSM_ERR_COMM
+    std::string why;
 };
+
+std::chrono::milliseconds comm_timeout() {
+    static const long long ms = getenv("LSM_COMM_TIMEOUT_MS") ? atoll(getenv("LSM_COMM_TIMEOUT_MS")) : 60000ll;
+    return std::chrono::milliseconds(ms > 0 ? ms : 60000ll);
+}
 
 }  // namespace
 
@@ -89,15 +129,29 @@ struct LsmComm {
     int rank, world;
     int up, dn;                // neighbour ranks (-1: none — a physical boundary)
     bool wrap_up, wrap_dn;     // the neighbour lies across the periodic wrap (period n-1: the duplicate end node is skipped)
+    // LOCAL: the stream and the events are the group's (LocalGroup::ranks[rank]) and are destroyed with the group
     hipStream_t stream;        // the exchange runs here
-    hipEvent_t ev_ready[2];    // handle's stream: the boundary planes of the posted field are final (parity of the exchange)
-    hipEvent_t ev_done[2];     // exchange stream: this rank's ghost planes are filled (LOCAL: and its copies have read the neighbours' planes)
+    hipEvent_t ev_ready[2];    // handle's stream: the buffers of the posted exchange are final (parity of the exchange)
+    hipEvent_t ev_done[2];     // exchange stream: this rank's receive buffers are filled (LOCAL: and its copies have read the neighbours' buffers)
     unsigned long long seq;    // exchanges started by this rank
-    bool pending;              // lsm_halo_start without its lsm_halo_wait
+    bool pending;              // an exchange was started and not yet waited for
     bool overlap;              // stages update the interface planes first and overlap the exchange with the interior
+    std::atomic<bool> failed;  // a call failed half-way, a peer is gone, or lsm_comm_abort was called: LSM_ERR_COMM from now on
     ncclComm_t nccl;
     double* d_dt;              // device scalar of the Δt all-reduce
+    double* h_dt;              // pinned host scalar
     LocalGroup* grp;
+    // slab-decomposed NarrowBandMeshField (lsm_band_overlap_*): W planes of each neighbour held as planes of this slab
+    int band_W;
+    unsigned* d_idx[4];        // band nodes (byte offsets within the plane range) of [send up, recv dn, send dn, recv up]
+    size_t idx_cap[4];
+    unsigned n_idx[4];
+    char* d_pack[4];           // packed values of those nodes
+    size_t pack_cap[4];
+    unsigned* d_nz_counts;     // scratch of the ordered compaction: per-chunk counts / offsets, and the four totals
+    size_t nz_cap;
+    unsigned* d_nz_total;      // 4 totals
+    unsigned* h_nz_total;      // pinned
 };
 
 namespace {
@@ -107,31 +161,50 @@ namespace {
         hipError_t e_ = (call);                                                                             \
         if (e_ != hipSuccess) return lsm_fail(h, LSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
-#define COMM_NCCL(h, call)                                                                                  \
-    do {                                                                                                    \
-        ncclResult_t r_ = (call);                                                                           \
-        if (r_ != ncclSuccess) return lsm_fail(h, LSM_ERR_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
-    } while (0)
 
 inline size_t esize(const LsmHandle* h) { return h->dtype == LSM_DTYPE_F32 ? sizeof(float) : sizeof(double); }
 
-// geometry of the exchange: elements per padded plane, local plane range -> pointer
+// geometry of the plane exchange: elements per padded plane, local plane range -> pointer
 struct Planes {
     long long sl;      // elements per padded plane of the last dimension
     int nloc, G;
     size_t es;
     char* at(void* field, int k) const { return (char*)field + es * (size_t)((long long)(k + G) * sl); }   // local plane k, -G <= k < nloc+G
-    size_t bytes() const { return es * (size_t)G * (size_t)sl; }
-    size_t count() const { return (size_t)G * (size_t)sl; }
+    size_t bytes(int nplanes) const { return es * (size_t)nplanes * (size_t)sl; }
 };
-Planes planes_of(const LsmHandle* h) {
+Planes planes_of(const LsmHandle* h, size_t es) {
     const int N = h->grid.ndim;
-    return Planes{h->lay.stride[N - 1], h->nloc[N - 1], LSM_GHOST, esize(h)};
+    return Planes{h->lay.stride[N - 1], h->nloc[N - 1], LSM_GHOST, es};
 }
 // first plane this rank sends up / down (src/boundaryconditions.jl:107-119: nodes 1 and n coincide on a periodic
 // dimension, so across the wrap the sender skips its duplicate end node)
 inline int send_up_from(const LsmComm* c, const Planes& p) { return p.nloc - p.G - (c->wrap_up ? 1 : 0); }
 inline int send_dn_from(const LsmComm* c) { return c->wrap_dn ? 1 : 0; }
+
+int comm_failed(LsmHandle* h, LsmComm* c, const char* what) {
+    std::string why = "the communicator has failed";
+    if (c->grp) { std::lock_guard<std::mutex> g(c->grp->mu); if (!c->grp->why.empty()) why = c->grp->why; }
+    return lsm_fail(h, LSM_ERR_COMM, std::string(what) + ": " + why);
+}
+// mark the communicator (and its LOCAL group) failed and wake every waiter
+void mark_failed(LsmComm* c, const std::string& why) {
+    c->failed.store(true);
+    if (c->grp) {
+        { std::lock_guard<std::mutex> g(c->grp->mu); if (!c->grp->failed) { c->grp->failed = true; c->grp->why = why; } }
+        c->grp->cv.notify_all();
+    }
+}
+
+void free_local_group(LocalGroup* g) {
+    for (auto& r : g->ranks) {
+        (void)hipSetDevice(r.device);
+        if (r.stream) (void)hipStreamSynchronize(r.stream);
+        for (auto e : r.ev_ready) if (e) (void)hipEventDestroy(e);
+        for (auto e : r.ev_done) if (e) (void)hipEventDestroy(e);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+    delete g;
+}
 
 int make_comm(LsmHandle* h, int transport, int rank, int world, LsmComm** out) {
     const int N = h->grid.ndim;
@@ -154,72 +227,307 @@ int make_comm(LsmHandle* h, int transport, int rank, int world, LsmComm** out) {
     c->wrap_dn = face_dn && rank == 0;
     c->wrap_up = face_up && rank == world - 1;
     c->overlap = !(getenv("LSM_SLAB_OVERLAP") && getenv("LSM_SLAB_OVERLAP")[0] == '0');
-    c->seq = 0; c->pending = false; c->nccl = nullptr; c->d_dt = nullptr; c->grp = nullptr; c->stream = nullptr;
+    c->seq = 0; c->pending = false; c->failed.store(false); c->nccl = nullptr; c->d_dt = nullptr; c->h_dt = nullptr; c->grp = nullptr;
+    c->stream = nullptr;
     for (auto& e : c->ev_ready) e = nullptr;
     for (auto& e : c->ev_done) e = nullptr;
+    c->band_W = 0;
+    for (int k = 0; k < 4; ++k) { c->d_idx[k] = nullptr; c->idx_cap[k] = 0; c->n_idx[k] = 0; c->d_pack[k] = nullptr; c->pack_cap[k] = 0; }
+    c->d_nz_counts = nullptr; c->nz_cap = 0; c->d_nz_total = nullptr; c->h_nz_total = nullptr;
     hipError_t e = hipSetDevice(h->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_dt, sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_dt, sizeof(double), hipHostMallocDefault);
     if (e != hipSuccess) {
+        if (c->d_dt) (void)hipFree(c->d_dt);
         delete c;
         return lsm_fail(h, LSM_ERR_HIP, std::string("lsm_comm_attach: ") + hipGetErrorString(e));
     }
     *out = c;
     return LSM_OK;
 }
+// the exchange stream and its events: owned by the communicator (RCCL) or by the group's rank entry (LOCAL)
+hipError_t make_stream_events(int device, hipStream_t* s, hipEvent_t (&ready)[2], hipEvent_t (&done)[2]) {
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    return e;
+}
 
 void free_comm(LsmHandle* h, LsmComm* c) {
     (void)hipSetDevice(h->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-    if (c->nccl) (void)rccl().CommDestroy(c->nccl);
-    for (auto e : c->ev_ready) if (e) (void)hipEventDestroy(e);
-    for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    LocalGroup* g = c->grp;
+    if (g) {
+        // leave the group: peers that still wait for this rank get LSM_ERR_COMM; the stream and the events stay with the group
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->ranks[c->rank].present = false;
+            if (!g->failed) { g->failed = true; g->why = "rank " + std::to_string(c->rank) + " has left the group"; }
+        }
+        g->cv.notify_all();
+        // this rank's copies, and the neighbours' copies out of this rank's buffers, must have finished before the caller frees them
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        for (int nb : {c->dn, c->up})
+            if (nb >= 0 && g->ranks[nb].stream) { (void)hipSetDevice(g->ranks[nb].device); (void)hipStreamSynchronize(g->ranks[nb].stream); }
+        (void)hipSetDevice(h->device);
+    } else {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(h->stream);            // the Δt all-reduce runs on the handle's stream
+        if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+        for (auto e : c->ev_ready) if (e) (void)hipEventDestroy(e);
+        for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
     if (c->d_dt) (void)hipFree(c->d_dt);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->grp) {
+    if (c->h_dt) (void)hipHostFree(c->h_dt);
+    for (int k = 0; k < 4; ++k) { if (c->d_idx[k]) (void)hipFree(c->d_idx[k]); if (c->d_pack[k]) (void)hipFree(c->d_pack[k]); }
+    if (c->d_nz_counts) (void)hipFree(c->d_nz_counts);
+    if (c->d_nz_total) (void)hipFree(c->d_nz_total);
+    if (c->h_nz_total) (void)hipHostFree(c->h_nz_total);
+    if (g) {
         bool last;
-        { std::lock_guard<std::mutex> g(c->grp->mu); last = --c->grp->refs == 0; }
-        if (last) delete c->grp;
+        { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
+        if (last) free_local_group(g);
     }
     delete c;
 }
 
-// LOCAL: enqueue the plane copies of exchange `seq` for every rank of the group (called, under the group's mutex,
-// by the rank that posted last).  Rank r PULLS its ghost planes from its neighbours' posted fields on its own exchange
-// stream, behind the neighbours' and its own "boundary planes final" events.
-int local_enqueue(LocalGroup* g, unsigned long long seq) {
+// LOCAL: enqueue the copies of exchange `seq` for every rank of the group (called, under the group's mutex, by the rank
+// that posted last).  Rank r PULLS its receive buffers from its neighbours' posted send buffers on its own exchange
+// stream, behind the neighbours' and its own "buffers final" events.
+int local_enqueue(LsmHandle* h, LocalGroup* g, unsigned long long seq) {
     const int par = (int)(seq & 1);
     int cur = -1;
     (void)hipGetDevice(&cur);
     for (int r = 0; r < g->world; ++r) {
-        LsmHandle* h = g->handles[r];
-        LsmComm* c = h->comm;
-        const Planes p = planes_of(h);
-        COMM_HIP(h, hipSetDevice(h->device));
-        COMM_HIP(h, hipStreamWaitEvent(c->stream, c->ev_ready[par], 0));
-        if (c->dn >= 0) {
-            LsmHandle* n = g->handles[c->dn];
-            const Planes q = planes_of(n);
-            COMM_HIP(h, hipStreamWaitEvent(c->stream, n->comm->ev_ready[par], 0));
-            COMM_HIP(h, hipMemcpyAsync(p.at(g->field[r], -p.G), q.at(g->field[c->dn], send_up_from(n->comm, q)), p.bytes(), hipMemcpyDefault, c->stream));
+        LocalRank& me = g->ranks[r];
+        COMM_HIP(h, hipSetDevice(me.device));
+        COMM_HIP(h, hipStreamWaitEvent(me.stream, me.ev_ready[par], 0));
+        if (me.dn >= 0) {
+            LocalRank& n = g->ranks[me.dn];
+            if (n.msg.n_send_up != me.msg.n_recv_dn) return lsm_fail(h, LSM_ERR_COMM, "exchange: message sizes of neighbouring ranks differ");
+            COMM_HIP(h, hipStreamWaitEvent(me.stream, n.ev_ready[par], 0));
+            if (me.msg.n_recv_dn) COMM_HIP(h, hipMemcpyAsync(me.msg.recv_dn, n.msg.send_up, me.msg.n_recv_dn, hipMemcpyDefault, me.stream));
         }
-        if (c->up >= 0) {
-            LsmHandle* n = g->handles[c->up];
-            const Planes q = planes_of(n);
-            COMM_HIP(h, hipStreamWaitEvent(c->stream, n->comm->ev_ready[par], 0));
-            COMM_HIP(h, hipMemcpyAsync(p.at(g->field[r], p.nloc), q.at(g->field[c->up], send_dn_from(n->comm)), p.bytes(), hipMemcpyDefault, c->stream));
+        if (me.up >= 0) {
+            LocalRank& n = g->ranks[me.up];
+            if (n.msg.n_send_dn != me.msg.n_recv_up) return lsm_fail(h, LSM_ERR_COMM, "exchange: message sizes of neighbouring ranks differ");
+            COMM_HIP(h, hipStreamWaitEvent(me.stream, n.ev_ready[par], 0));
+            if (me.msg.n_recv_up) COMM_HIP(h, hipMemcpyAsync(me.msg.recv_up, n.msg.send_dn, me.msg.n_recv_up, hipMemcpyDefault, me.stream));
         }
-        COMM_HIP(h, hipEventRecord(c->ev_done[par], c->stream));
+        COMM_HIP(h, hipEventRecord(me.ev_done[par], me.stream));
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     return LSM_OK;
 }
 
+// wait (group mutex held) until done() — which wins even over a failed group — or the group fails / the timeout passes
+template <class P>
+int group_wait(LsmHandle* h, LsmComm* c, std::unique_lock<std::mutex>& lk, P done, const char* what) {
+    LocalGroup* g = c->grp;
+    const auto deadline = std::chrono::steady_clock::now() + comm_timeout();
+    while (!done()) {
+        if (g->failed) { c->failed.store(true); return lsm_fail(h, LSM_ERR_COMM, std::string(what) + ": " + g->why); }
+        if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout && !done() && !g->failed) {
+            g->failed = true;
+            g->why = "rank " + std::to_string(c->rank) + " timed out waiting for the other ranks (LSM_COMM_TIMEOUT_MS)";
+            g->cv.notify_all();
+        }
+    }
+    return LSM_OK;
+}
+
+// start one exchange of four messages on the communicator
+int exchange_start(LsmHandle* h, const Msg& m, ncclDataType_t ty, size_t tysize, const char* what) {
+    LsmComm* c = h->comm;
+    if (c->failed.load()) return comm_failed(h, c, what);
+    if (c->pending) return lsm_fail(h, LSM_ERR_INVALID, std::string(what) + ": the previous exchange has not been waited for (lsm_halo_wait)");
+    const unsigned long long seq = ++c->seq;
+    const int par = (int)(seq & 1);
+    COMM_HIP(h, hipSetDevice(h->device));
+    COMM_HIP(h, hipEventRecord(c->ev_ready[par], h->stream));
+    c->pending = true;
+    if (c->transport == LSM_COMM_RCCL) {
+        if (c->up < 0 && c->dn < 0) { COMM_HIP(h, hipEventRecord(c->ev_done[par], h->stream)); return LSM_OK; }
+        Rccl& r = rccl();
+        COMM_HIP(h, hipStreamWaitEvent(c->stream, c->ev_ready[par], 0));
+        // op order [send up, recv dn, send dn, recv up]: the messages of one pair of ranks match in posting order, which
+        // matters when up == dn (two ranks on a periodic ring).  A failure inside the group closes it, drops the exchange
+        // and fails the communicator: nothing later waits on an event that was never recorded.
+        ncclResult_t nr = r.GroupStart();
+        if (nr == ncclSuccess) {
+            if (c->up >= 0 && m.n_send_up && nr == ncclSuccess) nr = r.Send(m.send_up, m.n_send_up / tysize, ty, c->up, c->nccl, c->stream);
+            if (c->dn >= 0 && m.n_recv_dn && nr == ncclSuccess) nr = r.Recv(m.recv_dn, m.n_recv_dn / tysize, ty, c->dn, c->nccl, c->stream);
+            if (c->dn >= 0 && m.n_send_dn && nr == ncclSuccess) nr = r.Send(m.send_dn, m.n_send_dn / tysize, ty, c->dn, c->nccl, c->stream);
+            if (c->up >= 0 && m.n_recv_up && nr == ncclSuccess) nr = r.Recv(m.recv_up, m.n_recv_up / tysize, ty, c->up, c->nccl, c->stream);
+            const ncclResult_t ne = r.GroupEnd();
+            if (nr == ncclSuccess) nr = ne;
+        }
+        if (nr != ncclSuccess) {
+            c->pending = false;
+            c->failed.store(true);
+            return lsm_fail(h, LSM_ERR_COMM, std::string(what) + ": RCCL: " + r.GetErrorString(nr));
+        }
+        COMM_HIP(h, hipEventRecord(c->ev_done[par], c->stream));
+        return LSM_OK;
+    }
+    // LOCAL: post; the last rank to post enqueues the copies of the whole group
+    LocalGroup* g = c->grp;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->failed) { c->pending = false; c->failed.store(true); return lsm_fail(h, LSM_ERR_COMM, std::string(what) + ": " + g->why); }
+    g->ranks[c->rank].msg = m;
+    if (++g->nposted == g->world) {
+        g->nposted = 0;
+        const int rc = local_enqueue(h, g, seq);
+        if (rc) { g->failed = true; g->why = "enqueueing the copies of an exchange failed"; c->pending = false; c->failed.store(true); }
+        else g->posted_seq = seq;
+        lk.unlock();
+        g->cv.notify_all();
+        return rc;
+    }
+    return LSM_OK;
+}
+
+// The handle's stream waits for the messages received (and, LOCAL, for the neighbours' reads of this rank's buffers).
+// LOCAL blocks the calling thread until every rank of the group has posted the exchange.
+int exchange_wait(LsmHandle* h, const char* what) {
+    LsmComm* c = h->comm;
+    if (!c->pending) return c->failed.load() ? comm_failed(h, c, what) : LSM_OK;
+    c->pending = false;
+    const int par = (int)(c->seq & 1);
+    COMM_HIP(h, hipSetDevice(h->device));
+    if (c->transport == LSM_COMM_LOCAL) {
+        LocalGroup* g = c->grp;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            const int rc = group_wait(h, c, lk, [&] { return g->posted_seq >= c->seq; }, what);
+            if (rc) return rc;
+        }
+        // the neighbours' events belong to the group: valid even if the neighbour has been destroyed since
+        if (c->dn >= 0) COMM_HIP(h, hipStreamWaitEvent(h->stream, g->ranks[c->dn].ev_done[par], 0));
+        if (c->up >= 0) COMM_HIP(h, hipStreamWaitEvent(h->stream, g->ranks[c->up].ev_done[par], 0));
+    } else if (c->failed.load()) {
+        return comm_failed(h, c, what);
+    }
+    COMM_HIP(h, hipStreamWaitEvent(h->stream, c->ev_done[par], 0));
+    return LSM_OK;
+}
+
+// host wait for the handle's stream that gives up when the communicator fails or the timeout passes
+int stream_wait(LsmHandle* h, LsmComm* c, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto deadline = t0 + comm_timeout();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) return LSM_OK;
+        if (e != hipErrorNotReady) return lsm_fail(h, LSM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        const auto now = std::chrono::steady_clock::now();
+        if (c->failed.load() || now > deadline) {
+            const bool timed_out = !c->failed.load();
+            c->failed.store(true);
+            if (c->nccl && rccl().CommAbort) { (void)rccl().CommAbort(c->nccl); c->nccl = nullptr; }   // releases the kernels waiting for the peer
+            return lsm_fail(h, LSM_ERR_COMM, std::string(what) + (timed_out ? ": timed out waiting for the other ranks (LSM_COMM_TIMEOUT_MS)"
+                                                                           : ": the communicator was aborted"));
+        }
+        if (now - t0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// ---- ordered compaction of a byte mask range: offsets (ascending) of the non-zero bytes -------------------------------
+constexpr int NZ_CHUNK = 4096;      // bytes per workgroup (256 threads x 16)
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ unsigned nz_bytes16(const unsigned char* p, size_t off, size_t n, unsigned& bits) {
+    bits = 0;
+    if (off + 16 <= n) {
+        const unsigned long long a = *reinterpret_cast<const u64_unaligned*>(p + off), b = *reinterpret_cast<const u64_unaligned*>(p + off + 8);
+        for (int k = 0; k < 8; ++k) {
+            bits |= ((a >> (8 * k)) & 0xff) ? (1u << k) : 0u;
+            bits |= ((b >> (8 * k)) & 0xff) ? (1u << (8 + k)) : 0u;
+        }
+    } else {
+        for (int k = 0; k < 16; ++k)
+            if (off + k < n && p[off + k]) bits |= 1u << k;
+    }
+    return (unsigned)__builtin_popcount(bits);
+}
+__device__ __forceinline__ unsigned block_sum256(unsigned v, unsigned* sh) {      // sum over a 256-thread block; sh: 4 words
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const unsigned t = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return t;
+}
+__global__ void __launch_bounds__(256) nz_count_kernel(const unsigned char* p, size_t n, unsigned* counts) {
+    __shared__ unsigned sh[4];
+    unsigned bits;
+    const unsigned c = nz_bytes16(p, (size_t)blockIdx.x * NZ_CHUNK + threadIdx.x * 16, n, bits);
+    const unsigned t = block_sum256(c, sh);
+    if (threadIdx.x == 0) counts[blockIdx.x] = t;
+}
+// exclusive scan of the per-chunk counts in place (one workgroup), total -> *total
+__global__ void __launch_bounds__(1024) nz_scan_kernel(unsigned* counts, unsigned nchunks, unsigned* total) {
+    __shared__ unsigned sh[1024];
+    const unsigned per = (nchunks + 1023u) / 1024u, b = threadIdx.x * per;
+    unsigned s = 0;
+    for (unsigned k = 0; k < per && b + k < nchunks; ++k) s += counts[b + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024; off <<= 1) {
+        const unsigned v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = sh[threadIdx.x] - s;
+    for (unsigned k = 0; k < per && b + k < nchunks; ++k) { const unsigned c = counts[b + k]; counts[b + k] = run; run += c; }
+    if (threadIdx.x == 1023) *total = sh[1023];
+}
+__global__ void __launch_bounds__(256) nz_write_kernel(const unsigned char* p, size_t n, const unsigned* offsets, unsigned* out, size_t cap) {
+    __shared__ unsigned wsum[4];
+    unsigned bits;
+    const size_t off = (size_t)blockIdx.x * NZ_CHUNK + threadIdx.x * 16;
+    const unsigned c = nz_bytes16(p, off, n, bits);
+    unsigned inc = c;                                   // inclusive scan over the wave, then over the 4 waves
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(inc, o, 64); if ((int)lane >= o) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned base = offsets[blockIdx.x];
+    for (unsigned w = 0; w < wave; ++w) base += wsum[w];
+    unsigned k = base + inc - c;
+    for (int j = 0; j < 16; ++j)
+        if ((bits >> j) & 1u) { if (k < cap) out[k] = (unsigned)(off + j); ++k; }
+}
+// values of the listed nodes of a plane range <-> a packed buffer (es = 4 or 8 bytes per value)
+__global__ void __launch_bounds__(256) pack_kernel(const char* base, const unsigned* idx, unsigned n, int es, char* out) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (es == 8) reinterpret_cast<double*>(out)[i] = reinterpret_cast<const double*>(base)[idx[i]];
+    else reinterpret_cast<float*>(out)[i] = reinterpret_cast<const float*>(base)[idx[i]];
+}
+__global__ void __launch_bounds__(256) unpack_kernel(char* base, const unsigned* idx, unsigned n, int es, const char* in) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (es == 8) reinterpret_cast<double*>(base)[idx[i]] = reinterpret_cast<const double*>(in)[i];
+    else reinterpret_cast<float*>(base)[idx[i]] = reinterpret_cast<const float*>(in)[i];
+}
+
+// the four plane ranges of the band overlap: [send up, recv dn, send dn, recv up] as first local plane (W planes each);
+// -1 = no neighbour on that side
+void band_ranges(const LsmHandle* h, const LsmComm* c, int first[4]) {
+    const int W = c->band_W, nloc = h->nloc[h->grid.ndim - 1];
+    const int wlo = c->dn >= 0 ? W : 0, whi = c->up >= 0 ? W : 0;
+    first[0] = c->up >= 0 ? nloc - whi - W : -1;      // my top owned planes -> up's lower overlap
+    first[1] = c->dn >= 0 ? 0 : -1;                    // my lower overlap <- dn's top owned planes
+    first[2] = c->dn >= 0 ? wlo : -1;                  // my bottom owned planes -> dn's upper overlap
+    first[3] = c->up >= 0 ? nloc - whi : -1;           // my upper overlap <- up's bottom owned planes
+}
+
 }  // namespace
 
 bool lsm_comm_overlap(const LsmHandle* h) { return h->comm && h->comm->overlap; }
+int lsm_comm_band_overlap(const LsmHandle* h) { return h->comm ? h->comm->band_W : 0; }
 
 extern "C" {
 
@@ -242,6 +550,11 @@ int lsm_comm_attach_rccl(LsmHandle* h, const void* unique_id, int rank, int worl
     LsmComm* c = nullptr;
     int rc = make_comm(h, LSM_COMM_RCCL, rank, world, &c);
     if (rc) return rc;
+    const hipError_t e = make_stream_events(h->device, &c->stream, c->ev_ready, c->ev_done);
+    if (e != hipSuccess) {
+        free_comm(h, c);
+        return lsm_fail(h, LSM_ERR_HIP, std::string("lsm_comm_attach_rccl: ") + hipGetErrorString(e));
+    }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     ncclResult_t nr = r.CommInitRank(&c->nccl, world, id, rank);   // collective: every rank of the group is in this call
@@ -260,22 +573,36 @@ int lsm_comm_attach_local(LsmHandle* const* handles, int world) {
         if (!handles[r]) return LSM_ERR_INVALID;
     LocalGroup* g = new LocalGroup();
     g->world = world;
-    g->handles.assign(handles, handles + world);
-    g->seq.assign(world, 0);
-    g->field.assign(world, nullptr);
+    g->ranks.resize(world);
     g->red.assign(world, 0.0);
-    for (int r = 0; r < world; ++r) {
+    std::vector<LsmComm*> made;
+    int rc = LSM_OK;
+    for (int r = 0; r < world && rc == LSM_OK; ++r) {
         LsmComm* c = nullptr;
-        int rc = make_comm(handles[r], LSM_COMM_LOCAL, r, world, &c);
-        if (rc == LSM_OK && (handles[r]->dtype != handles[0]->dtype || handles[r]->lay.stride[handles[r]->grid.ndim - 1] != handles[0]->lay.stride[handles[0]->grid.ndim - 1]))
+        rc = make_comm(handles[r], LSM_COMM_LOCAL, r, world, &c);
+        if (rc) break;
+        made.push_back(c);
+        if (handles[r]->dtype != handles[0]->dtype || handles[r]->lay.stride[handles[r]->grid.ndim - 1] != handles[0]->lay.stride[handles[0]->grid.ndim - 1])
             rc = lsm_fail(handles[r], LSM_ERR_INVALID, "lsm_comm_attach_local: the handles must share dtype and plane shape");
-        if (rc) {
-            if (c) { c->grp = nullptr; free_comm(handles[r], c); }
-            for (int q = 0; q < r; ++q) { LsmComm* d = handles[q]->comm; handles[q]->comm = nullptr; d->grp = nullptr; free_comm(handles[q], d); }
-            delete g;
-            return rc;
+        LocalRank& lr = g->ranks[r];
+        lr.device = handles[r]->device; lr.up = c->up; lr.dn = c->dn;
+        if (rc == LSM_OK) {
+            const hipError_t e = make_stream_events(lr.device, &lr.stream, lr.ev_ready, lr.ev_done);
+            if (e != hipSuccess) rc = lsm_fail(handles[r], LSM_ERR_HIP, std::string("lsm_comm_attach_local: ") + hipGetErrorString(e));
         }
+    }
+    if (rc) {
+        for (size_t q = 0; q < made.size(); ++q) { made[q]->grp = nullptr; made[q]->stream = nullptr; free_comm(handles[q], made[q]); }
+        free_local_group(g);          // releases whatever streams / events were created
+        return rc;
+    }
+    for (int r = 0; r < world; ++r) {
+        LsmComm* c = made[r];
+        LocalRank& lr = g->ranks[r];
+        lr.present = true;
         c->grp = g;
+        c->stream = lr.stream;
+        for (int i = 0; i < 2; ++i) { c->ev_ready[i] = lr.ev_ready[i]; c->ev_done[i] = lr.ev_done[i]; }
         handles[r]->comm = c;
     }
     g->refs = world;
@@ -288,6 +615,17 @@ int lsm_comm_detach(LsmHandle* h) {
     LsmComm* c = h->comm;
     h->comm = nullptr;
     free_comm(h, c);
+    return LSM_OK;
+}
+
+// Fail the communicator of this handle — and, LOCAL, its whole group: every rank blocked in (or later entering) an exchange
+// wait or the Δt all-reduce returns LSM_ERR_COMM instead of waiting for a rank that will not come.  Callable from any
+// thread.  RCCL: ncclCommAbort releases this rank's kernels; the other processes notice through their own timeout.
+int lsm_comm_abort(LsmHandle* h) {
+    if (!h) return LSM_ERR_INVALID;
+    LsmComm* c = h->comm;
+    if (!c) return LSM_OK;
+    mark_failed(c, "aborted by rank " + std::to_string(c->rank) + " (lsm_comm_abort)");
     return LSM_OK;
 }
 
@@ -312,68 +650,18 @@ int lsm_halo_start(LsmHandle* h, void* field) {
     if (!h || !field) return LSM_ERR_INVALID;
     LsmComm* c = h->comm;
     if (!c) return lsm_fail(h, LSM_ERR_INVALID, "lsm_halo_start: no communicator attached (lsm_comm_attach_rccl / _local)");
-    if (c->pending) return lsm_fail(h, LSM_ERR_INVALID, "lsm_halo_start: the previous exchange has not been waited for (lsm_halo_wait)");
-    const unsigned long long seq = ++c->seq;
-    const int par = (int)(seq & 1);
-    c->pending = true;
-    COMM_HIP(h, hipSetDevice(h->device));
-    COMM_HIP(h, hipEventRecord(c->ev_ready[par], h->stream));
-    const Planes p = planes_of(h);
-    if (c->transport == LSM_COMM_RCCL) {
-        if (c->up < 0 && c->dn < 0) { COMM_HIP(h, hipEventRecord(c->ev_done[par], h->stream)); return LSM_OK; }
-        Rccl& r = rccl();
-        const ncclDataType_t ty = h->dtype == LSM_DTYPE_F32 ? ncclFloat : ncclDouble;
-        COMM_HIP(h, hipStreamWaitEvent(c->stream, c->ev_ready[par], 0));
-        // op order [send up, recv dn, send dn, recv up]: the messages of one pair of ranks match in posting order, which
-        // matters when up == dn (two ranks on a periodic ring)
-        COMM_NCCL(h, r.GroupStart());
-        if (c->up >= 0) COMM_NCCL(h, r.Send(p.at(field, send_up_from(c, p)), p.count(), ty, c->up, c->nccl, c->stream));
-        if (c->dn >= 0) {
-            COMM_NCCL(h, r.Recv(p.at(field, -p.G), p.count(), ty, c->dn, c->nccl, c->stream));
-            COMM_NCCL(h, r.Send(p.at(field, send_dn_from(c)), p.count(), ty, c->dn, c->nccl, c->stream));
-        }
-        if (c->up >= 0) COMM_NCCL(h, r.Recv(p.at(field, p.nloc), p.count(), ty, c->up, c->nccl, c->stream));
-        COMM_NCCL(h, r.GroupEnd());
-        COMM_HIP(h, hipEventRecord(c->ev_done[par], c->stream));
-        return LSM_OK;
-    }
-    // LOCAL: post; the last rank to post enqueues the copies of the whole group
-    LocalGroup* g = c->grp;
-    std::unique_lock<std::mutex> lk(g->mu);
-    g->seq[c->rank] = seq;
-    g->field[c->rank] = field;
-    if (++g->nposted == g->world) {
-        g->nposted = 0;
-        const int rc = local_enqueue(g, seq);
-        g->posted_seq = seq;
-        lk.unlock();
-        g->cv.notify_all();
-        return rc;
-    }
-    return LSM_OK;
+    const Planes p = planes_of(h, esize(h));
+    Msg m;
+    const size_t nb = p.bytes(p.G);
+    if (c->up >= 0) { m.send_up = p.at(field, send_up_from(c, p)); m.n_send_up = nb; m.recv_up = p.at(field, p.nloc); m.n_recv_up = nb; }
+    if (c->dn >= 0) { m.recv_dn = p.at(field, -p.G); m.n_recv_dn = nb; m.send_dn = p.at(field, send_dn_from(c)); m.n_send_dn = nb; }
+    return exchange_start(h, m, h->dtype == LSM_DTYPE_F32 ? ncclFloat : ncclDouble, esize(h), "lsm_halo_start");
 }
 
-// The handle's stream waits for the planes received (and, LOCAL, for the neighbours' reads of this rank's planes).
-// LOCAL blocks the calling thread until every rank of the group has posted the exchange.
 int lsm_halo_wait(LsmHandle* h) {
     if (!h) return LSM_ERR_INVALID;
-    LsmComm* c = h->comm;
-    if (!c) return lsm_fail(h, LSM_ERR_INVALID, "lsm_halo_wait: no communicator attached");
-    if (!c->pending) return LSM_OK;
-    c->pending = false;
-    const int par = (int)(c->seq & 1);
-    COMM_HIP(h, hipSetDevice(h->device));
-    if (c->transport == LSM_COMM_LOCAL) {
-        LocalGroup* g = c->grp;
-        {
-            std::unique_lock<std::mutex> lk(g->mu);
-            g->cv.wait(lk, [&] { return g->posted_seq >= c->seq; });
-        }
-        if (c->dn >= 0) COMM_HIP(h, hipStreamWaitEvent(h->stream, g->handles[c->dn]->comm->ev_done[par], 0));
-        if (c->up >= 0) COMM_HIP(h, hipStreamWaitEvent(h->stream, g->handles[c->up]->comm->ev_done[par], 0));
-    }
-    COMM_HIP(h, hipStreamWaitEvent(h->stream, c->ev_done[par], 0));
-    return LSM_OK;
+    if (!h->comm) return lsm_fail(h, LSM_ERR_INVALID, "lsm_halo_wait: no communicator attached");
+    return exchange_wait(h, "lsm_halo_wait");
 }
 
 int lsm_halo_exchange(LsmHandle* h, void* field) {
@@ -388,21 +676,27 @@ int lsm_allreduce_dt(LsmHandle* h, double* dt) {
     LsmComm* c = h->comm;
     if (!c) return lsm_fail(h, LSM_ERR_INVALID, "lsm_allreduce_dt: no communicator attached");
     if (c->world == 1) return LSM_OK;
+    if (c->failed.load()) return comm_failed(h, c, "lsm_allreduce_dt");
     if (c->transport == LSM_COMM_RCCL) {
         // NaN encoded as -1 (any valid or invalid Δt is >= 0 or NaN; -Inf cannot occur): MIN then makes it win
-        const double enc = *dt != *dt ? -1.0 : *dt;
+        *c->h_dt = *dt != *dt ? -1.0 : *dt;
         COMM_HIP(h, hipSetDevice(h->device));
         // on the handle's stream, behind the stages of the previous step: one collective in flight per rank at a time
-        COMM_HIP(h, hipMemcpyAsync(c->d_dt, &enc, sizeof(double), hipMemcpyHostToDevice, h->stream));
-        COMM_NCCL(h, rccl().AllReduce(c->d_dt, c->d_dt, 1, ncclDouble, ncclMin, c->nccl, h->stream));
-        double out = 0.0;
-        COMM_HIP(h, hipMemcpyAsync(&out, c->d_dt, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        COMM_HIP(h, hipStreamSynchronize(h->stream));
-        *dt = out < 0 ? __builtin_nan("") : out;
+        COMM_HIP(h, hipMemcpyAsync(c->d_dt, c->h_dt, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const ncclResult_t nr = rccl().AllReduce(c->d_dt, c->d_dt, 1, ncclDouble, ncclMin, c->nccl, h->stream);
+        if (nr != ncclSuccess) {
+            c->failed.store(true);
+            return lsm_fail(h, LSM_ERR_COMM, std::string("lsm_allreduce_dt: RCCL: ") + rccl().GetErrorString(nr));
+        }
+        COMM_HIP(h, hipMemcpyAsync(c->h_dt, c->d_dt, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        const int rc = stream_wait(h, c, "lsm_allreduce_dt");
+        if (rc) return rc;
+        *dt = *c->h_dt < 0 ? __builtin_nan("") : *c->h_dt;
         return LSM_OK;
     }
     LocalGroup* g = c->grp;
     std::unique_lock<std::mutex> lk(g->mu);
+    if (g->failed) { c->failed.store(true); return lsm_fail(h, LSM_ERR_COMM, "lsm_allreduce_dt: " + g->why); }
     g->red[c->rank] = *dt;
     const unsigned long long gen = g->red_gen;
     if (++g->nred == g->world) {
@@ -419,8 +713,119 @@ int lsm_allreduce_dt(LsmHandle* h, double* dt) {
         *dt = m;
         return LSM_OK;
     }
-    g->cv.wait(lk, [&] { return g->red_gen != gen; });
+    const int rc = group_wait(h, c, lk, [&] { return g->red_gen != gen; }, "lsm_allreduce_dt");
+    if (rc) return rc;
     *dt = g->red_result;
+    return LSM_OK;
+}
+
+// ---- slab-decomposed NarrowBandMeshField --------------------------------------------------------------------------------
+// A band's operations reach farther across a slab interface than a stencil (nearest band node within 6, its slope
+// neighbour, the stencil's 3 — src/meshfield.jl:481-530), so the slab of each rank is created `overlap` planes larger towards
+// each neighbour; those planes are ordinary planes of the slab, computed redundantly, and refreshed from their owners:
+//   lsm_band_overlap_mask    whole planes of mask bytes; then both sides enumerate the band nodes of the exchanged plane
+//                            ranges in index order from the (now identical) masks — no index ever travels.  Synchronous
+//                            (the list lengths size the value messages).
+//   lsm_band_overlap_values  the values of exactly those nodes, packed (≈0.4 MB instead of 48 MB per direction at 768³).
+int lsm_band_overlap_config(LsmHandle* h, int64_t overlap) {
+    if (!h) return LSM_ERR_INVALID;
+    LsmComm* c = h->comm;
+    if (!c) return lsm_fail(h, LSM_ERR_INVALID, "lsm_band_overlap_config: no communicator attached");
+    const int N = h->grid.ndim;
+    const int64_t need = overlap * ((c->dn >= 0 ? 1 : 0) + (c->up >= 0 ? 1 : 0)) + overlap;
+    if (overlap < 1 || h->nloc[N - 1] < need)
+        return lsm_fail(h, LSM_ERR_INVALID, "lsm_band_overlap_config: the slab must hold `overlap` planes of each neighbour and at least as many of its own");
+    if (c->wrap_up || c->wrap_dn) return lsm_fail(h, LSM_ERR_INVALID, "lsm_band_overlap_config: PeriodicBC is not supported on a NarrowBandMeshField");
+    c->band_W = (int)overlap;
+    for (int k = 0; k < 4; ++k) c->n_idx[k] = 0;
+    if (!c->d_nz_total) {
+        COMM_HIP(h, hipSetDevice(h->device));
+        COMM_HIP(h, hipMalloc((void**)&c->d_nz_total, 4 * sizeof(unsigned)));
+        COMM_HIP(h, hipHostMalloc((void**)&c->h_nz_total, 4 * sizeof(unsigned), hipHostMallocDefault));
+    }
+    return LSM_OK;
+}
+
+int lsm_band_overlap_mask(LsmHandle* h, void* mask) {
+    if (!h || !mask) return LSM_ERR_INVALID;
+    LsmComm* c = h->comm;
+    if (!c || c->band_W < 1) return lsm_fail(h, LSM_ERR_INVALID, "lsm_band_overlap_mask: call lsm_band_overlap_config first");
+    const Planes p = planes_of(h, 1);
+    const int W = c->band_W;
+    int first[4];
+    band_ranges(h, c, first);
+    const size_t nb = p.bytes(W);
+    Msg m;
+    if (first[0] >= 0) { m.send_up = p.at(mask, first[0]); m.n_send_up = nb; m.recv_up = p.at(mask, first[3]); m.n_recv_up = nb; }
+    if (first[1] >= 0) { m.recv_dn = p.at(mask, first[1]); m.n_recv_dn = nb; m.send_dn = p.at(mask, first[2]); m.n_send_dn = nb; }
+    int rc = exchange_start(h, m, ncclChar, 1, "lsm_band_overlap_mask");
+    if (rc == LSM_OK) rc = exchange_wait(h, "lsm_band_overlap_mask");
+    if (rc) return rc;
+    // band nodes of the four plane ranges, in index order
+    const unsigned nchunks = (unsigned)((nb + NZ_CHUNK - 1) / NZ_CHUNK);
+    COMM_HIP(h, hipSetDevice(h->device));
+    if (c->nz_cap < (size_t)4 * nchunks) {
+        if (c->d_nz_counts) (void)hipFree(c->d_nz_counts);
+        c->d_nz_counts = nullptr; c->nz_cap = 0;
+        COMM_HIP(h, hipMalloc((void**)&c->d_nz_counts, (size_t)4 * nchunks * sizeof(unsigned)));
+        c->nz_cap = (size_t)4 * nchunks;
+    }
+    COMM_HIP(h, hipMemsetAsync(c->d_nz_total, 0, 4 * sizeof(unsigned), h->stream));
+    for (int k = 0; k < 4; ++k) {
+        if (first[k] < 0) continue;
+        const unsigned char* base = (const unsigned char*)p.at(mask, first[k]);
+        hipLaunchKernelGGL(nz_count_kernel, dim3(nchunks), dim3(256), 0, h->stream, base, nb, c->d_nz_counts + (size_t)k * nchunks);
+        hipLaunchKernelGGL(nz_scan_kernel, dim3(1), dim3(1024), 0, h->stream, c->d_nz_counts + (size_t)k * nchunks, nchunks, c->d_nz_total + k);
+    }
+    COMM_HIP(h, hipMemcpyAsync(c->h_nz_total, c->d_nz_total, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    COMM_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t es = esize(h);
+    for (int k = 0; k < 4; ++k) {
+        c->n_idx[k] = first[k] >= 0 ? c->h_nz_total[k] : 0u;
+        if (!c->n_idx[k]) continue;
+        if (c->idx_cap[k] < c->n_idx[k]) {
+            if (c->d_idx[k]) (void)hipFree(c->d_idx[k]);
+            if (c->d_pack[k]) (void)hipFree(c->d_pack[k]);
+            c->d_idx[k] = nullptr; c->d_pack[k] = nullptr; c->idx_cap[k] = 0;
+            const size_t cap = (size_t)c->n_idx[k] + c->n_idx[k] / 2 + 1024;
+            COMM_HIP(h, hipMalloc((void**)&c->d_idx[k], cap * sizeof(unsigned)));
+            COMM_HIP(h, hipMalloc((void**)&c->d_pack[k], cap * sizeof(double)));
+            c->idx_cap[k] = cap;
+        }
+        const unsigned char* base = (const unsigned char*)p.at(mask, first[k]);
+        hipLaunchKernelGGL(nz_write_kernel, dim3(nchunks), dim3(256), 0, h->stream, base, nb, c->d_nz_counts + (size_t)k * nchunks, c->d_idx[k], c->idx_cap[k]);
+    }
+    (void)es;
+    COMM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+int lsm_band_overlap_values(LsmHandle* h, void* field) {
+    if (!h || !field) return LSM_ERR_INVALID;
+    LsmComm* c = h->comm;
+    if (!c || c->band_W < 1) return lsm_fail(h, LSM_ERR_INVALID, "lsm_band_overlap_values: call lsm_band_overlap_config first");
+    const size_t es = esize(h);
+    const Planes p = planes_of(h, es);
+    int first[4];
+    band_ranges(h, c, first);
+    COMM_HIP(h, hipSetDevice(h->device));
+    for (int k : {0, 2})      // pack what this rank sends
+        if (first[k] >= 0 && c->n_idx[k])
+            hipLaunchKernelGGL(pack_kernel, dim3((c->n_idx[k] + 255u) / 256u), dim3(256), 0, h->stream, (const char*)p.at(field, first[k]), c->d_idx[k],
+                               c->n_idx[k], (int)es, c->d_pack[k]);
+    Msg m;
+    m.send_up = c->d_pack[0]; m.n_send_up = es * c->n_idx[0];
+    m.recv_dn = c->d_pack[1]; m.n_recv_dn = es * c->n_idx[1];
+    m.send_dn = c->d_pack[2]; m.n_send_dn = es * c->n_idx[2];
+    m.recv_up = c->d_pack[3]; m.n_recv_up = es * c->n_idx[3];
+    int rc = exchange_start(h, m, ncclChar, 1, "lsm_band_overlap_values");
+    if (rc == LSM_OK) rc = exchange_wait(h, "lsm_band_overlap_values");
+    if (rc) return rc;
+    for (int k : {1, 3})      // scatter what it received
+        if (first[k] >= 0 && c->n_idx[k])
+            hipLaunchKernelGGL(unpack_kernel, dim3((c->n_idx[k] + 255u) / 256u), dim3(256), 0, h->stream, (char*)p.at(field, first[k]), c->d_idx[k],
+                               c->n_idx[k], (int)es, c->d_pack[k]);
+    COMM_HIP(h, hipGetLastError());
     return LSM_OK;
 }
 

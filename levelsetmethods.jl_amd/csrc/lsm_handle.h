@@ -65,8 +65,8 @@ struct LsmHandle {
     size_t ev_used;
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
-    unsigned* d_tail_ctr;          // ticket counter of the dynamic tail (never reset: launches pass their base)
-    unsigned tail_ticket;          // host: next base
+    unsigned* d_tail_ctr;          // ring of LSM_TAIL_SLOTS ticket counters of the dynamic tail (each launch resets its own)
+    unsigned tail_ticket;          // host: launches that took a slot so far
     bool xredirect;                // set around the stages of a whole-grid lsm_advance_*: x ghosts are resolved by the stage kernel's loads
     unsigned long long* d_stamp;   // diagnostic build (-DLSM_STAMP): 8192 x {Δs_memtime, Δs_memrealtime, start, end} of the stage kernel's workgroups
 };
@@ -75,3 +75,4 @@ struct LsmHandle {
 int lsm_fail(LsmHandle* h, int code, const std::string& msg);
 // lsm_comm.hip: the attached communicator wants boundary-first stages (lsm_comm_set_overlap; LSM_SLAB_OVERLAP=0 at attach time)
 bool lsm_comm_overlap(const LsmHandle* h);
+int lsm_comm_band_overlap(const LsmHandle* h);   // overlap depth declared by lsm_band_overlap_config (0 = none)

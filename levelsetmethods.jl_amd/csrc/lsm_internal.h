@@ -75,10 +75,16 @@ struct StageArgs {
     // dynamic tail (set by the launcher when the graded tail is on and the handle lends its counter): the workgroups behind
     // the long chunks take the short chunks in the order they START, through one ticket counter — the eight XCDs get equal
     // numbers of workgroups from the hardware but do not run at the same speed; 30 % spare tail workgroups let the faster
-    // ones take more of the tail.  ticket = atomicAdd(tail_ctr, 1) - tail_base; tickets past the last short chunk leave.
-    unsigned* tail_ctr;
-    unsigned tail_base, tail_wgs;
-    unsigned* tail_ticket_host;        // host side: the handle's running ticket base (advanced by tail_wgs per launch)
+    // ones take more of the tail.  ticket = atomicAdd(tail_ctr, 1); tickets past the last short chunk leave.  Every launch is
+    // self-contained: exactly tail_wgs workgroups draw, and the one that draws the last ticket sets the counter back to 0.  The
+    // handle lends a RING of LSM_TAIL_SLOTS counters and every launch takes the next one, so a counter is re-used only
+    // LSM_TAIL_SLOTS launches later; launches on a stream other than the handle's own get no counter at all (tail_ring ==
+    // NULL: static tail) — two launches that could run concurrently never share one, and a launch that failed leaves nothing
+    // behind (the slot still holds 0).
+    unsigned* tail_ctr;                // this launch's counter (set by the launcher from tail_ring)
+    unsigned tail_wgs;
+    unsigned* tail_ring;               // LSM_TAIL_SLOTS counters, all 0 between launches (NULL = no dynamic tail)
+    unsigned* tail_slot_host;          // host side: the handle's running launch count (selects the slot)
     int xredirect;
     int xkind[2];
     int yredirect;     // the same for dimension 2 of a 3-D grid (the tile's y): its ghost rows are skipped by the fills as well
@@ -90,6 +96,8 @@ struct StageArgs {
     int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
     unsigned long long* stamp;         // diagnostic build (-DLSM_STAMP, `make stamp`): per-workgroup {Δs_memtime, Δs_memrealtime} of the plane loop
 };
+
+#define LSM_TAIL_SLOTS 16
 
 struct GhostArgs {
     int n[3];
@@ -149,6 +157,7 @@ struct BandArgs {
     unsigned nlist;
     int f32;                     // the value arrays hold float
     int force_bytes;             // A/B switch (LSM_BAND_BYTES at lsm_create): byte-mask kernels in 3-D too
+    int exp;                     // timing experiments (LSM_BAND_EXP bit mask, results are WRONG): see lsm_band.hip
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s);
 void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
@@ -163,6 +172,7 @@ struct BandEntry {          // a halo node and its nearest band node (16 bytes)
     signed char d[4];       // I - P per dimension
 };
 void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s);
+void launch_band_copy_values(const BandArgs& a, const unsigned char* mask, const void* src, void* dst, hipStream_t s);
 void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s);
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,

@@ -972,7 +972,12 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     bool tail_tile;
     if (NDIM == 3 && !MASKED && a.tail_wgs && blockIdx.x >= 8u * ord.big_per) {      // dynamic tail (StageArgs::tail_ctr)
         __shared__ unsigned s_ticket;
-        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.tail_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.tail_base;
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(a.tail_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // exactly tail_wgs workgroups draw: the last ticket leaves the counter at 0 for the slot's next launch
+            if (t + 1u == a.tail_wgs) __hip_atomic_store(a.tail_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = t;
+        }
         __syncthreads();
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
         if (t >= ord.ntiles - ord.nbigt) return;
@@ -1083,11 +1088,10 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
         const unsigned nbigt = b.nb[0] * b.nb[1] * b.nbig;
         grid.x = 8u * ((nbigt + 7u) / 8u + (ntiles - nbigt + 7u) / 8u);
         static const int dyn_env = getenv("LSM_STAGE_TAIL_DYN") ? atoi(getenv("LSM_STAGE_TAIL_DYN")) : LSM_STAGE_TAIL_DYN_DEFAULT;
-        if (dyn_env > 0 && a.tail_ctr && a.tail_ticket_host && nbigt % 8u == 0) {
+        if (dyn_env > 0 && a.tail_ring && a.tail_slot_host && nbigt % 8u == 0) {
             const unsigned ntail = ntiles - nbigt;
             b.tail_wgs = ((ntail + ntail * (unsigned)dyn_env / 100u) + 7u) / 8u * 8u;      // dyn_env % spare workgroups
-            b.tail_base = *a.tail_ticket_host;
-            *a.tail_ticket_host += b.tail_wgs;
+            b.tail_ctr = a.tail_ring + (*a.tail_slot_host)++ % LSM_TAIL_SLOTS;
             grid.x = nbigt + b.tail_wgs;
         }
     }

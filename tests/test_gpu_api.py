@@ -226,88 +226,6 @@ def test_volume_perimeter_known_answers_and_parity(lsm, orc):
     assert st.values()[3, 4, 5] == 7.5 and st.ghosts_dirty
 
 
-class _FakeWorld:
-    """In-process stand-in for a torch.distributed group: the ranks are threads of this process, point-to-point
-    messages are device-tensor copies through FIFO mailboxes (matched in posting order per pair, as RCCL does)."""
-
-    def __init__(self, world):
-        import threading
-        self.world = world
-        self.cond = threading.Condition()
-        self.mail = {}
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-
-    def post(self, src, dst, t):
-        with self.cond:
-            self.mail.setdefault((src, dst), []).append(t.clone())
-            self.cond.notify_all()
-
-    def take(self, src, dst):
-        with self.cond:
-            assert self.cond.wait_for(lambda: self.mail.get((src, dst)), timeout=120), "exchange deadlock"
-            return self.mail[(src, dst)].pop(0)
-
-    def exchange(self, rank, value):
-        self.slots[rank] = value
-        self.barrier.wait()
-        out = list(self.slots)
-        self.barrier.wait()
-        return out
-
-
-class _FakeRank:
-    def __init__(self, w, rank):
-        self.w, self.rank = w, rank
-
-
-def _patch_dist(monkeypatch):
-    import collections
-    import torch.distributed as dist
-    P2P = collections.namedtuple("P2POp", "op tensor peer group")
-    monkeypatch.setattr(dist, "get_rank", lambda g=None: g.rank)
-    monkeypatch.setattr(dist, "get_world_size", lambda g=None: g.w.world)
-    monkeypatch.setattr(dist, "P2POp", lambda op, tensor, peer, group=None: P2P(op, tensor, peer, group))
-    monkeypatch.setattr(dist, "isend", "isend")
-    monkeypatch.setattr(dist, "irecv", "irecv")
-
-    class Work:
-        def __init__(self, fn):
-            self.fn = fn
-
-        def wait(self):
-            self.fn()
-
-    def batch(ops):
-        works = []
-        for o in ops:
-            g = o.group
-            if o.op == "isend":
-                g.w.post(g.rank, o.peer, o.tensor)
-            else:
-                works.append(Work(lambda o=o, g=g: o.tensor.copy_(g.w.take(o.peer, g.rank))))
-        return works
-
-    def all_reduce(x, op=None, group=None):
-        vals = group.w.exchange(group.rank, x.clone())
-        r = vals[0].clone()
-        for v in vals[1:]:
-            r = torch_min(r, v) if op == dist.ReduceOp.MIN else r + v
-        x.copy_(r)
-
-    import torch
-    torch_min = torch.minimum
-
-    def all_gather_object(parts, v, group=None):
-        vals = group.w.exchange(group.rank, v)
-        for i, x in enumerate(vals):
-            parts[i] = x
-
-    monkeypatch.setattr(dist, "batch_isend_irecv", batch)
-    monkeypatch.setattr(dist, "all_reduce", all_reduce)
-    monkeypatch.setattr(dist, "all_gather_object", all_gather_object)
-
-
 @pytest.mark.parametrize("world,bc,overlap,integ", [(2, "neumann", True, "rk3"), (3, "neumann", False, "rk3"), (3, "periodic", True, "rk3"),
                                                    (2, "periodic", False, "rk3"), (3, "periodic", True, "rk2"), (2, "neumann", True, "fe"),
                                                    (4, "extrap2", True, "rk2")])
@@ -342,9 +260,9 @@ def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkey
         except BaseException as e:   # noqa: BLE001 - reported by the main thread
             import traceback
             errs.append((r, traceback.format_exc()))
-            g._barrier.abort()
+            g.abort()
 
-    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:
@@ -360,9 +278,10 @@ def test_slab_handles_on_one_gpu_compose_to_the_single_device_result(lsm, monkey
 def test_slab_decomposed_narrow_band_matches_single_device(lsm, monkeypatch, world, integ, reinit):
     """BASELINE config 5's decomposition: a narrow band cut into slabs.  Each rank carries BAND_OVERLAP planes of its
     neighbours and refreshes them after every stage and band update; on the planes a rank owns, the band set and
-    the values must equal the single-device band run bit for bit (ranks = threads over the in-process group)."""
+    the values must equal the single-device band run bit for bit.  Ranks = threads over an LSM_COMM_LOCAL group: the mask
+    planes, the sparse values and Δt all move inside the library (lsm_band_overlap_mask / _values, lsm_advance_band_*,
+    lsm_allreduce_dt) — the calls a Julia host would make."""
     import threading
-    _patch_dist(monkeypatch)
     n = (28, 24, 66)
     grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), n)
     phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.05) ** 2 + x[1] ** 2 + (x[2] + 0.02) ** 2) - 0.62, grid)
@@ -378,12 +297,13 @@ def test_slab_decomposed_narrow_band_matches_single_device(lsm, monkeypatch, wor
     st = ref.current_state()
     want_m, want_v = st.active_mask(), st.values()
     assert want_m[:, :, 20:46].any() and 2000 < want_m.sum()       # the band crosses every slab interface
-    w = _FakeWorld(world)
+    g = lsm.LocalGroup(world)
     got, errs = [None] * world, []
 
     def run(r):
         try:
-            eq = mk(comm=_FakeRank(w, r))
+            eq = mk(comm=g.rank(r))
+            assert eq.lib_comm and eq.backend.comm_info() == (r, world, 2)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 lsm.integrate_(eq, 0.04, posthook=hook)
@@ -393,9 +313,9 @@ def test_slab_decomposed_narrow_band_matches_single_device(lsm, monkeypatch, wor
         except BaseException as e:   # noqa: BLE001 - reported by the main thread
             import traceback
             errs.append((r, traceback.format_exc()))
-            w.barrier.abort()
+            g.abort()
 
-    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:
@@ -438,3 +358,50 @@ def test_fast_mode_refuses_fields_outside_its_domain(lsm):
     ok_eq._range_checked_at = 63
     with pytest.raises(ValueError, match="outside the domain"):
         lsm.integrate_(ok_eq, ok_eq.current_time() + 2 * dt)
+
+
+def test_whole_grid_stages_of_one_handle_on_two_streams(lsm):
+    """The dynamic tail of the dense 3-D stage kernel hands its short chunks out through a ticket counter.  Every launch is
+    self-contained (it resets its counter, consecutive launches take different counters of a ring), and a launch on a
+    caller's stream — which may run concurrently with one on the handle's — gets the static tail: two whole-grid stages of
+    one handle issued back to back on two streams produce exactly what the serial launches produce, and so do the serial
+    launches that follow them."""
+    import ctypes as C
+    import torch
+    from lsm_amd import _lib as L
+    from lsm_amd.api import _terms_c
+    n = 256                                            # 8 chunk layers of 32 planes: graded + dynamic tail are on
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (n, n, n))
+    ic = lsm.LazyMeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.35) ** 2) - 0.15, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((0.7, -0.4, 1.1), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+                              ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    b = eq.backend
+    psi = eq.state.buf
+    b.fill_ghosts(psi, 7)
+    arr, nt = _terms_c(eq.terms), len(eq.terms)
+    ref = [b.alloc() for _ in range(2)]
+    for k, o in enumerate(ref):
+        b.stage(arr, nt, psi, None, o, None, L.BASE_PSI, 1e-3 * (k + 1), 0.0, 0.0)
+    b.sync()
+    outs = [b.alloc() for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for rep in range(3):
+        for k, (o, s) in enumerate(zip(outs, streams)):
+            L.check(b.h, b.lib.lsm_stage(b.h, arr, nt, b.ptr(psi), None, b.ptr(o), None, L.BASE_PSI, 1e-3 * (k + 1), 0.0, 0.0,
+                                         C.c_void_p(s.cuda_stream)), "lsm_stage")
+        # ... and one on the handle's own stream at the same time (it uses the ticket counters)
+        own = b.alloc()
+        b.stage(arr, nt, psi, None, own, None, L.BASE_PSI, 1e-3, 0.0, 0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1]) and torch.equal(own, ref[0]), rep
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()              # the zeroing ran on torch's stream: order it before the next round on the side streams
+    # many serial launches in a row: every slot of the counter ring is taken more than once
+    for rep in range(40):
+        o = outs[rep % 2]
+        b.stage(arr, nt, psi, None, o, None, L.BASE_PSI, 1e-3 * (rep % 2 + 1), 0.0, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])

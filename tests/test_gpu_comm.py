@@ -168,9 +168,9 @@ def test_local_groups_in_two_dimensions_and_float32(lsm, ndim, dtype, integ, wor
         except BaseException:   # noqa: BLE001 - reported by the main thread
             import traceback
             errs.append((r, traceback.format_exc()))
-            g._barrier.abort()
+            g.abort()
 
-    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
     for t in ts:
         t.start()
     for t in ts:
@@ -178,3 +178,122 @@ def test_local_groups_in_two_dimensions_and_float32(lsm, ndim, dtype, integ, wor
     assert not errs, errs
     full = np.concatenate(got, axis=ndim - 1)
     assert np.array_equal(full, want), np.abs(full.astype(np.float64) - want).max()
+
+
+def _three_slabs(lsm):
+    from lsm_amd.api import _bc_c, _normalize_bc
+    from lsm_amd.backend import HipBackend
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (16, 16, 36))
+    bcs = _normalize_bc(lsm.NeumannBC(), 3)
+    backs = [HipBackend(grid._c(), _bc_c(bcs, 3, (r > 0, r < 2)), slab=(12 * r, 12)) for r in range(3)]
+    HipBackend.comm_attach_local(backs)
+    return backs
+
+
+@pytest.mark.parametrize("how", ["abort", "leave"])
+def test_a_failed_rank_fails_its_peers_instead_of_hanging_them(lsm, how):
+    """include/lsm.h, "Failure": rank 1 of three never posts its exchange — it calls lsm_comm_abort, or is destroyed — while
+    ranks 0 and 2 sit in lsm_halo_wait / lsm_allreduce_dt: they return LSM_ERR_COMM within a second, and every later call on
+    their communicators fails the same way."""
+    import threading
+    import time
+    from lsm_amd import _lib as L
+    backs = _three_slabs(lsm)
+    fields = [b.alloc() for b in backs]
+    out, t_done = {}, {}
+
+    def waiter(r, what):
+        try:
+            if what == "halo":
+                backs[r].halo_start(fields[r])
+                backs[r].halo_wait()
+            else:
+                backs[r].allreduce_dt(0.1)
+            out[r] = "returned"
+        except L.LsmCommError as e:
+            out[r] = str(e)
+        t_done[r] = time.perf_counter()
+
+    ts = [threading.Thread(target=waiter, args=(0, "halo"), daemon=True), threading.Thread(target=waiter, args=(2, "halo"), daemon=True)]
+    for t in ts:
+        t.start()
+    time.sleep(0.3)                      # both are blocked now: rank 1 has not posted
+    assert not out
+    t0 = time.perf_counter()
+    if how == "abort":
+        backs[1].comm_abort()
+    else:
+        backs[1].close()
+    for t in ts:
+        t.join(5)
+    assert set(out) == {0, 2} and all("aborted by rank 1" in v or "rank 1 has left" in v for v in out.values()), out
+    assert max(t_done.values()) - t0 < 1.0
+    # the communicators stay failed
+    for r in (0, 2):
+        with pytest.raises(L.LsmCommError):
+            backs[r].allreduce_dt(0.5)
+        with pytest.raises(L.LsmCommError):
+            backs[r].halo_exchange(fields[r])
+    for b in backs:
+        b.close()
+
+
+def test_finished_rank_may_be_destroyed_while_a_neighbour_still_orders_its_stream(lsm):
+    """The group owns the exchange streams and events: rank 0 completes an exchange and is destroyed at once; rank 1, which
+    posted the same exchange, still waits for it successfully afterwards (its stream is ordered behind events that must
+    outlive rank 0's handle), and only its NEXT exchange reports the missing peer."""
+    from lsm_amd import _lib as L
+    from lsm_amd.api import _bc_c, _normalize_bc
+    from lsm_amd.backend import HipBackend
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (16, 16, 24))
+    bcs = _normalize_bc(lsm.NeumannBC(), 3)
+    b0 = HipBackend(grid._c(), _bc_c(bcs, 3, (False, True)), slab=(0, 12))
+    b1 = HipBackend(grid._c(), _bc_c(bcs, 3, (True, False)), slab=(12, 12))
+    HipBackend.comm_attach_local([b0, b1])
+    f0, f1 = b0.alloc(), b1.alloc()
+    f0.fill_(1.0)
+    f1.fill_(2.0)
+    b0.halo_start(f0)
+    b1.halo_start(f1)
+    b0.halo_wait()
+    b0.sync()
+    b0.close()                           # rank 0 is gone; its planes were read by rank 1's copies already (close waits for them)
+    b1.halo_wait()                       # complete exchange: succeeds
+    b1.sync()
+    lay = b1.lay
+    sl = int(lay.stride[2])
+    ghosts = f1[:3 * sl].cpu().numpy()   # the three ghost planes below rank 1's slab hold rank 0's values
+    assert (ghosts == 1.0).all()
+    with pytest.raises(L.LsmCommError, match="rank 0 has left"):
+        b1.halo_exchange(f1)
+    b1.close()
+
+
+def test_comm_timeout_in_a_fresh_process(lsm, tmp_path):
+    """LSM_COMM_TIMEOUT_MS (read once per process): a rank that waits for a peer which never posts gives up by itself."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import sys, time
+sys.path.insert(0, %r)
+import lsm_amd as lsm
+from lsm_amd import _lib as L
+from lsm_amd.api import _bc_c, _normalize_bc
+from lsm_amd.backend import HipBackend
+grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), (16, 16, 24))
+bcs = _normalize_bc(lsm.NeumannBC(), 3)
+b0 = HipBackend(grid._c(), _bc_c(bcs, 3, (False, True)), slab=(0, 12))
+b1 = HipBackend(grid._c(), _bc_c(bcs, 3, (True, False)), slab=(12, 12))
+HipBackend.comm_attach_local([b0, b1])
+t0 = time.perf_counter()
+try:
+    b0.halo_exchange(b0.alloc())
+    print("RETURNED")
+except L.LsmCommError as e:
+    print("COMM_ERROR %%.2f %%s" %% (time.perf_counter() - t0, e))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSM_COMM_TIMEOUT_MS="400")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "COMM_ERROR" in r.stdout and "timed out" in r.stdout, (r.stdout, r.stderr[-2000:])
+    assert 0.3 < float(r.stdout.split()[1]) < 3.0

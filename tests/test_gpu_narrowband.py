@@ -494,3 +494,44 @@ def test_active_cellindices(lsm):
     nodes = set(st.active_nodeindices())
     want = {I for I in nodes if I[0] < 30 and I[1] < 28 and all((I[0] + a, I[1] + b) in nodes for a in (0, 1) for b in (0, 1))}
     assert set(st.active_cellindices()) == want and len(want) > 50
+
+
+@pytest.mark.parametrize("shape,integ,dtype,hooked", [((40, 36, 44), "rk3", "float32", False), ((40, 36, 44), "rk2", "float64", False),
+                                                    ((40, 36, 44), "fe", "float64", False), ((48, 40), "rk3", "float64", False),
+                                                    ((30, 28, 26), "rk3", "float64", True), ((48, 40), "rk2", "float32", True)])
+def test_library_band_step_equals_the_stage_by_stage_sequence_bitwise(lsm, monkeypatch, shape, integ, dtype, hooked):
+    """lsm_advance_band_fe/rk2/rk3 (what `_advance!` of a band field ccalls, include/lsm.h) against the same step driven stage
+    by stage through lsm_band_prepare + lsm_stage_band: band sets and band values bit for bit over several steps with
+    update_band! between them — with and without an update hook (a speed field refreshed from the stage input at the stage
+    time, src/timestepping.jl:174,185,196)."""
+    dt = np.dtype(dtype)
+    N = len(shape)
+    grid = lsm.CartesianGrid((-1.0,) * N, (1.0,) * N, shape)
+    phi = lsm.MeshField(lambda x: np.sqrt(sum((xi - 0.07 * (i + 1)) ** 2 for i, xi in enumerate(x))) - 0.55, grid, dtype=dt)
+    I = {"rk3": lsm.RK3, "rk2": lsm.RK2, "fe": lsm.ForwardEuler}[integ]
+    calls = []
+
+    def terms():
+        adv = lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5())
+        if not hooked:
+            return (adv, lsm.CurvatureTerm(-0.02))
+        speed = lsm.MeshField(np.zeros(shape), grid)
+
+        def upd(coeff, field, t):            # v = 0.3 + t: depends on the stage time only, so both drivers see the same field
+            calls.append(t)
+            coeff.set_values(np.full(shape, 0.3 + t))
+        return (adv, lsm.NormalMotionTerm(speed, update_func=upd))
+
+    def run(py):
+        monkeypatch.setenv("LSM_BAND_PY", "1" if py else "0")
+        calls.clear()
+        eq = lsm.LevelSetEquation(terms=terms(), ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2), integrator=I())
+        lsm.integrate_(eq, 0.05)
+        st = eq.current_state()
+        return st.active_mask(), st.values(), list(calls)
+
+    m0, v0, c0 = run(True)
+    m1, v1, c1 = run(False)
+    assert m0.sum() > 500 and np.array_equal(m0, m1)
+    assert v0.dtype == dt and np.array_equal(v0[m0], v1[m1])
+    assert c0 == c1 and (len(c0) > 0) == hooked

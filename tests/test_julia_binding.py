@@ -169,7 +169,7 @@ def compare(header_text, julia_text):
             hdim = None if hd is None else str(consts.get(hd, hd))
             if (hn, hb, hdim) != (jn, jb, jd):
                 errs.append(f"struct {name}: field {jn}::{jt} where the header has {hb} {hn}" + (f"[{hd}]" if hd else ""))
-    for need in ("LsmGrid", "LsmBc", "LsmSlab", "LsmLayout", "LsmCoeff", "LsmTerm"):
+    for need in ("LsmGrid", "LsmBc", "LsmSlab", "LsmLayout", "LsmCoeff", "LsmTerm", "LsmBand"):
         if need not in js:
             errs.append(f"struct {need} is not mirrored")
     hf = header_functions(h)
@@ -205,8 +205,27 @@ def test_julia_binding_matches_the_header():
                 "lsm_advance_fe", "lsm_advance_rk2", "lsm_advance_rk3", "lsm_eikonal_sign", "lsm_extrema", "lsm_fill_ghosts",
                 "lsm_comm_unique_id", "lsm_comm_attach_rccl", "lsm_comm_attach_local", "lsm_halo_start", "lsm_halo_wait",
                 "lsm_halo_exchange", "lsm_allreduce_dt", "lsm_comm_detach", "lsm_comm_info", "lsm_comm_set_overlap",
-                "lsm_band_update", "lsm_stage_band", "lsm_compute_cfl_band", "lsm_reinitialize", "lsm_volume", "lsm_perimeter"):
+                "lsm_band_update", "lsm_stage_band", "lsm_compute_cfl_band", "lsm_reinitialize", "lsm_volume", "lsm_perimeter",
+                # a NarrowBandMeshField steps through the same _advance! dispatch (src/timestepping.jl:128-202), slab-decomposed or not
+                "lsm_advance_band_fe", "lsm_advance_band_rk2", "lsm_advance_band_rk3", "lsm_band_status", "lsm_band_halo", "lsm_band_retile",
+                "lsm_band_overlap_config", "lsm_band_overlap_mask", "lsm_band_overlap_values", "lsm_comm_abort"):
         assert sym in called, f"{sym} is not bound"
+
+
+def test_the_band_field_has_every_method_the_integrator_dispatches_on():
+    """integrate! on a ROCNarrowBandMeshField must not end in a MethodError: _alloc_buffers and _advance! for the three
+    integrators, compute_cfl, update_band!, copy and copy! are defined on it (src/timestepping.jl:101-202, src/levelsetequation.jl:67-76)."""
+    j = _strip_jl_comments(open(JULIA).read())
+    for pat in (r"LSM\._alloc_buffers\(::LSM\.ForwardEuler, ϕ::ROCNarrowBandMeshField\)",
+                r"LSM\._alloc_buffers\(::Union\{LSM\.RK2, LSM\.RK3\}, ϕ::ROCNarrowBandMeshField\)",
+                r"function LSM\._advance!\(::LSM\.ForwardEuler, ϕ::ROCNarrowBandMeshField",
+                r"function LSM\._advance!\(::LSM\.RK2, ϕ::ROCNarrowBandMeshField",
+                r"function LSM\._advance!\(::LSM\.RK3, ϕ::ROCNarrowBandMeshField",
+                r"function LSM\.compute_cfl\(terms, ϕ::ROCNarrowBandMeshField",
+                r"function LSM\.update_band!\(ϕ::ROCNarrowBandMeshField",
+                r"function Base\.copy\(ϕ::ROCNarrowBandMeshField",
+                r"function Base\.copy!\(dst::ROCNarrowBandMeshField"):
+        assert re.search(pat, j), pat
 
 
 def test_header_parser_sees_every_declaration():
