@@ -118,7 +118,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->yredirect = false;
     h->cfl_cache_on = true;
     h->d_cand_count = nullptr;
-    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->work_cap = 0;
+    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->d_tiles_old = nullptr; h->work_cap = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
     h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
     h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
@@ -225,7 +225,7 @@ void lsm_destroy(LsmHandle* h) {
     if (h->ch_result) (void)hipHostFree(h->ch_result);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
     (void)hipFree(h->d_result);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1030,8 +1030,9 @@ static int ensure_ring(LsmHandle* h) {
 // handle-owned scratch for the per-tile work flags
 static int ensure_work(LsmHandle* h, int64_t ntiles) {
     if (h->work_cap >= ntiles) return LSM_OK;
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
     LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
+    LSM_HIP(h, hipMalloc((void**)&h->d_tiles_old, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_act_list, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_work_list, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_lcounts, 3 * sizeof(unsigned)));
@@ -1128,6 +1129,36 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
         a.work = h->d_work;
     }
     const size_t bytes = (size_t)h->lay.total;
+    // Bit-row path (lsm_band.hip): every node read once, the mask updated in place, new nodes extrapolated by the grow kernel itself
+    const bool bits_env = !(getenv("LSM_BAND_BITS") && getenv("LSM_BAND_BITS")[0] == '0');   // A/B switch (read per call: tests flip it)
+    const size_t words = (size_t)ntiles * (size_t)(a.ty * a.tm);                 // u32 words per bit array
+    if (bits_env && local && nlayers <= 3 && band_bits_fit(a, nlayers) && 2 * words * sizeof(unsigned) <= bytes &&
+        ((uintptr_t)scratch_a & 7) == 0 && ((uintptr_t)scratch_b & 7) == 0) {
+        unsigned *OB = (unsigned*)scratch_a, *LE = OB + words, *GE = (unsigned*)scratch_b, *NB = GE + words;
+        LSM_HIP(h, hipMemcpyAsync(h->d_tiles_old, tiles, (size_t)ntiles, hipMemcpyDeviceToDevice, h->stream));
+        BandArgs act = band_args(h, mc, nullptr);
+        if (listed) { act.list = h->d_act_list; act.nlist = h->nact; }
+        else act.work = h->d_tiles_old;
+        launch_band_bits(act, vals, (const unsigned char*)mask, OB, LE, GE, h->stream);
+        launch_band_grow_bits(a, vals, (unsigned char*)mask, nlayers, h->d_tiles_old, (unsigned char*)tiles, OB, LE, GE, NB, h->d_miss, h->stream);
+        LSM_HIP(h, hipGetLastError());
+        const bool interior_b = listed && h->nface == 0;     // the new band lies in the old work tiles: none on a face
+        h->lists_host_valid = false;                          // from here on the lists describe the previous band
+        if (interior_b && halo_list && halo_count) {
+            LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
+            launch_band_halo_bits(a, (const unsigned char*)tiles, NB, (unsigned char*)halo_mask, h->d_miss, (BandEntry*)halo_list,
+                                  (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
+            LSM_HIP(h, hipGetLastError());
+        } else {
+            LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior_b ? 1 : 0));
+        }
+        BandArgs full = band_args(h, mc, nullptr);
+        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->stream);
+        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+        h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
+        LSM_HIP(h, hipGetLastError());
+        return LSM_OK;
+    }
     unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
     const unsigned char* old_mask = from_dense ? nullptr : (const unsigned char*)mask;
     const bool fused = band_grow_fits(a, nlayers);

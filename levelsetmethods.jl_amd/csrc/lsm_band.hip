@@ -770,6 +770,378 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bit-row path of update_band! (3-D, 32×8×tm tiles, nlayers <= 3, a band that moves by less than a tile per step — the
+// conditions of the "listed" / "local" update of lsm_band_update).  The kernels above stage the byte mask and the values of a
+// tile's whole box (tile + apron: 5 times the tile) — one 40-byte mask row per lane and one 160-byte value row per wave
+// instruction, 17 k work tiles per step at 768³: they are bound by the latency of those rows.  Here every node is read ONCE:
+//   band_bits_kernel       per ACTIVE tile: mask bytes and values of the tile's own nodes -> three bit words per x-line
+//                          (in the band / value <= 0 / value >= 0), tile-major in a scratch array (64 words per tile and kind);
+//   band_grow_bits_kernel  per work tile: the box's row words assembled from the words of the 27 neighbouring tiles (one round
+//                          of independent 4-byte loads per thread; tiles without a band node are known from their flag and
+//                          not read), cut cells -> seeds -> dilations as in band_grow3_kernel, then — nothing else reads the
+//                          byte mask any more — the new band is written IN PLACE (only x-lines that changed), the newly
+//                          active nodes get their extrapolated value from the old band's words in LDS (_extrapolate_to_ghost,
+//                          src/meshfield.jl:481-511; no second kernel, no scratch mask, no copy pass), and the new band's words
+//                          are left for
+//   band_halo_bits_kernel  per work tile: halo mask and (node, nearest band node) list of the NEW band from its row words
+//                          (band_search3_kernel's search), with the slope neighbours of the nearest node resolved here —
+//                          band_apply_kernel then needs no mask reads.
+// ------------------------------------------------------------------------------------------------
+constexpr int BAP = 4;     // apron of the row-word boxes: nlayers + 1 <= 4 for the dilations, RL + 1 for the slope neighbours of a nearest node
+
+// flags of the 27 tiles around `tile` (0 outside the tile grid) -> nbflag[(dx+1) + 3 (dy+1) + 9 (dm+1)]
+__device__ __forceinline__ void load_nbflags(const BandArgs& a, unsigned tile, const unsigned char* flags, unsigned char* nbflag) {
+    if (threadIdx.x < 27) {
+        const int bx = tile % a.nbx, by = (tile / a.nbx) % a.nby, bm = tile / (a.nbx * a.nby);
+        const int X = bx + (int)(threadIdx.x % 3) - 1, Y = by + (int)((threadIdx.x / 3) % 3) - 1, M = bm + (int)(threadIdx.x / 9) - 1;
+        const bool ok = (unsigned)X < a.nbx && (unsigned)Y < a.nby && (unsigned)M < a.nbm;
+        nbflag[threadIdx.x] = ok ? flags[X + a.nbx * (Y + a.nby * M)] : (unsigned char)0;
+    }
+}
+// row words of the box (tile + apron BAP) of up to three bit arrays, assembled from the tile-major words of the neighbours
+template <int NA>
+__device__ __forceinline__ void stage_bit_rows(const BandArgs& a, unsigned tile, int by, int bm, const unsigned char* nbflag,
+                                               const unsigned* const (&src)[NA], u64* const (&dst)[NA]) {
+    const int bxT = tile % a.nbx, byT = (tile / a.nbx) % a.nby, bmT = tile / (a.nbx * a.nby);
+    const int y0 = byT * a.ty, m0 = bmT * a.tm, nrows = by * bm, wpt = a.ty * a.tm;
+    const int bxw = a.tx + 2 * BAP;
+    const float rby = 1.0f / (float)by;
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) {
+        int lm = (int)((float)t * rby), ly = t - lm * by;
+        if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+        const int gy = y0 - BAP + ly, gm = m0 - BAP + lm;
+        u64 w[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) w[k] = 0;
+        if ((unsigned)gy < (unsigned)a.n[1] && (unsigned)gm < (unsigned)a.n[2]) {
+            const int tyi = gy / a.ty, tmi = gm / a.tm;
+            const unsigned slot = (unsigned)((gy - tyi * a.ty) + a.ty * (gm - tmi * a.tm));
+            const int fb = 3 * (tyi - byT + 1) + 9 * (tmi - bmT + 1);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int X = bxT + dx;
+                if ((unsigned)X >= a.nbx || !nbflag[fb + dx + 1]) continue;
+                const size_t sidx = (size_t)((unsigned)X + a.nbx * ((unsigned)tyi + a.nby * (unsigned)tmi)) * (size_t)wpt + slot;
+#pragma unroll
+                for (int k = 0; k < NA; ++k) {
+                    const u64 x = src[k][sidx];
+                    w[k] |= dx < 0 ? x >> (32 - BAP) : (dx == 0 ? x << BAP : x << (32 + BAP));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) dst[k][t] = w[k] & ((1ull << bxw) - 1ull);
+    }
+}
+// 8 bits -> 8 mask bytes (byte k = bit k)
+__device__ __forceinline__ u64 bits8_to_bytes(u64 bits) {
+    u64 w = (bits * 0x0101010101010101ull) & 0x8040201008040201ull;
+    return ((((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w) >> 7) & 0x0101010101010101ull;
+}
+// xkey table of band_search3_kernel (nearest set bit of a 7-bit line pattern, the lower x winning ties)
+__device__ __forceinline__ void fill_xkey(unsigned* xkey) {
+    for (int p = threadIdx.x; p < 128; p += blockDim.x) {
+        unsigned k = 1u << 20;
+        for (int d = RL; d >= 0; --d) {
+            if (p & (1 << (RL + d))) k = ((unsigned)(d * d) << 9) | (unsigned)(RL + d);
+            if (p & (1 << (RL - d))) k = ((unsigned)(d * d) << 9) | (unsigned)(RL - d);
+        }
+        xkey[p] = k;
+    }
+}
+// _nearest_band_node inside the 7^3 cube around box position (lx, r = ly + by·lm): smallest (|off|², o_z, o_y, o_x) among the set bits
+__device__ __forceinline__ unsigned nearest_key(const u64* B, const unsigned* xkey, int by, int r, int lx) {
+    unsigned best = 0xffffffffu;
+#pragma unroll
+    for (int dm = -RL; dm <= RL; ++dm)
+#pragma unroll
+        for (int dy = -RL; dy <= RL; ++dy) {
+            const unsigned pat = (unsigned)(B[r + dy + dm * by] >> (lx - RL)) & 0x7fu;
+            const unsigned key = xkey[pat] + (((unsigned)(dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7));
+            best = key < best ? key : best;
+        }
+    return best;
+}
+
+__global__ void __launch_bounds__(256) band_bits_kernel(BandArgs a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE,
+                                                        unsigned* GE) {
+    const unsigned tile = LSM_TILE_ID(a);
+    if (a.work && !a.work[tile]) return;
+    const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
+    const int p = threadIdx.x & 3, ry = (threadIdx.x >> 2) & 7, wpt = a.ty * a.tm;
+    const int gx0 = x0 + 8 * p, gy = y0 + ry;
+    int hi = a.n[0] - gx0;
+    hi = hi > 8 ? 8 : (hi < 0 ? 0 : hi);
+    const u64 keep = hi > 0 ? (~0ull >> (64 - 8 * hi)) : 0ull;
+    for (int i = threadIdx.x >> 5; i < a.tm; i += 8) {
+        const int gm = m0 + i;
+        unsigned b8 = 0, le8 = 0, ge8 = 0;
+        if (gy < a.n[1] && gm < a.n[2] && keep) {
+            const long long q0 = a.origin + gx0 + (long long)gy * a.s1 + (long long)gm * a.s2;
+            u64 w = *reinterpret_cast<const u64_unaligned*>(mask + q0) & keep;
+            u64 t = ((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w;
+            t = (t >> 7) & 0x0101010101010101ull;
+            b8 = (unsigned)((t * 0x0102040810204080ull) >> 56);
+            if (b8) {
+                double xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = ld_val(v, q0 + (((b8 >> k) & 1u) ? k : 0), a.f32);   // independent loads, always a valid address
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned on = (b8 >> k) & 1u;
+                    le8 |= (on && xv[k] <= 0.0) ? (1u << k) : 0u;
+                    ge8 |= (on && xv[k] >= 0.0) ? (1u << k) : 0u;
+                }
+            }
+        }
+        unsigned wb = b8 << (8 * p), wl = le8 << (8 * p), wg = ge8 << (8 * p);
+        wb |= __shfl_xor(wb, 1, 64); wl |= __shfl_xor(wl, 1, 64); wg |= __shfl_xor(wg, 1, 64);
+        wb |= __shfl_xor(wb, 2, 64); wl |= __shfl_xor(wl, 2, 64); wg |= __shfl_xor(wg, 2, 64);
+        if (p == 0) {
+            const size_t sidx = (size_t)tile * wpt + ry + a.ty * i;
+            OB[sidx] = wb; LE[sidx] = wl; GE[sidx] = wg;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) band_grow_bits_kernel(BandArgs a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles,
+                                                             unsigned char* tiles, const unsigned* OB, const unsigned* LEw, const unsigned* GEw,
+                                                             unsigned* NB, int* miss) {
+    const unsigned tile = LSM_TILE_ID(a);
+    if (a.work && !a.work[tile]) return;
+    const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
+    const int ap = BAP, by = a.ty + 2 * ap, bm = a.tm + 2 * ap, nrows = by * bm, wpt = a.ty * a.tm;
+    extern __shared__ u64 w3[];
+    u64 *B = w3, *LE = w3 + nrows, *GE = w3 + 2 * nrows, *S0 = w3 + 3 * nrows, *S1 = w3 + 4 * nrows;
+    __shared__ unsigned char nbflag[32];
+    load_nbflags(a, tile, old_tiles, nbflag);
+    __syncthreads();
+    {
+        const unsigned* const src[3] = {OB, LEw, GEw};
+        u64* const dst[3] = {B, LE, GE};
+        stage_bit_rows<3>(a, tile, by, bm, nbflag, src, dst);
+    }
+    __syncthreads();
+    {
+        int anyb = 0;
+        for (int t = threadIdx.x; t < nrows; t += blockDim.x) anyb |= B[t] ? 1 : 0;
+        if (!__syncthreads_or(anyb)) return;      // no band node in the box: the tile was and stays empty (flag, mask and words untouched = 0)
+    }
+    const float rby = 1.0f / (float)by;
+    auto rowcoords = [&](int t, int& ly, int& lm) {
+        lm = (int)((float)t * rby); ly = t - lm * by;
+        if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+    };
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) {      // cut cells (see band_grow3_kernel)
+        int ly, lm;
+        rowcoords(t, ly, lm);
+        u64 cut = 0;
+        if (ly + 1 < by && lm + 1 < bm) {
+            u64 all = B[t] & B[t + 1] & B[t + by] & B[t + by + 1];
+            u64 le = LE[t] | LE[t + 1] | LE[t + by] | LE[t + by + 1];
+            u64 ge = GE[t] | GE[t + 1] | GE[t + by] | GE[t + by + 1];
+            all &= all >> 1; le |= le >> 1; ge |= ge >> 1;
+            cut = all & le & ge;
+        }
+        S0[t] = cut;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nrows; t += blockDim.x) {      // seeds
+        int ly, lm;
+        rowcoords(t, ly, lm);
+        u64 c = S0[t];
+        if (ly > 0) c |= S0[t - 1];
+        if (lm > 0) c |= S0[t - by];
+        if (ly > 0 && lm > 0) c |= S0[t - by - 1];
+        S1[t] = c | (c << 1);
+    }
+    __syncthreads();
+    u64 *cur = S1, *nxt = S0;
+    for (int it = 0; it < nl; ++it) {                             // nl von-Neumann dilations
+        for (int t = threadIdx.x; t < nrows; t += blockDim.x) {
+            int ly, lm;
+            rowcoords(t, ly, lm);
+            const u64 c = cur[t];
+            u64 r = c | (c << 1) | (c >> 1);
+            if (ly > 0) r |= cur[t - 1];
+            if (ly + 1 < by) r |= cur[t + 1];
+            if (lm > 0) r |= cur[t - by];
+            if (lm + 1 < bm) r |= cur[t + by];
+            nxt[t] = r;
+        }
+        __syncthreads();
+        u64* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // outputs: the new band's words, the byte mask where an x-line changed, the tile flag; NEWB = newly active nodes of the tile rows
+    unsigned* NEWB = reinterpret_cast<unsigned*>(nxt);
+    unsigned* xkey = NEWB + wpt;
+    const int nxv = a.n[0] - x0;
+    const unsigned xvalid = nxv >= 32 ? 0xffffffffu : ((1u << nxv) - 1u);
+    int any = 0, anynew = 0;
+    for (int e = threadIdx.x; e < 4 * wpt; e += blockDim.x) {
+        const int p = e & 3, row = e >> 2, ry = row % a.ty, i = row / a.ty;
+        const bool ing = y0 + ry < a.n[1] && m0 + i < a.n[2];
+        const int r = (ry + ap) + by * (i + ap);
+        const unsigned nw = ing ? ((unsigned)(cur[r] >> ap) & xvalid) : 0u, ow = (unsigned)(B[r] >> ap);
+        if (p == 0) { NB[(size_t)tile * wpt + row] = nw; NEWB[row] = nw & ~ow; }
+        any |= nw ? 1 : 0;
+        anynew |= (nw & ~ow) ? 1 : 0;
+        const unsigned n8 = (nw >> (8 * p)) & 0xffu, o8 = (ow >> (8 * p)) & 0xffu;
+        if (ing && n8 != o8) {
+            const long long q0 = a.origin + x0 + 8 * p + (long long)(y0 + ry) * a.s1 + (long long)(m0 + i) * a.s2;
+            if (x0 + 8 * p + 8 <= a.n[0]) *reinterpret_cast<u64_unaligned*>(mask + q0) = bits8_to_bytes(n8);
+            else for (int k = 0; k < 8 && x0 + 8 * p + k < a.n[0]; ++k) mask[q0 + k] = (unsigned char)((n8 >> k) & 1u);
+        }
+    }
+    any = __syncthreads_or(any);
+    anynew = __syncthreads_or(anynew);
+    if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
+    if (!anynew) return;
+    // newly active nodes: affine extrapolant from the nearest node of the OLD band (B), in place — reads old band nodes only, writes new ones only
+    fill_xkey(xkey);
+    __syncthreads();
+    const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
+    const int x = x0 + tx_, y = y0 + ty_, lx = tx_ + ap;
+    for (int i = pg; i < a.tm; i += npg) {
+        if (!((NEWB[ty_ + a.ty * i] >> tx_) & 1u)) continue;
+        const int m = m0 + i, r = (ty_ + ap) + by * (i + ap);
+        const unsigned best = nearest_key(B, xkey, by, r, lx);
+        if (best >= (16u << 9)) { atomicOr(miss, 1); continue; }      // cannot happen for nl <= 3: a new node lies within nl L1-steps of the old band
+        const int code = best & 511, ox = code % 7 - RL, oy = (code / 7) % 7 - RL, oz = code / 49 - RL;
+        const int rP = r + oy + oz * by, lxP = lx + ox;
+        const long long q = a.origin + x + (long long)y * a.s1 + (long long)m * a.s2;
+        const long long qp = q + ox + (long long)oy * a.s1 + (long long)oz * a.s2;
+        const double phiP = ld_val(v, qp, a.f32);
+        double val = phiP;
+        const int delta[3] = {-ox, -oy, -oz};
+        const int rstep[3] = {0, 1, by};
+        const long long sd[3] = {1, a.s1, a.s2};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (delta[d] == 0) continue;
+            const bool plus = d == 0 ? ((B[rP] >> (lxP + 1)) & 1ull) : ((B[rP + rstep[d]] >> lxP) & 1ull);
+            const bool minus = d == 0 ? ((B[rP] >> (lxP - 1)) & 1ull) : ((B[rP - rstep[d]] >> lxP) & 1ull);
+            double slope = 0.0;                                   // _axis_slope: + neighbour first, then -
+            if (plus) slope = ld_val(v, qp + sd[d], a.f32) - phiP;
+            else if (minus) slope = phiP - ld_val(v, qp - sd[d], a.f32);
+            val += (double)delta[d] * slope;
+        }
+        const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
+        st_val(v, q, a.f32, (phiP == 0.0 || sv == sp) ? val : phiP);
+    }
+}
+
+// halo mask and (node, nearest band node) list of the new band from its row words; interior bands only (no boundary-condition
+// sources pre-marked in halo[]): the halo bytes of every visited tile are written whole, no clearing pass
+template <int J>
+__global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo,
+                                                             int* miss, BandEntry* list, unsigned* list_count, unsigned list_cap) {
+    const unsigned tile = LSM_TILE_ID(a);
+    if (a.work && !a.work[tile]) return;
+    const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
+    const int ap = BAP, by = a.ty + 2 * ap, bm = a.tm + 2 * ap, nrows = by * bm, wpt = a.ty * a.tm;
+    extern __shared__ u64 w3[];
+    u64 *B = w3, *T = w3 + nrows;
+    unsigned* xkey = reinterpret_cast<unsigned*>(T + wpt);
+    __shared__ unsigned char nbflag[32];
+    __shared__ unsigned s_cnt, s_base;
+    load_nbflags(a, tile, tiles, nbflag);
+    fill_xkey(xkey);
+    __syncthreads();
+    {
+        const unsigned* const src[1] = {NB};
+        u64* const dst[1] = {B};
+        stage_bit_rows<1>(a, tile, by, bm, nbflag, src, dst);
+    }
+    __syncthreads();
+    // what stencils centred on band nodes read: LSM_GHOST nodes along each axis and the 3^3 box
+    int anyh = 0;
+    for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
+        const int ly = t % a.ty + ap, lm = t / a.ty + ap, r = ly + by * lm;
+        const u64 c = B[r];
+        u64 h = c | (c << 1) | (c >> 1) | (c << 2) | (c >> 2) | (c << 3) | (c >> 3);
+        for (int k = 1; k <= LSM_GHOST; ++k) h |= B[r + k] | B[r - k] | B[r + k * by] | B[r - k * by];
+        for (int dm = -1; dm <= 1; ++dm)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const u64 d = B[r + dy + dm * by];
+                h |= d | (d << 1) | (d >> 1);
+            }
+        T[t] = h;
+        anyh |= ((unsigned)(h >> ap)) ? 1 : 0;
+    }
+    anyh = __syncthreads_or(anyh);
+    // halo bytes of the tile (band nodes included), whole x-lines
+    const int nxv = a.n[0] - x0;
+    const unsigned xvalid = nxv >= 32 ? 0xffffffffu : ((1u << nxv) - 1u);
+    for (int e = threadIdx.x; e < 4 * wpt; e += blockDim.x) {
+        const int p = e & 3, row = e >> 2, ry = row % a.ty, i = row / a.ty;
+        if (y0 + ry >= a.n[1] || m0 + i >= a.n[2]) continue;
+        const unsigned hw = anyh ? ((unsigned)(T[row] >> ap) & xvalid) : 0u, h8 = (hw >> (8 * p)) & 0xffu;
+        const long long q0 = a.origin + x0 + 8 * p + (long long)(y0 + ry) * a.s1 + (long long)(m0 + i) * a.s2;
+        if (x0 + 8 * p + 8 <= a.n[0]) *reinterpret_cast<u64_unaligned*>(halo + q0) = bits8_to_bytes(h8);
+        else for (int k = 0; k < 8 && x0 + 8 * p + k < a.n[0]; ++k) halo[q0 + k] = (unsigned char)((h8 >> k) & 1u);
+    }
+    if (!anyh) return;
+    const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
+    const int x = x0 + tx_, y = y0 + ty_, lx = tx_ + ap, ly = ty_ + ap, lane = threadIdx.x & 63;
+    const bool inxy = x < a.n[0] && y < a.n[1];
+    const long long qxy = a.origin + x + (long long)y * a.s1;
+    for (int i0 = 0; i0 < a.tm; i0 += J * npg) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        unsigned rec[J], slot[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int i = i0 + j * npg + pg, m = m0 + i, r = ly + by * (i + ap);
+            rec[j] = 0; slot[j] = 0;
+            bool want = inxy && i < a.tm && m < a.n[2];
+            if (want) want = !((B[r] >> lx) & 1ull) && ((T[ty_ + a.ty * i] >> lx) & 1ull);
+            if (want) {
+                const unsigned best = nearest_key(B, xkey, by, r, lx);
+                if (best >= (16u << 9)) { atomicOr(miss, 1); }      // a halo node lies within Chebyshev distance 3 of the band: cannot happen
+                else {
+                    const int code = best & 511, ox = code % 7 - RL, oy = (code / 7) % 7 - RL, oz = code / 49 - RL;
+                    const int rP = r + oy + oz * by, lxP = lx + ox;
+                    // _axis_slope's choice per axis with a non-zero offset (+ neighbour first, then -): 1 = plus, 2 = minus
+                    unsigned sc = 0;
+                    if (ox) sc |= ((B[rP] >> (lxP + 1)) & 1ull) ? 1u : (((B[rP] >> (lxP - 1)) & 1ull) ? 2u : 0u);
+                    if (oy) sc |= (((B[rP + 1] >> lxP) & 1ull) ? 1u : (((B[rP - 1] >> lxP) & 1ull) ? 2u : 0u)) << 2;
+                    if (oz) sc |= (((B[rP + by] >> lxP) & 1ull) ? 1u : (((B[rP - by] >> lxP) & 1ull) ? 2u : 0u)) << 4;
+                    rec[j] = 0x80000000u | (unsigned)(8 - ox) | ((unsigned)(8 - oy) << 4) | ((unsigned)(8 - oz) << 8) | (sc << 12);
+                }
+            }
+            if (list) {
+                const u64 bal = __ballot(rec[j] != 0);
+                if (bal) {
+                    const int leader = __ffsll((long long)bal) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                    slot[j] = __shfl(base, leader, 64) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                }
+            }
+        }
+        if (list) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(list_count, s_cnt) : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (!rec[j]) continue;
+                const unsigned k = s_base + slot[j];
+                if (k >= list_cap) continue;
+                const int d0 = (int)(rec[j] & 15u) - 8, d1 = (int)((rec[j] >> 4) & 15u) - 8, d2 = (int)((rec[j] >> 8) & 15u) - 8;   // I - P
+                BandEntry e;
+                e.q = qxy + (long long)(m0 + i0 + j * npg + pg) * a.s2;
+                e.rel = -(int)(d0 + d1 * a.s1 + d2 * a.s2);
+                e.d[0] = (signed char)d0; e.d[1] = (signed char)d1; e.d[2] = (signed char)d2;
+                e.d[3] = (signed char)(0x40u | ((rec[j] >> 12) & 0x3fu));       // 0x40: the slope neighbours are resolved (2 bits per axis)
+                list[k] = e;
+            }
+        }
+    }
+}
+
 // _extrapolate_to_ghost from a precomputed (node, nearest band node) list: one thread per entry
 __global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
                                                          const unsigned char* src_mask, const void* src, void* dst) {
@@ -780,14 +1152,34 @@ __global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandE
         const long long qp = e.q + e.rel;
         const double phiP = ld_val(src, qp, a.f32);
         double val = phiP;
-        for (int d = 0; d < a.ndim; ++d) {
-            const int delta = e.d[d];
-            if (delta == 0) continue;
-            const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-            double slope = 0.0;                                   // mask ghosts are 0: no bounds test needed
-            if (src_mask[qp + sd]) slope = ld_val(src, qp + sd, a.f32) - phiP;
-            else if (src_mask[qp - sd]) slope = phiP - ld_val(src, qp - sd, a.f32);
-            val += (double)delta * slope;
+        const unsigned sc = (unsigned)(unsigned char)e.d[3];
+        if (sc & 0x40u) {
+            // slope neighbours resolved by band_halo_bits_kernel (1 = plus, 2 = minus per axis): no mask reads, independent value loads
+            double nbv[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned c = (sc >> (2 * d)) & 3u;
+                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+                nbv[d] = ld_val(src, c == 1u ? qp + sd : (c == 2u ? qp - sd : qp), a.f32);
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const unsigned c = (sc >> (2 * d)) & 3u;
+                const int delta = e.d[d];
+                if (delta == 0 || d >= a.ndim) continue;
+                const double slope = c == 1u ? nbv[d] - phiP : (c == 2u ? phiP - nbv[d] : 0.0);
+                val += (double)delta * slope;
+            }
+        } else {
+            for (int d = 0; d < a.ndim; ++d) {
+                const int delta = e.d[d];
+                if (delta == 0) continue;
+                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+                double slope = 0.0;                                   // mask ghosts are 0: no bounds test needed
+                if (src_mask[qp + sd]) slope = ld_val(src, qp + sd, a.f32) - phiP;
+                else if (src_mask[qp - sd]) slope = phiP - ld_val(src, qp - sd, a.f32);
+                val += (double)delta * slope;
+            }
         }
         const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
         st_val(dst, e.q, a.f32, (phiP == 0.0 || sv == sp) ? val : phiP);
@@ -1018,6 +1410,25 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_extrapolate_kernel, tile_grid(a), dim3(256), (size_t)(bytes <= LSM_BAND_LDS ? bytes : 0), s, a, target, halo,
                        src_mask, ring, nring, nring_lds, src, dst, miss, list, list_count, list_cap);
+}
+bool band_bits_fit(const BandArgs& a, int nl) {
+    return fast3(a, BAP, 5) && nl >= 0 && nl + 1 <= BAP && a.tm >= BAP;
+}
+void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE, hipStream_t s) {
+    if (no_tiles(a)) return;
+    hipLaunchKernelGGL(band_bits_kernel, tile_grid(a), dim3(256), 0, s, a, v, mask, OB, LE, GE);
+}
+void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
+                           const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s) {
+    if (no_tiles(a)) return;
+    const size_t lds = (size_t)5 * 8 * (a.ty + 2 * BAP) * (a.tm + 2 * BAP);
+    hipLaunchKernelGGL(band_grow_bits_kernel, tile_grid(a), dim3(256), lds, s, a, v, mask, nl, old_tiles, tiles, OB, LE, GE, NB, miss);
+}
+void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
+                           unsigned* list_count, unsigned list_cap, hipStream_t s) {
+    if (no_tiles(a)) return;
+    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + a.ty * a.tm) + 128 * sizeof(unsigned);
+    hipLaunchKernelGGL(band_halo_bits_kernel<8>, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap);
 }
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s) {

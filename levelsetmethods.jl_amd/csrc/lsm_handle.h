@@ -26,6 +26,7 @@ struct LsmHandle {
     int* d_miss;
     unsigned long long* d_count;
     unsigned char* d_work;             // per-tile work flags (narrow band)
+    unsigned char* d_tiles_old;        // the old band's tile flags during an update (the new ones are written in place)
     int64_t work_cap;
     const unsigned char* band_mask;    // set for the duration of a *_band call
     const unsigned char* band_tiles;

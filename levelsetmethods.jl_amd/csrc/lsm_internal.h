@@ -172,11 +172,18 @@ struct BandEntry {          // a halo node and its nearest band node (16 bytes)
     signed char d[4];       // I - P per dimension
 };
 void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s);
+// bit-row path of update_band! (lsm_band.hip)
+bool band_bits_fit(const BandArgs& a, int nl);
+void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE, hipStream_t s);
+void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
+                           const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s);
 void launch_band_copy_values(const BandArgs& a, const unsigned char* mask, const void* src, void* dst, hipStream_t s);
 void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s);
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
+void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
+                           unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s);
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
