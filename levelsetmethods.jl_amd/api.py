@@ -682,6 +682,10 @@ class ROCNarrowBandMeshField(ROCMeshField):
         self.tiles.copy_(src.tiles)
         if src._hlist is not None:
             self._hlist, self._hcount = src._hlist.clone(), src._hcount.clone()
+        # the handle's compact tile lists (and a prefetched Δt) describe the band this buffer held before: rebuild them
+        self.backend.band_retile(self.mask, self.tiles, self.MC)
+        if self._hcount is not None:
+            self.backend.band_status(self._hcount)
         self.ghosts_dirty = True
         return self
 

@@ -112,15 +112,18 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->comm = nullptr;
+    h->d_pf_flag = nullptr;
+    memset(&h->band_cfl, 0, sizeof(h->band_cfl));
+    h->cfl_prefetched = false;
     h->d_stamp = nullptr;
     h->d_tail_ctr = nullptr; h->tail_ticket = 0;
     h->xredirect = false;
     h->yredirect = false;
     h->cfl_cache_on = true;
     h->d_cand_count = nullptr;
-    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->d_tiles_old = nullptr; h->work_cap = 0;
+    h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->d_tiles_old = nullptr; h->work_cap = 0; h->halo_n_key = nullptr; h->halo_n = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
-    h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
+    h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_stage_list = nullptr; h->d_head = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
     h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
     h->no_lists = getenv("LSM_BAND_NO_LISTS") != nullptr;
     h->band_bytes = getenv("LSM_BAND_BYTES") != nullptr;
@@ -196,8 +199,9 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->ch_result, sizeof(double) * 2, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_w, sizeof(h->w));
     if (e == hipSuccess) e = hipMemcpy(h->d_w, h->w, sizeof(h->w), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 8);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 16);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 16, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_pf_flag, sizeof(int) * 4);
     if (e != hipSuccess) {
         std::string m = std::string("lsm_create: ") + hipGetErrorString(e);
         delete h;
@@ -225,8 +229,9 @@ void lsm_destroy(LsmHandle* h) {
     if (h->ch_result) (void)hipHostFree(h->ch_result);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
     (void)hipFree(h->d_result);
+    if (h->d_pf_flag) (void)hipFree(h->d_pf_flag);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -487,6 +492,17 @@ int lsm_stage_planes(LsmHandle* h, const LsmTerm* terms, int nterms, const void*
 // Julia's min: NaN-propagating
 static double jl_min(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (b < a ? b : a); }
 
+static void cfl_args(const LsmHandle* h, const LsmTerm& tm, double t, CflArgs& a) {
+    memset(&a, 0, sizeof(a));
+    for (int d = 0; d < 3; ++d) {
+        a.n[d] = h->nloc[d]; a.goff[d] = h->goff[d]; a.gn[d] = h->gn[d];
+        a.lc[d] = h->grid.lc[d]; a.h[d] = h->h[d];
+    }
+    a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
+    a.term_kind = tm.kind;
+    fill_coeff(tm.coeff, t, a.coeff);
+}
+
 int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, double t, double* dt_out) {
     if (!h || !terms || !dt_out) return h ? fail(h, LSM_ERR_INVALID, "lsm_compute_cfl: null argument") : LSM_ERR_INVALID;
     if (nterms < 1 || nterms > LSM_MAX_TERMS) return fail(h, LSM_ERR_INVALID, "lsm_compute_cfl: nterms must be in 1..8");
@@ -522,15 +538,13 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
                 for (auto& e : h->cfl_cache)
                     if (memcmp(&e.first, &tm, sizeof(LsmTerm)) == 0) { dt = e.second; hit = true; break; }
             if (hit) { best = k == 0 ? dt : jl_min(best, dt); continue; }
-            CflArgs a;
-            memset(&a, 0, sizeof(a));
-            for (int d = 0; d < 3; ++d) {
-                a.n[d] = h->nloc[d]; a.goff[d] = h->goff[d]; a.gn[d] = h->gn[d];
-                a.lc[d] = h->grid.lc[d]; a.h[d] = h->h[d];
+            if (h->cfl_prefetched && h->band_cfl.slot[k] >= 0) {      // lsm_compute_cfl_band: this term's Δt came home with lsm_band_status
+                dt = h->band_cfl.dt[k];
+                best = k == 0 ? dt : jl_min(best, dt);
+                continue;
             }
-            a.s1 = h->lay.stride[1]; a.s2 = h->lay.stride[2]; a.origin = h->lay.origin;
-            a.term_kind = tm.kind;
-            fill_coeff(tm.coeff, t, a.coeff);
+            CflArgs a;
+            cfl_args(h, tm, t, a);
             // ϕ-independent coefficient, dense field: the reduction runs on the handle's CFL stream with its own scratch and
             // does not queue behind the stages on the main stream (LSM_CFL_MAIN_STREAM=1 is the A/B switch).  A table is
             // waited for once, the first time it is seen (its upload was ordered on the main stream).
@@ -607,7 +621,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             }
             int nlisted = 0;
             if (h->band_mask && N == 3 && a.tile_active && have_lists(h, h->band_tiles, h->band_mc))
-                nlisted = launch_cfl_band_list(a, h->d_act_list, h->nact, 1024, cs);   // one workgroup per active tile
+                nlisted = launch_cfl_band_list(a, h->d_act_list, h->nact, nullptr, 1024, cs);   // one workgroup per active tile
             if (nlisted > 0) {
                 nb = nlisted;
             } else if (cand) {
@@ -1000,6 +1014,9 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.force_bytes = h->band_bytes ? 1 : 0;
     static const int band_exp = getenv("LSM_BAND_EXP") ? atoi(getenv("LSM_BAND_EXP")) : 0;
     a.exp = band_exp;
+    static const bool no_pieces = getenv("LSM_BAND_PIECES") && getenv("LSM_BAND_PIECES")[0] == '0';   // A/B switch
+    static const bool want_pieces = getenv("LSM_BAND_PIECES") && getenv("LSM_BAND_PIECES")[0] == '1';
+    a.pieces = (want_pieces && !no_pieces && a.ndim == 3 && (long long)a.nbx * a.nby * a.nbm < (1ll << 24)) ? 1 : 0;
     return a;
 }
 
@@ -1030,12 +1047,14 @@ static int ensure_ring(LsmHandle* h) {
 // handle-owned scratch for the per-tile work flags
 static int ensure_work(LsmHandle* h, int64_t ntiles) {
     if (h->work_cap >= ntiles) return LSM_OK;
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
     LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_tiles_old, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_act_list, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_work_list, (size_t)ntiles * sizeof(int)));
-    LSM_HIP(h, hipMalloc((void**)&h->d_lcounts, 3 * sizeof(unsigned)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_lcounts, 4 * sizeof(unsigned)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_stage_list, (size_t)ntiles * sizeof(int)));
+    LSM_HIP(h, hipMalloc((void**)&h->d_head, (size_t)ntiles));
     h->work_cap = ntiles;
     h->lists_tiles = nullptr; h->lists_host_valid = false;
     return LSM_OK;
@@ -1071,7 +1090,7 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
     } else if (have_lists(h, tiles, mc)) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
         a.work = h->d_work;
     }
     const int N = h->grid.ndim;
@@ -1089,10 +1108,41 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
         for (int d = N - 1; d >= 0; --d)
             launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
     if (halo_count) LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
+    h->halo_n_key = nullptr;
     launch_band_extrapolate(a, nullptr, (unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
                             vals, nullptr, h->d_miss, halo_count ? (BandEntry*)halo_list : nullptr,
                             (unsigned*)halo_count, halo_list && halo_count ? (unsigned)halo_cap : 0u, h->stream);
     LSM_HIP(h, hipGetLastError());
+    return LSM_OK;
+}
+
+// Δt of the next step over the band just built (see LsmHandle::BandCfl): the reductions of the armed term list run over
+// the new compact tile list, whose length is still on the device; lsm_band_status reads the results back with its own numbers.
+static bool band_cfl_node_dependent(const LsmTerm& tm) {
+    return tm.kind != LSM_TERM_EIKONAL && tm.coeff.kind != LSM_COEFF_CONST;
+}
+static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, int mc) {
+    LsmHandle::BandCfl& pf = h->band_cfl;
+    pf.pending = false; pf.valid = false;
+    static const bool off = getenv("LSM_BAND_CFL_PREFETCH") && getenv("LSM_BAND_CFL_PREFETCH")[0] == '0';   // A/B switch
+    if (off || !pf.armed || pf.mask != mask || pf.tiles != tiles || pf.mc != mc || h->grid.ndim != 3 || h->no_lists) return LSM_OK;
+    const BandArgs ba = band_args(h, mc, nullptr);
+    for (int k = 0; k < pf.nterms; ++k) {
+        const int sl = pf.slot[k];
+        if (sl < 0) continue;
+        CflArgs a;
+        cfl_args(h, pf.terms[k], 0.0, a);              // armed terms carry no time factor
+        a.partial = h->d_partial + 1024 * sl;
+        a.nanflag = h->d_pf_flag + sl;
+        a.mask = (const unsigned char*)mask;
+        a.tile_active = (const unsigned char*)tiles;
+        a.tx = ba.tx; a.ty = ba.ty; a.tm = ba.tm; a.nbx = ba.nbx; a.nby = ba.nby;
+        LSM_HIP(h, hipMemsetAsync(h->d_pf_flag + sl, 0, sizeof(int), h->stream));
+        if (launch_cfl_band_list(a, h->d_act_list, 0, h->d_lcounts, 1024, h->stream) != 1024) return LSM_OK;   // tile shape not served: no prefetch
+        launch_cfl_final(a.partial, 1024, a.nanflag, h->d_result + 8 + sl, pf.terms[k].kind, h->dxmin, 1, h->stream);
+    }
+    LSM_HIP(h, hipGetLastError());
+    pf.pending = true;
     return LSM_OK;
 }
 
@@ -1101,6 +1151,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (!h || !vals || !mask || !scratch_a || !scratch_b || !halo_mask || !tiles)
         return h ? fail(h, LSM_ERR_INVALID, "lsm_band_update: null argument") : LSM_ERR_INVALID;
     if (nlayers < 0 || mc < 1) return fail(h, LSM_ERR_INVALID, "lsm_band_update: nlayers must be >= 0 and mc >= 1");
+    h->band_cfl.valid = false; h->band_cfl.pending = false;      // the band changes: a prefetched Δt is void
     const int N = h->grid.ndim;
     for (int d = 0; d < N; ++d)
         for (int sd = 0; sd < 2; ++sd)
@@ -1125,7 +1176,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (listed) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (local) {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
         a.work = h->d_work;
     }
     const size_t bytes = (size_t)h->lay.total;
@@ -1146,6 +1197,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
         h->lists_host_valid = false;                          // from here on the lists describe the previous band
         if (interior_b && halo_list && halo_count) {
             LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
+            h->halo_n_key = nullptr;
             launch_band_halo_bits(a, (const unsigned char*)tiles, NB, (unsigned char*)halo_mask, h->d_miss, (BandEntry*)halo_list,
                                   (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
             LSM_HIP(h, hipGetLastError());
@@ -1153,11 +1205,11 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
             LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior_b ? 1 : 0));
         }
         BandArgs full = band_args(h, mc, nullptr);
-        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->stream);
-        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
         h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
         LSM_HIP(h, hipGetLastError());
-        return LSM_OK;
+        return band_cfl_prefetch(h, mask, tiles, mc);
     }
     unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
     const unsigned char* old_mask = from_dense ? nullptr : (const unsigned char*)mask;
@@ -1188,11 +1240,11 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior, clear_with_copy));
     // compact lists of the new band's tiles for the launches that follow lsm_band_status
     BandArgs full = band_args(h, mc, nullptr);
-    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->stream);
-    launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+    launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
-    return LSM_OK;
+    return band_cfl_prefetch(h, mask, tiles, mc);
 }
 
 // halo_mask := the in-grid nodes stencils centred on band nodes read, directly (axis lines of length LSM_GHOST and
@@ -1209,12 +1261,13 @@ int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_m
 // lsm_band_halo
 int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
     if (!h || !mask || !tiles || mc < 1) return LSM_ERR_INVALID;
+    h->band_cfl.valid = false; h->band_cfl.pending = false;      // the mask was changed from outside
     LSM_TRY(ensure_ring(h));
     BandArgs a = band_args(h, mc, nullptr);
     LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
     launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
-    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
-    launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
+    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+    launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -1230,7 +1283,7 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (tiles) {
         LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
         a.work = h->d_work;
     }
     launch_band_extrapolate(a, (const unsigned char*)targets, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
@@ -1243,7 +1296,8 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
 // a gather per stage input.  Call lsm_fill_ghosts afterwards for the out-of-grid layers.
 int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap, const void* halo_count) {
     if (!h || !vals || !mask || !halo_list || !halo_count) return LSM_ERR_INVALID;
-    launch_band_apply(band_args(h, 8, nullptr), (const BandEntry*)halo_list, (const unsigned*)halo_count, (unsigned)halo_cap,
+    const long long n_host = (h->halo_n_key == halo_count && h->halo_n_key) ? h->halo_n : -1;
+    launch_band_apply(band_args(h, 8, nullptr), (const BandEntry*)halo_list, (const unsigned*)halo_count, n_host, (unsigned)halo_cap,
                       (const unsigned char*)mask, vals, vals, h->stream);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -1288,12 +1342,19 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
     LSM_TRY(ensure_ring(h));
     // one gather kernel and ONE copy into pinned memory instead of three small copies into pageable memory (a host round trip each)
     launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->d_result + 2, h->stream);
-    LSM_HIP(h, hipMemcpyAsync(h->h_result + 2, h->d_result + 2, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSM_HIP(h, hipMemcpyAsync(h->h_result + 2, h->d_result + 2, 10 * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // [2..6] status, [8..11] prefetched Δt
     LSM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->band_cfl.pending) {
+        for (int k = 0; k < h->band_cfl.nterms; ++k)
+            if (h->band_cfl.slot[k] >= 0) h->band_cfl.dt[k] = h->h_result[8 + h->band_cfl.slot[k]];
+        h->band_cfl.pending = false;
+        h->band_cfl.valid = true;
+    }
     *missed = (int)h->h_result[3];
-    if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->lists_host_valid = true; }
+    if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->nstage = (unsigned)h->h_result[7]; h->lists_host_valid = true; }
     if (*missed) LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
     *count = (int64_t)h->h_result[2];
+    h->halo_n_key = halo_count; h->halo_n = *count;
     return LSM_OK;
 }
 
@@ -1305,7 +1366,7 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
     h->band_mask = (const unsigned char*)mask;
     h->band_tiles = (const unsigned char*)tiles;
     h->band_mc = tiles ? mc : 0;
-    if (tiles && have_lists(h, tiles, mc)) { h->band_list = h->d_act_list; h->band_nlist = h->nact; }
+    if (tiles && have_lists(h, tiles, mc)) { h->band_list = h->d_stage_list; h->band_nlist = h->nstage; }   // tile | (bricks - 1) << 24
     const int r = stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, 0, h->nloc[h->grid.ndim - 1], stream);
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
     return r;
@@ -1314,14 +1375,35 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
 int lsm_compute_cfl_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* phi, const void* mask, const void* tiles, int mc,
                          double t, double* dt_out) {
     if (!h || !mask || (tiles && mc < 1)) return LSM_ERR_INVALID;
+    LsmHandle::BandCfl& pf = h->band_cfl;
+    const bool same = terms && nterms >= 1 && nterms <= LSM_MAX_TERMS && pf.nterms == nterms && pf.mask == mask && pf.tiles == tiles && pf.mc == mc &&
+                      memcmp(pf.terms, terms, sizeof(LsmTerm) * (size_t)nterms) == 0;
     h->band_mask = (const unsigned char*)mask;
     h->band_tiles = (const unsigned char*)tiles;
     h->band_mc = tiles ? mc : 0;
     const bool keep = h->cfl_cache_on;
     h->cfl_cache_on = false;            // the minimum runs over the current band only
+    h->cfl_prefetched = same && pf.valid;      // Δt of the node-dependent terms came home with the last lsm_band_status
     const int r = lsm_compute_cfl(h, terms, nterms, phi, t, dt_out);
+    h->cfl_prefetched = false;
     h->cfl_cache_on = keep;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0;
+    if (r == LSM_OK && !same && terms && nterms >= 1 && nterms <= LSM_MAX_TERMS) {
+        // arm the prefetch for the bands to come: every term independent of t and of device fields, at most 4 node-dependent ones
+        pf.valid = false; pf.pending = false; pf.armed = tiles != nullptr && h->cfl_cache_on;
+        memcpy(pf.terms, terms, sizeof(LsmTerm) * (size_t)nterms);
+        pf.nterms = nterms; pf.mask = mask; pf.tiles = tiles; pf.mc = mc;
+        int nslots = 0;
+        for (int k = 0; k < nterms; ++k) {
+            const LsmTerm& tm = terms[k];
+            pf.slot[k] = -1;
+            if (!band_cfl_node_dependent(tm)) continue;
+            const bool timeless = tm.coeff.kind == LSM_COEFF_ROTATION || (tm.coeff.kind == LSM_COEFF_SEPARABLE && tm.coeff.time_kind == LSM_TIME_ONE);
+            if (!timeless || nslots == 4) { pf.armed = false; break; }
+            pf.slot[k] = nslots++;
+        }
+        if (nslots == 0) pf.armed = false;     // nothing to launch: the host evaluates every term
+    }
     return r;
 }
 
@@ -1480,6 +1562,8 @@ int lsm_cfl_cache(LsmHandle* h, int enable) {
     if (!h) return LSM_ERR_INVALID;
     h->cfl_cache_on = enable != 0;
     h->cfl_cache.clear();
+    h->band_cfl.armed = h->band_cfl.valid = h->band_cfl.pending = false;   // a prefetched band Δt goes with the cache
+    h->band_cfl.nterms = 0;
     for (auto& e : h->cfl_cand) (void)hipFree(e.d_cand);
     h->cfl_cand.clear();
     return LSM_OK;

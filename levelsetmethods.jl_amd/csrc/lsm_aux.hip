@@ -509,7 +509,8 @@ void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream
 // flags to visit 3.7 M band nodes).  Exact divisions throughout: the band is small.  Same node formulas and the same
 // max-then-divide reduction as cfl_kernel, so Δt is bit-identical.
 template <int TKIND, int CKIND>
-__global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, const int* list, unsigned nlist) {
+__global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, const int* list, unsigned nlist_host, const unsigned* nlist_dev) {
+    const unsigned nlist = nlist_dev ? *nlist_dev : nlist_host;      // the list's length may still be on the device only (prefetch after update_band!)
     constexpr int NCOMP = TKIND == LSM_TERM_ADVECTION ? 3 : 1;
     const CoeffArgs& c = a.coeff;
     double best = 0.0;
@@ -564,21 +565,23 @@ __global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, con
     }
 }
 template <int TKIND>
-static void launch_cfl_band_list_ck(const CflArgs& a, const int* list, unsigned nlist, unsigned grid, hipStream_t s) {
+static void launch_cfl_band_list_ck(const CflArgs& a, const int* list, unsigned nlist, const unsigned* nlist_dev, unsigned grid, hipStream_t s) {
     switch (a.coeff.kind) {
-    case LSM_COEFF_CONST: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_CONST>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
-    case LSM_COEFF_ROTATION: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_ROTATION>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
-    case LSM_COEFF_SEPARABLE: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_SEPARABLE>), dim3(grid), dim3(256), 0, s, a, list, nlist); break;
-    default: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_FIELD>), dim3(grid), dim3(256), 0, s, a, list, nlist);
+    case LSM_COEFF_CONST: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_CONST>), dim3(grid), dim3(256), 0, s, a, list, nlist, nlist_dev); break;
+    case LSM_COEFF_ROTATION: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_ROTATION>), dim3(grid), dim3(256), 0, s, a, list, nlist, nlist_dev); break;
+    case LSM_COEFF_SEPARABLE: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_SEPARABLE>), dim3(grid), dim3(256), 0, s, a, list, nlist, nlist_dev); break;
+    default: hipLaunchKernelGGL((cfl_band_list_kernel<TKIND, LSM_COEFF_FIELD>), dim3(grid), dim3(256), 0, s, a, list, nlist, nlist_dev);
     }
 }
 // returns the number of partials written (0: not applicable — use launch_cfl)
-int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, int max_partials, hipStream_t s) {
-    if (!list || nlist == 0 || !a.mask || a.tx * a.ty != 256 || a.tm < 1) return 0;
-    const unsigned grid = nlist < (unsigned)max_partials ? nlist : (unsigned)max_partials;
-    if (a.term_kind == LSM_TERM_ADVECTION) launch_cfl_band_list_ck<LSM_TERM_ADVECTION>(a, list, nlist, grid, s);
-    else if (a.term_kind == LSM_TERM_NORMAL_MOTION) launch_cfl_band_list_ck<LSM_TERM_NORMAL_MOTION>(a, list, nlist, grid, s);
-    else launch_cfl_band_list_ck<LSM_TERM_CURVATURE>(a, list, nlist, grid, s);
+// nlist_dev != NULL: the length is read on the device and max_partials workgroups are launched (those without a tile write the
+// neutral partial 0)
+int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, const unsigned* nlist_dev, int max_partials, hipStream_t s) {
+    if (!list || (!nlist_dev && nlist == 0) || !a.mask || a.tx * a.ty != 256 || a.tm < 1) return 0;
+    const unsigned grid = (nlist_dev || nlist >= (unsigned)max_partials) ? (unsigned)max_partials : nlist;
+    if (a.term_kind == LSM_TERM_ADVECTION) launch_cfl_band_list_ck<LSM_TERM_ADVECTION>(a, list, nlist, nlist_dev, grid, s);
+    else if (a.term_kind == LSM_TERM_NORMAL_MOTION) launch_cfl_band_list_ck<LSM_TERM_NORMAL_MOTION>(a, list, nlist, nlist_dev, grid, s);
+    else launch_cfl_band_list_ck<LSM_TERM_CURVATURE>(a, list, nlist, nlist_dev, grid, s);
     return (int)grid;
 }
 

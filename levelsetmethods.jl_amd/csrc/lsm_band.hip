@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned cha
 }
 
 // the numbers lsm_band_status hands to the host, gathered into one pinned-memory copy: {halo entries wanted, search misses,
-// active tiles, work tiles, face tiles}
+// active tiles, work tiles, face tiles, stage pieces}
 __global__ void band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out) {
     if (threadIdx.x == 0) {
         out[0] = (double)halo_count[0];
@@ -261,6 +261,7 @@ __global__ void band_status_kernel(const unsigned* halo_count, const int* miss, 
         out[2] = lcounts ? (double)lcounts[0] : 0.0;
         out[3] = lcounts ? (double)lcounts[1] : 0.0;
         out[4] = lcounts ? (double)lcounts[2] : 0.0;
+        out[5] = lcounts ? (double)lcounts[3] : 0.0;
     }
 }
 
@@ -1034,7 +1035,6 @@ __global__ void __launch_bounds__(256) band_grow_bits_kernel(BandArgs a, void* v
 
 // halo mask and (node, nearest band node) list of the new band from its row words; interior bands only (no boundary-condition
 // sources pre-marked in halo[]): the halo bytes of every visited tile are written whole, no clearing pass
-template <int J>
 __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo,
                                                              int* miss, BandEntry* list, unsigned* list_count, unsigned list_cap) {
     const unsigned tile = LSM_TILE_ID(a);
@@ -1083,102 +1083,97 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
         else for (int k = 0; k < 8 && x0 + 8 * p + k < a.n[0]; ++k) halo[q0 + k] = (unsigned char)((h8 >> k) & 1u);
     }
     if (!anyh) return;
-    const int tx_ = threadIdx.x & 31, ty_ = (threadIdx.x >> 5) & 7, pg = threadIdx.x >> 8, npg = blockDim.x >> 8;
-    const int x = x0 + tx_, y = y0 + ty_, lx = tx_ + ap, ly = ty_ + ap, lane = threadIdx.x & 63;
-    const bool inxy = x < a.n[0] && y < a.n[1];
-    const long long qxy = a.origin + x + (long long)y * a.s1;
-    for (int i0 = 0; i0 < a.tm; i0 += J * npg) {
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        unsigned rec[J], slot[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int i = i0 + j * npg + pg, m = m0 + i, r = ly + by * (i + ap);
-            rec[j] = 0; slot[j] = 0;
-            bool want = inxy && i < a.tm && m < a.n[2];
-            if (want) want = !((B[r] >> lx) & 1ull) && ((T[ty_ + a.ty * i] >> lx) & 1ull);
-            if (want) {
-                const unsigned best = nearest_key(B, xkey, by, r, lx);
-                if (best >= (16u << 9)) { atomicOr(miss, 1); }      // a halo node lies within Chebyshev distance 3 of the band: cannot happen
-                else {
-                    const int code = best & 511, ox = code % 7 - RL, oy = (code / 7) % 7 - RL, oz = code / 49 - RL;
-                    const int rP = r + oy + oz * by, lxP = lx + ox;
-                    // _axis_slope's choice per axis with a non-zero offset (+ neighbour first, then -): 1 = plus, 2 = minus
-                    unsigned sc = 0;
-                    if (ox) sc |= ((B[rP] >> (lxP + 1)) & 1ull) ? 1u : (((B[rP] >> (lxP - 1)) & 1ull) ? 2u : 0u);
-                    if (oy) sc |= (((B[rP + 1] >> lxP) & 1ull) ? 1u : (((B[rP - 1] >> lxP) & 1ull) ? 2u : 0u)) << 2;
-                    if (oz) sc |= (((B[rP + by] >> lxP) & 1ull) ? 1u : (((B[rP - by] >> lxP) & 1ull) ? 2u : 0u)) << 4;
-                    rec[j] = 0x80000000u | (unsigned)(8 - ox) | ((unsigned)(8 - oy) << 4) | ((unsigned)(8 - oz) << 8) | (sc << 12);
-                }
-            }
-            if (list) {
-                const u64 bal = __ballot(rec[j] != 0);
-                if (bal) {
-                    const int leader = __ffsll((long long)bal) - 1;
-                    unsigned base = 0;
-                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
-                    slot[j] = __shfl(base, leader, 64) + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                }
-            }
+    // The wanted nodes (in the halo, not in the band) are few — 130 of a tile's 2048 on average at 768³ — and scattered: one
+    // thread per NODE with lanes waiting for the few that search ran the 49-row scan for almost every wave.  They are listed
+    // first (row-major, x ascending: the order of the tile's entries is deterministic) and then searched by full waves.
+    unsigned* cnt = reinterpret_cast<unsigned*>(xkey + 128);                      // wpt + 1 words
+    unsigned short* wl = reinterpret_cast<unsigned short*>(cnt + wpt + 1);       // up to 32·wpt entries: (row << 5) | x
+    for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
+        const int ry = t % a.ty, i = t / a.ty;
+        const bool ing = y0 + ry < a.n[1] && m0 + i < a.n[2];
+        const int r = (ry + ap) + by * (i + ap);
+        const unsigned w = ing ? ((unsigned)(T[t] >> ap) & ~(unsigned)(B[r] >> ap) & xvalid) : 0u;
+        cnt[t] = w;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
+        unsigned off = 0;
+        for (int j = 0; j < t; ++j) off += (unsigned)__builtin_popcount(cnt[j]);
+        unsigned w = cnt[t];
+        if (t == wpt - 1) s_cnt = off + (unsigned)__builtin_popcount(w);
+        while (w) {
+            const int bpos = __builtin_ctz(w);
+            wl[off++] = (unsigned short)((t << 5) | bpos);
+            w &= w - 1;
         }
-        if (list) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(list_count, s_cnt) : 0u;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                if (!rec[j]) continue;
-                const unsigned k = s_base + slot[j];
-                if (k >= list_cap) continue;
-                const int d0 = (int)(rec[j] & 15u) - 8, d1 = (int)((rec[j] >> 4) & 15u) - 8, d2 = (int)((rec[j] >> 8) & 15u) - 8;   // I - P
-                BandEntry e;
-                e.q = qxy + (long long)(m0 + i0 + j * npg + pg) * a.s2;
-                e.rel = -(int)(d0 + d1 * a.s1 + d2 * a.s2);
-                e.d[0] = (signed char)d0; e.d[1] = (signed char)d1; e.d[2] = (signed char)d2;
-                e.d[3] = (signed char)(0x40u | ((rec[j] >> 12) & 0x3fu));       // 0x40: the slope neighbours are resolved (2 bits per axis)
-                list[k] = e;
-            }
-        }
+    }
+    __syncthreads();
+    const unsigned tot = s_cnt;
+    if (tot == 0) return;
+    if (threadIdx.x == 0) s_base = list ? atomicAdd(list_count, tot) : 0u;
+    __syncthreads();
+    const unsigned base = s_base;
+    for (unsigned k = threadIdx.x; k < tot; k += blockDim.x) {
+        const unsigned code16 = wl[k];
+        const int row = (int)(code16 >> 5), tx_ = (int)(code16 & 31u), ry = row % a.ty, i = row / a.ty;
+        const int lx = tx_ + ap, r = (ry + ap) + by * (i + ap);
+        const unsigned best = nearest_key(B, xkey, by, r, lx);
+        if (best >= (16u << 9)) { atomicOr(miss, 1); continue; }      // a halo node lies within Chebyshev distance 3 of the band: cannot happen
+        const int code = best & 511, ox = code % 7 - RL, oy = (code / 7) % 7 - RL, oz = code / 49 - RL;
+        const int rP = r + oy + oz * by, lxP = lx + ox;
+        // _axis_slope's choice per axis with a non-zero offset (+ neighbour first, then -): 1 = plus, 2 = minus
+        unsigned sc = 0;
+        if (ox) sc |= ((B[rP] >> (lxP + 1)) & 1ull) ? 1u : (((B[rP] >> (lxP - 1)) & 1ull) ? 2u : 0u);
+        if (oy) sc |= (((B[rP + 1] >> lxP) & 1ull) ? 1u : (((B[rP - 1] >> lxP) & 1ull) ? 2u : 0u)) << 2;
+        if (oz) sc |= (((B[rP + by] >> lxP) & 1ull) ? 1u : (((B[rP - by] >> lxP) & 1ull) ? 2u : 0u)) << 4;
+        if (!list || base + k >= list_cap) continue;
+        BandEntry e;
+        e.q = a.origin + (x0 + tx_) + (long long)(y0 + ry) * a.s1 + (long long)(m0 + i) * a.s2;
+        e.rel = (int)(ox + oy * a.s1 + oz * a.s2);
+        e.d[0] = (signed char)(-ox); e.d[1] = (signed char)(-oy); e.d[2] = (signed char)(-oz);      // I - P
+        e.d[3] = (signed char)(0x40u | sc);                                // 0x40: the slope neighbours are resolved (2 bits per axis)
+        list[base + k] = e;
     }
 }
 
-// _extrapolate_to_ghost from a precomputed (node, nearest band node) list: one thread per entry
-__global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
-                                                         const unsigned char* src_mask, const void* src, void* dst) {
-    unsigned n = *list_count;
+// _extrapolate_to_ghost from a precomputed (node, nearest band node) list: one thread per entry.  n_host >= 0: the list's
+// length as the host knows it (lsm_band_status) — every wave reading the device counter is 16 k requests for ONE cache line.
+template <int NDIM>
+__global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* list_count, long long n_host,
+                                                         unsigned list_cap, const unsigned char* src_mask, const void* src, void* dst) {
+    unsigned n = n_host >= 0 ? (unsigned)n_host : *list_count;
     n = n < list_cap ? n : list_cap;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const BandEntry e = list[i];
         const long long qp = e.q + e.rel;
         const double phiP = ld_val(src, qp, a.f32);
         double val = phiP;
+        const int delta[3] = {e.d[0], e.d[1], e.d[2]};
+        const long long sdv[3] = {1, a.s1, a.s2};
         const unsigned sc = (unsigned)(unsigned char)e.d[3];
         if (sc & 0x40u) {
             // slope neighbours resolved by band_halo_bits_kernel (1 = plus, 2 = minus per axis): no mask reads, independent value loads
-            double nbv[3];
+            double nbv[NDIM];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
+            for (int d = 0; d < NDIM; ++d) {
                 const unsigned c = (sc >> (2 * d)) & 3u;
-                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-                nbv[d] = ld_val(src, c == 1u ? qp + sd : (c == 2u ? qp - sd : qp), a.f32);
+                nbv[d] = ld_val(src, c == 1u ? qp + sdv[d] : (c == 2u ? qp - sdv[d] : qp), a.f32);
             }
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
+            for (int d = 0; d < NDIM; ++d) {
                 const unsigned c = (sc >> (2 * d)) & 3u;
-                const int delta = e.d[d];
-                if (delta == 0 || d >= a.ndim) continue;
+                if (delta[d] == 0) continue;
                 const double slope = c == 1u ? nbv[d] - phiP : (c == 2u ? phiP - nbv[d] : 0.0);
-                val += (double)delta * slope;
+                val += (double)delta[d] * slope;
             }
         } else {
-            for (int d = 0; d < a.ndim; ++d) {
-                const int delta = e.d[d];
-                if (delta == 0) continue;
-                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) {
+                if (delta[d] == 0) continue;
                 double slope = 0.0;                                   // mask ghosts are 0: no bounds test needed
-                if (src_mask[qp + sd]) slope = ld_val(src, qp + sd, a.f32) - phiP;
-                else if (src_mask[qp - sd]) slope = phiP - ld_val(src, qp - sd, a.f32);
-                val += (double)delta * slope;
+                if (src_mask[qp + sdv[d]]) slope = ld_val(src, qp + sdv[d], a.f32) - phiP;
+                else if (src_mask[qp - sdv[d]]) slope = phiP - ld_val(src, qp - sdv[d], a.f32);
+                val += (double)delta[d] * slope;
             }
         }
         const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
@@ -1248,8 +1243,10 @@ __global__ void __launch_bounds__(256) band_tiles_kernel(BandArgs a, const unsig
     if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
 }
 
-// work[t] = OR of active over the 3^N tile neighbourhood of t
-__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work) {
+// work[t] = OR of active over the 3^N tile neighbourhood of t;  head[t] (may be NULL) = number of bricks of the stage piece that
+// starts at tile t, 0 if none does.  Stage pieces: two active bricks that follow each other along the march axis (an aligned
+// pair: the lower one has an even brick index) are marched by ONE workgroup — a brick pays 2G planes of prologue for its mc = 8.
+__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work, unsigned char* head) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -1263,6 +1260,15 @@ __global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsign
                 r |= active[X + a.nbx * (Y + a.nby * M)];
             }
     work[t] = r ? 1 : 0;
+    if (head) {
+        const unsigned P = a.nbx * a.nby;
+        unsigned char hd = 0;
+        if (active[t]) {
+            if ((bm & 1) == 0) hd = (unsigned char)(1 + ((bm + 1 < (int)a.nbm && active[t + P]) ? 1 : 0));
+            else if (!active[t - P]) hd = 1;
+        }
+        head[t] = a.pieces ? hd : (active[t] ? 1 : 0);
+    }
 }
 
 // compact, ordered lists of the active tiles and of the work tiles (active or next to one), so that the
@@ -1279,10 +1285,11 @@ __device__ __forceinline__ unsigned nz_bytes(unsigned long long w) {       // nu
     return (unsigned)__builtin_popcountll(w & 0x0101010101010101ull);
 }
 __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsigned char* active, const unsigned char* work,
-                                                          int* act_list, int* work_list, unsigned* counts) {
-    __shared__ unsigned red[2][16], wsum[2][16];
+                                                          const unsigned char* head, int* act_list, int* work_list, int* stage_list,
+                                                          unsigned* counts) {
+    __shared__ unsigned red[3][16], wsum[3][16];
     const unsigned ntiles = a.nbx * a.nby * a.nbm;
-    const bool words = (((unsigned long long)active | (unsigned long long)work) & 7ull) == 0;
+    const bool words = (((unsigned long long)active | (unsigned long long)work | (unsigned long long)head) & 7ull) == 0;
     auto flags8 = [&](const unsigned char* p, unsigned t) -> unsigned long long {   // flags of tiles t .. t+7 (t % 8 == 0)
         if (t >= ntiles) return 0ull;
         if (words && t + 8 <= ntiles) return *(const unsigned long long*)(p + t);
@@ -1296,34 +1303,36 @@ __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsi
         return v;
     };
     // offset of this chunk = set flags in the chunks before it
-    unsigned pa = 0, pw = 0;
+    unsigned pa = 0, pw = 0, ps = 0;
     for (unsigned cb = 0; cb < blockIdx.x; ++cb) {
         const unsigned t = cb * LISTS_CHUNK + threadIdx.x * 8;
         pa += nz_bytes(flags8(active, t));
         pw += nz_bytes(flags8(work, t));
+        ps += nz_bytes(flags8(head, t));
     }
-    pa = wave_sum(pa); pw = wave_sum(pw);
-    if (lane == 0) { red[0][wave] = pa; red[1][wave] = pw; }
+    pa = wave_sum(pa); pw = wave_sum(pw); ps = wave_sum(ps);
+    if (lane == 0) { red[0][wave] = pa; red[1][wave] = pw; red[2][wave] = ps; }
     // own chunk: one word per thread, exclusive scan over the workgroup (wave scan + 16 wave totals)
     const unsigned t0 = blockIdx.x * LISTS_CHUNK + threadIdx.x * 8;
-    const unsigned long long fa = flags8(active, t0), fw = flags8(work, t0);
-    const unsigned na = nz_bytes(fa), nw = nz_bytes(fw);
-    unsigned ia = na, iw = nw;                                    // inclusive wave scans
+    const unsigned long long fa = flags8(active, t0), fw = flags8(work, t0), fs = flags8(head, t0);
+    const unsigned na = nz_bytes(fa), nw = nz_bytes(fw), ns = nz_bytes(fs);
+    unsigned ia = na, iw = nw, is = ns;                           // inclusive wave scans
     for (int off = 1; off < 64; off <<= 1) {
-        const unsigned va = __shfl_up(ia, off, 64), vw = __shfl_up(iw, off, 64);
-        if ((int)lane >= off) { ia += va; iw += vw; }
+        const unsigned va = __shfl_up(ia, off, 64), vw = __shfl_up(iw, off, 64), vs = __shfl_up(is, off, 64);
+        if ((int)lane >= off) { ia += va; iw += vw; is += vs; }
     }
-    if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = iw; }
+    if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = iw; wsum[2][wave] = is; }
     __syncthreads();
-    unsigned offa = 0, offw = 0, tota = 0, totw = 0;
+    unsigned offa = 0, offw = 0, offs = 0, tota = 0, totw = 0, tots = 0;
     for (unsigned w = 0; w < 16; ++w) {
-        offa += red[0][w]; offw += red[1][w];
-        if (w < wave) { offa += wsum[0][w]; offw += wsum[1][w]; }
-        tota += wsum[0][w]; totw += wsum[1][w];
+        offa += red[0][w]; offw += red[1][w]; offs += red[2][w];
+        if (w < wave) { offa += wsum[0][w]; offw += wsum[1][w]; offs += wsum[2][w]; }
+        tota += wsum[0][w]; totw += wsum[1][w]; tots += wsum[2][w];
     }
-    ia = offa + ia - na; iw = offw + iw - nw;
+    ia = offa + ia - na; iw = offw + iw - nw; is = offs + is - ns;
     unsigned nbd = 0;
     for (unsigned k = 0; k < 8; ++k) {
+        if ((fs >> (8 * k)) & 0xff) stage_list[is++] = (int)((t0 + k) | ((unsigned)(((fs >> (8 * k)) & 0xff) - 1) << 24));   // tile | (bricks - 1) << 24
         if ((fa >> (8 * k)) & 0xff) act_list[ia++] = (int)(t0 + k);
         if ((fw >> (8 * k)) & 0xff) {
             work_list[iw++] = (int)(t0 + k);
@@ -1336,10 +1345,11 @@ __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsi
     nbd = wave_sum(nbd);
     if (lane == 0 && nbd) atomicAdd(&counts[2], nbd);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        unsigned ba = 0, bw = 0;
-        for (unsigned w = 0; w < 16; ++w) { ba += red[0][w]; bw += red[1][w]; }
+        unsigned ba = 0, bw = 0, bs = 0;
+        for (unsigned w = 0; w < 16; ++w) { ba += red[0][w]; bw += red[1][w]; bs += red[2][w]; }
         counts[0] = ba + tota;
         counts[1] = bw + totw;
+        counts[3] = bs + tots;
     }
 }
 
@@ -1427,14 +1437,20 @@ void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int 
 void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
                            unsigned* list_count, unsigned list_cap, hipStream_t s) {
     if (no_tiles(a)) return;
-    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + a.ty * a.tm) + 128 * sizeof(unsigned);
-    hipLaunchKernelGGL(band_halo_bits_kernel<8>, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap);
+    const size_t wpt = (size_t)a.ty * a.tm;
+    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + wpt) + 128 * sizeof(unsigned) + (wpt + 2) * sizeof(unsigned) + 64 * wpt;
+    hipLaunchKernelGGL(band_halo_bits_kernel, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap);
 }
-void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
+void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s) {
-    unsigned blocks = (list_cap + 255) / 256;
-    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
-    hipLaunchKernelGGL(band_apply_kernel, dim3(blocks), dim3(256), 0, s, a, list, list_count, list_cap, src_mask, src, dst);
+    if (n_host == 0) return;
+    // the length known on the host: one entry per thread; else a grid-stride loop over the capacity
+    unsigned blocks = n_host > 0 ? (unsigned)((n_host + 255) / 256) : (list_cap + 255) / 256;
+    const unsigned cap = n_host > 0 ? 65536u : 4096u;
+    blocks = blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
+    if (a.ndim == 3) hipLaunchKernelGGL(band_apply_kernel<3>, dim3(blocks), dim3(256), 0, s, a, list, list_count, n_host, list_cap, src_mask, src, dst);
+    else if (a.ndim == 2) hipLaunchKernelGGL(band_apply_kernel<2>, dim3(blocks), dim3(256), 0, s, a, list, list_count, n_host, list_cap, src_mask, src, dst);
+    else hipLaunchKernelGGL(band_apply_kernel<1>, dim3(blocks), dim3(256), 0, s, a, list, list_count, n_host, list_cap, src_mask, src, dst);
 }
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s) {
@@ -1449,15 +1465,16 @@ void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned ch
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_tiles_kernel, tile_grid(a), dim3(256), 0, s, a, mask, tiles);
 }
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s) {
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, hipStream_t s) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
-    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work);
+    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work, head);
 }
-void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list,
-                       unsigned* counts, hipStream_t s) {
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, const unsigned char* head, int* act_list,
+                       int* work_list, int* stage_list, unsigned* counts, hipStream_t s) {
     const unsigned ntiles = a.nbx * a.nby * a.nbm;
     (void)hipMemsetAsync(counts + 2, 0, sizeof(unsigned), s);
-    hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, act_list, work_list, counts);
+    hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, head, act_list, work_list,
+                       stage_list, counts);
 }
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s) {
     if (no_tiles(a)) return;

@@ -37,19 +37,38 @@ struct LsmHandle {
     // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
     int* d_act_list;
     int* d_work_list;
+    int* d_stage_list;                 // stage pieces: tile | (bricks - 1) << 24 (lsm_band.hip, band_work_kernel)
+    unsigned char* d_head;             // per tile: bricks of the stage piece starting there
     unsigned* d_lcounts;
     const void* lists_tiles;           // the tile-flag buffer the lists describe
     int lists_mc;
     bool lists_host_valid;
-    unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
+    const void* halo_n_key;            // the device counter whose value lsm_band_status last read (NULL: unknown on the host)
+    long long halo_n;
+    unsigned nact, nwork, nface, nstage;   // list lengths; work tiles on a face of the grid; stage pieces
     bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
     bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
-    double* d_result;    // 8 doubles: [0..1] reductions, [2..6] lsm_band_status
-    double* h_result;    // pinned, 8 doubles
+    double* d_result;    // 16 doubles: [0..1] reductions, [2..6] lsm_band_status, [8..11] Δt of the next step prefetched by lsm_band_update
+    double* h_result;    // pinned, 16 doubles
+    // Δt of a band, prefetched: when the terms of the last lsm_compute_cfl_band depend neither on t nor on a field (constants,
+    // ROTATION, SEPARABLE without time factor, Eikonal), lsm_band_update runs their reductions over the NEW band right behind
+    // its own kernels and lsm_band_status brings the results home in the read it does anyway — the next lsm_compute_cfl_band
+    // with the same terms on the same band launches nothing and waits for nothing
+    struct BandCfl {
+        LsmTerm terms[LSM_MAX_TERMS];
+        int nterms;
+        const void *mask, *tiles;
+        int mc;
+        bool armed, pending, valid;
+        int slot[LSM_MAX_TERMS];           // result slot of a node-dependent term, -1 otherwise
+        double dt[LSM_MAX_TERMS];
+    } band_cfl;
+    int* d_pf_flag;      // NaN flags of the prefetched reductions (4)
     std::string err;
     bool cfl_cache_on;
+    bool cfl_prefetched;   // set around lsm_compute_cfl by lsm_compute_cfl_band when band_cfl holds this call's values
     std::vector<std::pair<LsmTerm, double>> cfl_cache;   // time-independent analytic coefficients
     struct CflCand { LsmTerm key; long long* d_cand; unsigned count; };
     std::vector<CflCand> cfl_cand;                       // SEPARABLE × g(t): the arg-max candidates are time-independent

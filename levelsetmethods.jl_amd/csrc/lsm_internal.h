@@ -157,10 +157,11 @@ struct BandArgs {
     unsigned nlist;
     int f32;                     // the value arrays hold float
     int force_bytes;             // A/B switch (LSM_BAND_BYTES at lsm_create): byte-mask kernels in 3-D too
+    int pieces;                  // stage pieces may span two bricks (LSM_BAND_PIECES=0: one brick per workgroup)
     int exp;                     // timing experiments (LSM_BAND_EXP bit mask, results are WRONG): see lsm_band.hip
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s);
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, hipStream_t s);
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
@@ -184,13 +185,13 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
                            unsigned* list_count, unsigned list_cap, hipStream_t s);
-void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, unsigned list_cap,
+void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s);
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s);
-void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list,
-                       unsigned* counts, hipStream_t s);
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, const unsigned char* head, int* act_list,
+                       int* work_list, int* stage_list, unsigned* counts, hipStream_t s);
 void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned char* tiles, hipStream_t s);
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s);
 // tile geometry of the stage kernel for a given dimension and march chunk (stage_tu.hip)
@@ -231,7 +232,7 @@ void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s);
 int cfl_blocks(int ndim, const int n[3]);
 void launch_cfl(int ndim, const CflArgs& a, int nblocks, int pass, const double* thresh, hipStream_t s);
 void launch_cfl_candidates(int ndim, const CflArgs& a, unsigned count, hipStream_t s);
-int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, int max_partials, hipStream_t s);
+int launch_cfl_band_list(const CflArgs& a, const int* list, unsigned nlist, const unsigned* nlist_dev, int max_partials, hipStream_t s);
 void launch_cfl_final(const double* partial, int nblocks, const int* nanflag, double* out, int term_kind, double dxmin,
                       int pass, hipStream_t s);
 void launch_extrema(int ndim, const int n[3], long long s1, long long s2, long long origin, const void* v, int f32,

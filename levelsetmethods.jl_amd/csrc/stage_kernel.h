@@ -680,7 +680,8 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
 #ifdef LSM_STAMP
     const unsigned long long st_rb = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (a.tile_list) tile_id = (unsigned)a.tile_list[tile_id];
+    int nbricks = 1;                                               // narrow band: a listed piece may span two bricks of the march axis
+    if (a.tile_list) { const unsigned e = (unsigned)a.tile_list[tile_id]; tile_id = e & 0x00ffffffu; nbricks = (int)(e >> 24) + 1; }
     else if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
     // dense 3-D launches number the tiles of a layer y-fastest (StageArgs::yfast): workgroups dispatched one after the other are
     // then y-neighbours — they start together, march in phase and find each other's rows (6 of the 14 a tile loads per plane)
@@ -733,7 +734,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     const int mcl = a.mc > 0 ? a.mc : MC;
     const int mc = tail_tile ? a.mc_tail : mcl;
     const int m0 = MARCH ? (tail_tile ? a.mb + (int)a.nbig * mcl + (int)(tbm - a.nbig) * mc : a.mb + (int)tbm * mc) : 0;
-    const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
+    const int m1 = MARCH ? (m0 + mc * nbricks < a.me ? m0 + mc * nbricks : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
     auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
