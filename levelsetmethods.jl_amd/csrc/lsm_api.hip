@@ -200,7 +200,8 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_w, sizeof(h->w));
     if (e == hipSuccess) e = hipMemcpy(h->d_w, h->w, sizeof(h->w), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_result, sizeof(double) * 16);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 16, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_result, sizeof(double) * 16, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->h_result_dev, h->h_result, 0);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_pf_flag, sizeof(int) * 4);
     if (e != hipSuccess) {
         std::string m = std::string("lsm_create: ") + hipGetErrorString(e);
@@ -1090,7 +1091,7 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
     } else if (have_lists(h, tiles, mc)) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     const int N = h->grid.ndim;
@@ -1137,7 +1138,6 @@ static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, 
         a.mask = (const unsigned char*)mask;
         a.tile_active = (const unsigned char*)tiles;
         a.tx = ba.tx; a.ty = ba.ty; a.tm = ba.tm; a.nbx = ba.nbx; a.nby = ba.nby;
-        LSM_HIP(h, hipMemsetAsync(h->d_pf_flag + sl, 0, sizeof(int), h->stream));
         if (launch_cfl_band_list(a, h->d_act_list, 0, h->d_lcounts, 1024, h->stream) != 1024) return LSM_OK;   // tile shape not served: no prefetch
         launch_cfl_final(a.partial, 1024, a.nanflag, h->d_result + 8 + sl, pf.terms[k].kind, h->dxmin, 1, h->stream);
     }
@@ -1176,7 +1176,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (listed) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (local) {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     const size_t bytes = (size_t)h->lay.total;
@@ -1186,18 +1186,18 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (bits_env && local && nlayers <= 3 && band_bits_fit(a, nlayers) && 2 * words * sizeof(unsigned) <= bytes &&
         ((uintptr_t)scratch_a & 7) == 0 && ((uintptr_t)scratch_b & 7) == 0) {
         unsigned *OB = (unsigned*)scratch_a, *LE = OB + words, *GE = (unsigned*)scratch_b, *NB = GE + words;
-        LSM_HIP(h, hipMemcpyAsync(h->d_tiles_old, tiles, (size_t)ntiles, hipMemcpyDeviceToDevice, h->stream));
         BandArgs act = band_args(h, mc, nullptr);
         if (listed) { act.list = h->d_act_list; act.nlist = h->nact; }
-        else act.work = h->d_tiles_old;
-        launch_band_bits(act, vals, (const unsigned char*)mask, OB, LE, GE, h->stream);
+        else act.work = (const unsigned char*)tiles;           // unchanged until the grow kernel
+        const bool interior_b = listed && h->nface == 0;     // the new band lies in the old work tiles: none on a face
+        const bool halo_bits = interior_b && halo_list && halo_count;
+        launch_band_bits(act, vals, (const unsigned char*)mask, OB, LE, GE, (const unsigned char*)tiles, h->d_tiles_old,
+                         halo_bits ? (unsigned*)halo_count : nullptr, h->stream);
         launch_band_grow_bits(a, vals, (unsigned char*)mask, nlayers, h->d_tiles_old, (unsigned char*)tiles, OB, LE, GE, NB, h->d_miss, h->stream);
         LSM_HIP(h, hipGetLastError());
-        const bool interior_b = listed && h->nface == 0;     // the new band lies in the old work tiles: none on a face
         h->lists_host_valid = false;                          // from here on the lists describe the previous band
-        if (interior_b && halo_list && halo_count) {
-            LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
-            h->halo_n_key = nullptr;
+        if (halo_bits) {
+            h->halo_n_key = nullptr;                          // (the counter was cleared by band_bits_kernel)
             launch_band_halo_bits(a, (const unsigned char*)tiles, NB, (unsigned char*)halo_mask, h->d_miss, (BandEntry*)halo_list,
                                   (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
             LSM_HIP(h, hipGetLastError());
@@ -1205,7 +1205,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
             LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior_b ? 1 : 0));
         }
         BandArgs full = band_args(h, mc, nullptr);
-        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
         launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
         h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
         LSM_HIP(h, hipGetLastError());
@@ -1240,7 +1240,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior, clear_with_copy));
     // compact lists of the new band's tiles for the launches that follow lsm_band_status
     BandArgs full = band_args(h, mc, nullptr);
-    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
     launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
@@ -1266,7 +1266,7 @@ int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
     BandArgs a = band_args(h, mc, nullptr);
     LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
     launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
-    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->stream);
+    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
     launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
@@ -1283,7 +1283,7 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (tiles) {
         LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     launch_band_extrapolate(a, (const unsigned char*)targets, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
@@ -1341,8 +1341,9 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
     if (!h || !halo_count || !count || !missed) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
     // one gather kernel and ONE copy into pinned memory instead of three small copies into pageable memory (a host round trip each)
-    launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->d_result + 2, h->stream);
-    LSM_HIP(h, hipMemcpyAsync(h->h_result + 2, h->d_result + 2, 10 * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // [2..6] status, [8..11] prefetched Δt
+    // the kernel writes into the host's pinned page itself ([2..7] status, [8..11] prefetched Δt): no copy, one synchronisation
+    launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->band_cfl.pending ? h->d_result + 8 : nullptr,
+                       h->h_result_dev + 2, h->stream);
     LSM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->band_cfl.pending) {
         for (int k = 0; k < h->band_cfl.nterms; ++k)

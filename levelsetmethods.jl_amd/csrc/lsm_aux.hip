@@ -523,6 +523,19 @@ __global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, con
         if (i0 >= a.n[0] || i1 >= a.n[1]) continue;
         const int g0 = i0 + a.goff[0], g1 = i1 + a.goff[1];
         const long long cbase = a.origin + i0 + i1 * a.s1;
+        if constexpr (CKIND == LSM_COEFF_ROTATION && TKIND == LSM_TERM_ADVECTION) {
+            // the in-plane rotation's speed does not depend on the march index: one evaluation per column that holds a band node
+            // (same operations on the same operands as the per-node form below: the maximum is bit-identical)
+            unsigned anyb = 0;
+            for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) anyb |= a.mask[cbase + m * a.s2];
+            if (!anyb) continue;
+            const double u0 = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
+            const double u1 = c.v[0] * ((a.lc[0] + (double)g0 * a.h[0]) - c.v[1]);
+            if (u0 != u0 || u1 != u1) sawnan = 1;
+            const double sv = (__builtin_fabs(u0) / a.h[0] + __builtin_fabs(u1) / a.h[1]) + __builtin_fabs(0.0) / a.h[2];
+            if (sv == sv) best = sv > best ? sv : best;
+            continue;
+        }
         for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) {
             const long long q = cbase + m * a.s2;
             if (!a.mask[q]) continue;

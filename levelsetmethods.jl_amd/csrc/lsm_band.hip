@@ -254,7 +254,8 @@ __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned cha
 
 // the numbers lsm_band_status hands to the host, gathered into one pinned-memory copy: {halo entries wanted, search misses,
 // active tiles, work tiles, face tiles, stage pieces}
-__global__ void band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out) {
+__global__ void band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, double* out) {
+    if (threadIdx.x < 4 && prefetched) out[6 + threadIdx.x] = prefetched[threadIdx.x];      // Δt of the next step (LsmHandle::BandCfl)
     if (threadIdx.x == 0) {
         out[0] = (double)halo_count[0];
         out[1] = (double)miss[0];
@@ -866,7 +867,16 @@ __device__ __forceinline__ unsigned nearest_key(const u64* B, const unsigned* xk
 }
 
 __global__ void __launch_bounds__(256) band_bits_kernel(BandArgs a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE,
-                                                        unsigned* GE) {
+                                                        unsigned* GE, unsigned ntile_blocks, const unsigned char* flags_src,
+                                                        unsigned char* flags_dst, unsigned nflags, unsigned* zero0) {
+    if (blockIdx.x >= ntile_blocks) {
+        // the workgroups behind the tiles' copy the old band's tile flags aside (the update writes the new ones in place) and clear the
+        // halo list's counter: two small launches less per step
+        const unsigned c = (blockIdx.x - ntile_blocks) * 4096u + threadIdx.x * 16u;
+        for (unsigned k = c; k < c + 16u && k < nflags; ++k) flags_dst[k] = flags_src[k];
+        if (blockIdx.x == ntile_blocks && threadIdx.x == 0 && zero0) *zero0 = 0u;
+        return;
+    }
     const unsigned tile = LSM_TILE_ID(a);
     if (a.work && !a.work[tile]) return;
     const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
@@ -930,9 +940,14 @@ __global__ void __launch_bounds__(256) band_grow_bits_kernel(BandArgs a, void* v
         if (!__syncthreads_or(anyb)) return;      // no band node in the box: the tile was and stays empty (flag, mask and words untouched = 0)
     }
     const float rby = 1.0f / (float)by;
-    auto rowcoords = [&](int t, int& ly, int& lm) {
+    auto rowcoords_slow = [&](int t, int& ly, int& lm) {
         lm = (int)((float)t * rby); ly = t - lm * by;
         if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
+    };
+    int ly_own, lm_own;                         // the box has at most one row per thread when tm = 8: its coordinates once for all passes
+    rowcoords_slow((int)threadIdx.x, ly_own, lm_own);
+    auto rowcoords = [&](int t, int& ly, int& lm) {
+        if (t == (int)threadIdx.x) { ly = ly_own; lm = lm_own; } else rowcoords_slow(t, ly, lm);
     };
     for (int t = threadIdx.x; t < nrows; t += blockDim.x) {      // cut cells (see band_grow3_kernel)
         int ly, lm;
@@ -1097,9 +1112,14 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
     }
     __syncthreads();
     for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
-        unsigned off = 0;
-        for (int j = 0; j < t; ++j) off += (unsigned)__builtin_popcount(cnt[j]);
-        unsigned w = cnt[t];
+        unsigned w = cnt[t], off = 0;
+        if (wpt <= 64) {                          // one wave holds every row: exclusive scan by shuffles (uniform branch)
+            unsigned inc = (unsigned)__builtin_popcount(w);
+            for (int o = 1; o < 64; o <<= 1) { const unsigned vv = __shfl_up(inc, o, 64); if ((int)(threadIdx.x & 63) >= o) inc += vv; }
+            off = inc - (unsigned)__builtin_popcount(w);
+        } else {
+            for (int j = 0; j < t; ++j) off += (unsigned)__builtin_popcount(cnt[j]);
+        }
         if (t == wpt - 1) s_cnt = off + (unsigned)__builtin_popcount(w);
         while (w) {
             const int bpos = __builtin_ctz(w);
@@ -1246,9 +1266,14 @@ __global__ void __launch_bounds__(256) band_tiles_kernel(BandArgs a, const unsig
 // work[t] = OR of active over the 3^N tile neighbourhood of t;  head[t] (may be NULL) = number of bricks of the stage piece that
 // starts at tile t, 0 if none does.  Stage pieces: two active bricks that follow each other along the march axis (an aligned
 // pair: the lower one has an even brick index) are marched by ONE workgroup — a brick pays 2G planes of prologue for its mc = 8.
-__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work, unsigned char* head) {
+__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work, unsigned char* head,
+                                                        unsigned* zero_face, int* zero_flags) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {                       // counters the list / Δt kernels behind this one accumulate into
+        if (zero_face) *zero_face = 0u;
+        if (zero_flags) { zero_flags[0] = 0; zero_flags[1] = 0; zero_flags[2] = 0; zero_flags[3] = 0; }
+    }
     if (t >= nt) return;
     const int bx = t % a.nbx, by = (t / a.nbx) % a.nby, bm = t / (a.nbx * a.nby);
     unsigned char r = 0;
@@ -1403,8 +1428,8 @@ void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s) {
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_zero_kernel, tile_grid(a), dim3(256), 0, s, a, out);
 }
-void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, out);
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, prefetched, out);
 }
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
@@ -1424,9 +1449,11 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
 bool band_bits_fit(const BandArgs& a, int nl) {
     return fast3(a, BAP, 5) && nl >= 0 && nl + 1 <= BAP && a.tm >= BAP;
 }
-void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE, hipStream_t s) {
-    if (no_tiles(a)) return;
-    hipLaunchKernelGGL(band_bits_kernel, tile_grid(a), dim3(256), 0, s, a, v, mask, OB, LE, GE);
+void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE,
+                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, hipStream_t s) {
+    const unsigned nflags = a.nbx * a.nby * a.nbm, ntile_blocks = a.list ? a.nlist : nflags;
+    hipLaunchKernelGGL(band_bits_kernel, dim3(ntile_blocks + (nflags + 4095u) / 4096u), dim3(256), 0, s, a, v, mask, OB, LE, GE, ntile_blocks,
+                       flags_src, flags_dst, nflags, zero0);
 }
 void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
                            const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s) {
@@ -1465,14 +1492,14 @@ void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned ch
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_tiles_kernel, tile_grid(a), dim3(256), 0, s, a, mask, tiles);
 }
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, hipStream_t s) {
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, unsigned* zero_face,
+                      int* zero_flags, hipStream_t s) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
-    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work, head);
+    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work, head, zero_face, zero_flags);
 }
 void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, const unsigned char* head, int* act_list,
                        int* work_list, int* stage_list, unsigned* counts, hipStream_t s) {
-    const unsigned ntiles = a.nbx * a.nby * a.nbm;
-    (void)hipMemsetAsync(counts + 2, 0, sizeof(unsigned), s);
+    const unsigned ntiles = a.nbx * a.nby * a.nbm;      // counts[2] (face tiles) is accumulated: cleared by the band_work launch before this one
     hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, head, act_list, work_list,
                        stage_list, counts);
 }

@@ -52,6 +52,7 @@ struct LsmHandle {
     int* d_flag;
     double* d_result;    // 16 doubles: [0..1] reductions, [2..6] lsm_band_status, [8..11] Δt of the next step prefetched by lsm_band_update
     double* h_result;    // pinned, 16 doubles
+    double* h_result_dev;   // the same page as the device sees it: lsm_band_status's kernel writes its numbers there directly
     // Δt of a band, prefetched: when the terms of the last lsm_compute_cfl_band depend neither on t nor on a field (constants,
     // ROTATION, SEPARABLE without time factor, Eikonal), lsm_band_update runs their reductions over the NEW band right behind
     // its own kernels and lsm_band_status brings the results home in the read it does anyway — the next lsm_compute_cfl_band

@@ -161,7 +161,8 @@ struct BandArgs {
     int exp;                     // timing experiments (LSM_BAND_EXP bit mask, results are WRONG): see lsm_band.hip
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s);
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, hipStream_t s);
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, unsigned* zero_face,
+                      int* zero_flags, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
@@ -175,11 +176,12 @@ struct BandEntry {          // a halo node and its nearest band node (16 bytes)
 void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s);
 // bit-row path of update_band! (lsm_band.hip)
 bool band_bits_fit(const BandArgs& a, int nl);
-void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE, hipStream_t s);
+void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE,
+                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, hipStream_t s);
 void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
                            const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s);
 void launch_band_copy_values(const BandArgs& a, const unsigned char* mask, const void* src, void* dst, hipStream_t s);
-void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, double* out, hipStream_t s);
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, double* out, hipStream_t s);
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
