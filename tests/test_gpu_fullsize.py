@@ -196,3 +196,117 @@ def test_stage_refuses_planes_of_two_gib_and_accepts_just_below(lsm):
     tail = out[org + n - 1000:org + n].cpu().numpy()
     want = (np.arange(n - 1000, n) * h) - cdt * 1.0
     assert np.abs(tail - want).max() <= 1e-12
+
+
+def _symmetric_sphere(n, r0, dtype=np.float64):
+    """ϕ = ‖x‖ − r0 on [-1, 1]^3 sampled at coordinates c_i = (2i − (n−1))/(n−1): c_{n−1−i} = −c_i EXACTLY, so the array is
+    bit-for-bit invariant under the reflections of the axes and under permutations of them."""
+    c = (2.0 * np.arange(n) - (n - 1)) / (n - 1)
+    assert np.array_equal(c[::-1], -c)
+    c2 = c * c
+    out = np.empty((n, n, n), dtype=dtype, order="F")
+    for k in range(n):                                  # plane by plane: no 2 x n^3 float64 temporaries
+        out[:, :, k] = (np.sqrt((c2[:, None] + c2[None, :]) + c2[k]) - r0).astype(dtype)
+    return out
+
+
+def test_512_cubed_config3_sphere_octant_symmetry_and_radial_speed(lsm):
+    """BASELINE config 3 at full size: 512³ sphere under NormalMotionTerm(0.1) + CurvatureTerm(-0.1), ExtrapolationBC(2), one
+    RK3 step (Δt from the curvature CFL, src/levelsetterms.jl:123-127).  Size-independent properties of the scheme:
+      * the scheme is equivariant under the reflections of the axes up to the association of its three-term second differences
+        ((ϕ₊ − 2ϕ₀) + ϕ₋ becomes (ϕ₋ − 2ϕ₀) + ϕ₊, src/derivatives.jl:129-175): the result of an exactly symmetric field is
+        symmetric in all eight octants to a few ulp in STRICT mode (the reference's operation order) — nothing of the
+        tiling, the march direction or the wave-uniform sign paths may show through — and to FAST's tolerance in FAST mode;
+      * a sphere ϕ = r − R moves with radial speed v + 2b/r (κ = 2/r, |∇ϕ| = 1): (ϕ⁰ − ϕ¹)/Δt equals it near the interface to
+        O(h²) — in STRICT and in FAST mode, which agree to FAST's stated tolerance."""
+    n, R, v, b = 512, 0.5, 0.1, -0.1
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    phi0 = _symmetric_sphere(n, R)
+    h = grid.meshsize(0)
+    res = {}
+    for mode in ("strict", "fast"):
+        eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(v), lsm.CurvatureTerm(b)), ic=lsm.MeshField(phi0, grid), bc=lsm.ExtrapolationBC(2),
+                                  integrator=lsm.RK3(), mode=mode)
+        dt = 0.5 * eq.compute_cfl(0.0)
+        sv = (abs(v) / h + abs(v) / h) + abs(v) / h                                   # src/levelsetterms.jl:172-178, summed left to right
+        assert dt == 0.5 * min(h * h / (2 * abs(b)), 1 / sv)                          # :123-127
+        eq._advance(0.0, dt)
+        res[mode] = eq.current_state().values()
+        del eq
+    out = res["strict"]
+    assert all(np.array_equal(phi0, np.flip(phi0, axis=ax)) for ax in range(3))
+    for mode, tol in (("strict", 1e-15), ("fast", 3e-13)):
+        for ax in range(3):
+            d = np.abs(res[mode] - np.flip(res[mode], axis=ax)).max()
+            assert d <= tol * np.abs(out).max(), (mode, ax, d)
+    r = phi0 + R
+    near = np.abs(phi0) < 2 * h
+    assert near.sum() > 100000
+    for mode, o in res.items():
+        speed = (phi0[near] - o[near]) / dt                 # ϕ¹ = ϕ⁰ − Δt (v + bκ)|∇ϕ|
+        err = np.abs(speed - (v + 2 * b / r[near])).max()
+        assert err <= 60 * h * h, (mode, err, h * h)          # second-order ENO / centred differences on a smooth field
+    assert np.abs(res["fast"] - out).max() <= 3e-13 * np.abs(out).max()
+
+
+def test_768_cubed_config5_float32_band_is_symmetric_and_matches_the_dense_run(lsm):
+    """BASELINE config 5 at full size on one device: 768³, float32 storage, sphere r = 0.5, rigid rotation about z (WENO5) +
+    CurvatureTerm(-0.01), RK3, NeumannBC, narrow band nlayers = 3.  Properties that do not need an oracle run:
+      * the band built from the exactly symmetric field is invariant under the reflections of the three axes and under x <-> y
+        (cut cells and L1 dilations commute with them; the tile decomposition — 32 x 8 x 8 bricks — must not show through),
+        at the start and after a step + update_band!;
+      * one RK3 step on the band against the same step on the dense field: the band's edge nodes read extrapolated values
+        (src/meshfield.jl:481-511) and every stage carries their influence one stencil further in, so nothing is bitwise;
+        nodes whose own stencil lies inside the band agree to 1e-6, every band node within 1.5 h of the interface to 1e-5
+        (config 5's stated tolerance is 1e-4)."""
+    import torch
+    n = 768
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    phi0 = _symmetric_sphere(n, 0.5, np.float32)
+    terms = lambda: (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.01))
+    band = lsm.LevelSetEquation(terms=terms(), ic=lsm.NarrowBandMeshField(lsm.MeshField(phi0, grid, dtype=np.float32), nlayers=3),
+                                bc=lsm.NeumannBC(), integrator=lsm.RK3())
+
+    def symmetric(m):
+        return all(np.array_equal(m, np.flip(m, axis=ax)) for ax in range(3)) and np.array_equal(m, m.transpose(1, 0, 2))
+
+    m0 = band.current_state().active_mask()
+    assert 3.0e6 < m0.sum() < 4.5e6 and symmetric(m0)
+    dt = 0.5 * band.compute_cfl(0.0)
+    band._advance(0.0, dt)
+    vb = band.current_state().values()                    # before update_band!: the band is still m0
+    band.update_band()
+    m1 = band.current_state().active_mask()
+    assert symmetric(m1)
+    del band
+    torch.cuda.empty_cache()
+    dense = lsm.LevelSetEquation(terms=terms(), ic=lsm.MeshField(phi0, grid, dtype=np.float32), bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    assert 0.5 * dense.compute_cfl(0.0) <= dt               # the dense minimum runs over more nodes (the grid's corners): the band's Δt is taken for both
+    dense._advance(0.0, dt)
+    vd = dense.current_state().values()
+    del dense
+    # nodes whose whole stencil (3 along each axis, the 3^3 box) lies in the band: erode the mask accordingly — on two slabs of
+    # planes (the equator, where the band's normal lies in the plane, and the polar cap, where it is the march axis): the
+    # whole-array rolls of a 768³ mask cost minutes
+    h = grid.meshsize(0)
+    n_deep = n_near = 0
+    d_deep = d_near = 0.0
+    for z0, z1 in ((340, 428), (556, 600)):
+        sl = (slice(None), slice(None), slice(z0 - 3, z1 + 3))
+        mm = m0[sl]
+        deep = mm.copy()
+        for ax in range(3):
+            for k in (1, 2, 3):
+                deep &= np.roll(mm, k, axis=ax) & np.roll(mm, -k, axis=ax)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    deep &= np.roll(mm, (dx, dy, dz), axis=(0, 1, 2))
+        deep[:, :, :3] = False                        # the rolls wrapped around inside the slab there
+        deep[:, :, -3:] = False
+        b64, d64 = vb[sl].astype(np.float64), vd[sl].astype(np.float64)
+        near = mm & (np.abs(phi0[sl]) < 1.5 * h)
+        n_deep += int(deep.sum()); n_near += int(near.sum())
+        d_deep = max(d_deep, float(np.abs(b64[deep] - d64[deep]).max()))
+        d_near = max(d_near, float(np.abs(b64[near] - d64[near]).max()))
+    assert n_deep > 1.0e5 and n_near > 3.0e4 and d_deep <= 1e-6 and d_near <= 1e-5, (n_deep, n_near, d_deep, d_near)

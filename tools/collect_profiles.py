@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copies what is judged from a tools/profile_r2.sh output directory (gpurun_out/..., scratch) into profiles/rN/ (tracked):
+"""Copies what is judged from a tools/profile_round.sh output directory (gpurun_out/..., scratch) into profiles/rN/ (tracked):
 tools/collect_profiles.py <profile-dir> <profiles/rN>"""
 import collections
 import csv

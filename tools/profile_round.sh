@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: tools/profile_r2.sh <outdir>  (GPU box) — everything profiles/r2/ is made from, for the build in the tree:
+# usage: tools/profile_round.sh <outdir> [round, default r3]  (GPU box) — everything profiles/<round>/ is made from, for the build in the tree:
 #   rocprofv3 kernel trace + PMC passes of the default bench (separate passes per counter group, as the guide prescribes),
 #   the in-kernel clock of the diagnostic build, the bench line itself, configs 2/3/5, the single-term stages with their
 #   HBM traffic, the slab-overhead run and the reinit run.  tools/make_profile_summary.py turns the CSVs into
 #   pmc_per_dispatch.json (keyed by the sha256 of the kernel sources).
 set -u
 OUT=$1
+RND=${2:-r3}
 mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
@@ -19,7 +20,7 @@ python3 tools/timeline_probe.py 512 > $OUT/timeline_probe.json 2> $OUT/timeline_
 LSM_STAGE_TAIL=0 python3 tools/timeline_probe.py 512 > $OUT/timeline_probe_no_tail.json 2> $OUT/timeline_probe_no_tail.err
 (cd tools && python3 tail_probe.py && LSM_STAGE_TAIL=0 python3 tail_probe.py) > $OUT/tail_probe.jsonl 2> $OUT/tail_probe.err
 python3 tools/make_profile_summary.py $OUT $OUT/pmc_per_dispatch.json > $OUT/summary.log 2>&1
-mkdir -p profiles/r2 && cp $OUT/pmc_per_dispatch.json profiles/r2/pmc_per_dispatch.json   # the bench line below reads it (same build, same box)
+mkdir -p profiles/$RND && cp $OUT/pmc_per_dispatch.json profiles/$RND/pmc_per_dispatch.json   # the bench line below reads it (same build, same box)
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
 for c in 2 3 5; do python3 bench.py --config $c > $OUT/bench_config$c.json 2> $OUT/bench_config$c.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c3 -- python3 bench.py --config 3 --steps 4 > /dev/null 2> $OUT/trace_c3.err
