@@ -112,6 +112,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->dtype = dtype; h->mode = mode; h->device = device;
     h->prof = false; h->ev_used = 0;
     h->comm = nullptr;
+    h->ghost_depth = LSM_GHOST;
     h->d_pf_flag = nullptr;
     memset(&h->band_cfl, 0, sizeof(h->band_cfl));
     h->cfl_prefetched = false;
@@ -291,7 +292,8 @@ int lsm_download_f64(LsmHandle* h, const void* dev_padded, void* host_dense) {
     return copy_interior(h, (void*)dev_padded, host_dense, false, sizeof(double));
 }
 
-static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s, bool skip_x = false, bool skip_y = false) {
+static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill_last, hipStream_t s, bool skip_x = false, bool skip_y = false,
+                             int depth = 0 /* 0: the handle's current step depth (LSM_GHOST outside a step) */) {
     const int N = h->grid.ndim;
     GhostAllArgs a;
     for (int e = 0; e < 3; ++e) a.n[e] = h->nloc[e];
@@ -303,6 +305,9 @@ static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill
     a.mb = mb; a.me = me; a.fill_last = fill_last;
     a.skip_x = skip_x ? 1 : 0;
     a.skip_y = skip_y && N == 3 ? 1 : 0;
+    static const bool full_depth = getenv("LSM_GHOST_FULL_DEPTH") != nullptr;     // A/B switch
+    if (depth == 0) depth = h->ghost_depth;
+    a.depth = (depth < 1 || depth > LSM_GHOST || full_depth) ? LSM_GHOST : depth;
     launch_ghost_fill_all(N, a, s);
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -681,7 +686,15 @@ static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, cons
 struct XRedirect {
     LsmHandle* h;
     bool on;
-    XRedirect(LsmHandle* h_, LsmStageHook hook) : h(h_), on(false) {
+    XRedirect(LsmHandle* h_, LsmStageHook hook, const LsmTerm* terms, int nterms) : h(h_), on(false) {
+        // ghost layers the stencils of this step read (stage_kernel.h, halo_of): the fills inside the step write no more than that.
+        // Not with a hook: it may read the field through its own kernels.
+        int depth = 0;
+        for (int k = 0; terms && k < nterms; ++k) {
+            const int g = terms[k].kind == LSM_TERM_ADVECTION ? (terms[k].scheme == LSM_SCHEME_WENO5 ? 3 : 1) : (terms[k].kind == LSM_TERM_CURVATURE ? 1 : 2);
+            depth = g > depth ? g : depth;
+        }
+        h->ghost_depth = (hook || depth < 1) ? LSM_GHOST : depth;
         static const bool off = getenv("LSM_XREDIRECT") && getenv("LSM_XREDIRECT")[0] == '0';
         auto copies = [&](int d, int sd) {
             const int k = h->bc[d][sd].kind;
@@ -692,7 +705,7 @@ struct XRedirect {
         // dimension 2 of a 3-D grid likewise (in 2-D it is the march axis: its ghost rows stay in memory)
         h->yredirect = on && h->grid.ndim == 3 && h->nloc[1] >= 2 * LSM_GHOST + 2 && copies(1, 0) && copies(1, 1);
     }
-    ~XRedirect() { h->xredirect = false; h->yredirect = false; }
+    ~XRedirect() { h->xredirect = false; h->yredirect = false; h->ghost_depth = LSM_GHOST; }
     int fill(void* field) const {
         if (!on) return lsm_fill_ghosts(h, field, 7, nullptr);
         return fill_ghosts_fused(h, field, 0, h->nloc[h->grid.ndim - 1], 1, h->stream, true, h->yredirect);
@@ -733,7 +746,7 @@ static int stage_slab(LsmHandle* h, const LsmTerm* terms, int nterms, const void
 // lsm_fill_ghosts(7) + lsm_halo_exchange first.
 static int advance_slab(LsmHandle* h, int integ, const LsmTerm* terms, int nterms, void* phi, void* buf1, void* buf2, double tc,
                         double dt, LsmStageHook hook, void* user) {
-    const XRedirect xr(h, hook);   // the x ghosts of a slab's planes (its own and the received ones) are resolved by the loads too
+    const XRedirect xr(h, hook, terms, nterms);   // the x ghosts of a slab's planes (its own and the received ones) are resolved by the loads too
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     if (integ == 0) {           // ForwardEuler — src/timestepping.jl:128-137
         LSM_TRY(stage_slab(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
@@ -759,7 +772,7 @@ int lsm_advance_fe(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, vo
     if (!h || !phi || !buf1) return LSM_ERR_INVALID;
     if (is_slab(h)) return advance_slab(h, 0, terms, nterms, phi, buf1, nullptr, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
-    const XRedirect xr(h, hook);
+    const XRedirect xr(h, hook, terms, nterms);
     LSM_TRY(xr.fill(phi));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));
@@ -774,7 +787,7 @@ int lsm_advance_rk2(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, v
     if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
     if (is_slab(h)) return advance_slab(h, 1, terms, nterms, phi, buf1, buf2, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
-    const XRedirect xr(h, hook);
+    const XRedirect xr(h, hook, terms, nterms);
     LSM_TRY(xr.fill(phi));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc, nullptr));
@@ -789,7 +802,7 @@ int lsm_advance_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, void* phi, v
     if (!h || !phi || !buf1 || !buf2) return LSM_ERR_INVALID;
     if (is_slab(h)) return advance_slab(h, 2, terms, nterms, phi, buf1, buf2, tc, dt, hook, user);
     LSM_TRY(check_single_device(h));
-    const XRedirect xr(h, hook);
+    const XRedirect xr(h, hook, terms, nterms);
     LSM_TRY(xr.fill(phi));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     LSM_TRY(lsm_stage(h, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, nullptr));

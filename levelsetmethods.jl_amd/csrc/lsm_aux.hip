@@ -108,7 +108,7 @@ __device__ __forceinline__ double ghost_resolve(const GhostAllArgs& a, int I0, i
 // 4.8 M at 512³) or long long.  With 64-bit divisions the index arithmetic, not the 120 MB the kernel moves, set its time.
 template <int NDIM, class IT>
 __global__ void __launch_bounds__(256) ghost_fill_all_kernel(const GhostAllArgs a) {
-    constexpr int G = LSM_GHOST;
+    const int G = a.depth;       // layers to fill (<= LSM_GHOST, the layout's padding)
     const int P0 = a.n[0] + 2 * G, P1 = NDIM > 1 ? a.n[1] + 2 * G : 1;
     // region sizes: (A) ghosts of the last dim over the full padded lower dims, (B) [3-D only] y ghosts
     // over padded x and interior z, (C) x ghosts over interior y,z
@@ -176,7 +176,7 @@ __device__ __forceinline__ int ghost_copy_source(const GhostAllArgs& a, int i) {
 
 template <int NDIM, bool COPY>
 __global__ void __launch_bounds__(256) ghost_rows_kernel(const GhostAllArgs a) {
-    constexpr int G = LSM_GHOST;
+    const int G = a.depth;       // layers to fill (<= LSM_GHOST)
     const int P0 = a.n[0] + 2 * G, P1 = NDIM == 3 ? a.n[1] + 2 * G : 1;
     const int nl = a.n[NDIM - 1];
     const bool lastL = a.fill_last && a.kind[NDIM - 1][0] != LSM_BC_NONE, lastR = a.fill_last && a.kind[NDIM - 1][1] != LSM_BC_NONE;
@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(256) ghost_rows_kernel(const GhostAllArgs a) {
         const int nrows = NDIM == 3 ? a.n[1] : np;
         const int g = (int)threadIdx.x % (2 * G);
         const int I0 = g < G ? g - G : a.n[0] + (g - G);
-        if ((int)threadIdx.x >= 42 * 2 * G) return;
-        for (int r = (int)blockIdx.x * 42 + (int)threadIdx.x / (2 * G); r < nrows; r += 42 * (int)gridDim.x) {
+        const int rpb = 256 / (2 * G);                                   // rows per block: 42 with three layers
+        if ((int)threadIdx.x >= rpb * 2 * G) return;
+        for (int r = (int)blockIdx.x * rpb + (int)threadIdx.x / (2 * G); r < nrows; r += rpb * (int)gridDim.x) {
             if (NDIM == 3) put(I0, r, a.mb + l); else put(I0, a.mb + r, 0);
         }
     }
@@ -219,7 +220,7 @@ static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
     if (ndim < 2) return false;
     static const bool off = getenv("LSM_GHOST_FLAT") != nullptr;          // A/B switch: the flat enumeration
     if (off) return false;
-    const int G = LSM_GHOST;
+    const int G = a.depth;
     const long long P0 = a.n[0] + 2 * G, P1 = ndim == 3 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
     const long long np = a.me - a.mb;
@@ -233,8 +234,10 @@ static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
             if (k == LSM_BC_NONE) continue;
             if (k == LSM_BC_EXTRAPOLATION && a.degree[d][sd] != 0) copy = false;
         }
-    // weighted faces (extrapolation of degree >= 1) stay with the flat kernel: the nested sums inlined into both loops of the
-    // row form cost 166 registers and spills (289 µs against 75 µs at 512³ with ExtrapolationBC(2))
+    // weighted faces (extrapolation of degree >= 1) stay with the flat kernel.  Tried in row form twice: with the nested sums
+    // inlined as a recursion into both loops (166 registers, spills: 289 µs against 75 µs at 512³ with ExtrapolationBC(2)) and, in
+    // round 3, as runtime loops with the face ghosts' loads issued together (low registers: 65 µs against the flat kernel's 57 µs
+    // at two layers) — the time is the scattered sectors of the row ends, not the index arithmetic.
     if (!copy) return false;
     const dim3 grid((unsigned)((P0 + 255) / 256), (unsigned)lines);
     if (ndim == 2) hipLaunchKernelGGL((ghost_rows_kernel<2, true>), grid, dim3(256), 0, s, a);
@@ -244,7 +247,7 @@ static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
 
 void launch_ghost_fill_all(int ndim, const GhostAllArgs& a, hipStream_t s) {
     if (ghost_rows_launch(ndim, a, s)) return;
-    const int G = LSM_GHOST;
+    const int G = a.depth;
     const long long P0 = a.n[0] + 2 * G, P1 = ndim > 1 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;
     const long long np = a.me - a.mb;

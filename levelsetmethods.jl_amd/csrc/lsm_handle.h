@@ -86,6 +86,7 @@ struct LsmHandle {
     size_t ev_used;
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
+    int ghost_depth;               // ghost layers the fills write: LSM_GHOST, or what the step in progress reads (XRedirect)
     unsigned* d_tail_ctr;          // ring of LSM_TAIL_SLOTS ticket counters of the dynamic tail (each launch resets its own)
     unsigned tail_ticket;          // host: launches that took a slot so far
     bool xredirect;                // set around the stages of a whole-grid lsm_advance_*: x ghosts are resolved by the stage kernel's loads

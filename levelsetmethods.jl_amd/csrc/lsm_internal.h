@@ -123,6 +123,8 @@ struct GhostAllArgs {
     int fill_last;     // also fill the (physical) ghosts of the last dimension
     int skip_x;        // leave the ghost nodes at the ends of the interior rows alone (StageArgs::xredirect: nobody reads them)
     int skip_y;        // 3-D: leave the ghost rows of dimension 2 of the interior planes alone (StageArgs::yredirect)
+    int depth;         // ghost layers to fill, 1..LSM_GHOST: what the stencils of the step about to run read (a ghost's value
+                       // depends on interior nodes only, so the outer layers may stay stale)
 };
 
 struct CflArgs {
