@@ -87,6 +87,30 @@ LSM_DEV void stg(ST* base, unsigned boff, double v) {
     if constexpr (sizeof(ST) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lsm_v2u, v), plane_rsrc(base), boff, 0, AUX);
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), plane_rsrc(base), boff, 0, AUX);
 }
+// two neighbouring elements in one access (16 bytes for double, 8 for float): the pair kernels below (stage_tile2)
+typedef unsigned lsm_v4u __attribute__((ext_vector_type(4)));
+template <class ST, int AUX = 0>
+LSM_DEV void ldg2(const ST* base, unsigned boff, double& x, double& y, int range = (int)0x80000000u) {
+    if constexpr (sizeof(ST) == 8) {
+        const lsm_v4u v = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(base, range), boff, 0, AUX));
+        x = __builtin_bit_cast(double, lsm_v2u{v.x, v.y});
+        y = __builtin_bit_cast(double, lsm_v2u{v.z, v.w});
+    } else {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base, range), boff, 0, AUX));
+        x = (double)__builtin_bit_cast(float, (unsigned)u);
+        y = (double)__builtin_bit_cast(float, (unsigned)(u >> 32));
+    }
+}
+template <class ST, int AUX = 0>
+LSM_DEV void stg2(ST* base, unsigned boff, double x, double y) {
+    if constexpr (sizeof(ST) == 8) {
+        const lsm_v2u a = __builtin_bit_cast(lsm_v2u, x), b = __builtin_bit_cast(lsm_v2u, y);
+        __builtin_amdgcn_raw_buffer_store_b128(lsm_v4u{a.x, a.y, b.x, b.y}, plane_rsrc(base), boff, 0, AUX);
+    } else {
+        const unsigned long long u = (unsigned long long)__builtin_bit_cast(unsigned, (float)x) | ((unsigned long long)__builtin_bit_cast(unsigned, (float)y) << 32);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lsm_v2u, u), plane_rsrc(base), boff, 0, AUX);
+    }
+}
 // byte load with an explicit range: range 0 (no array) returns 0 without touching memory
 LSM_DEV unsigned ldg_u8(const unsigned char* base, unsigned boff, int range) {
     return __builtin_amdgcn_raw_buffer_load_b8(
@@ -990,6 +1014,178 @@ __global__ void __launch_bounds__(TX* TY, (LSM_ZROT && !LSM_STRICT && NDIM == 3 
     stage_tile<NDIM, ADV, NM, CURV, EIK, TX, TY, MC, ST, AK, MASKED>(a, tile_id, tail_tile, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Two nodes per thread along x (round 3): the memory-bound members of the family — a single upwind / NormalMotion / Eikonal
+// term with constant coefficients on a dense 3-D field — move their field with 16-byte accesses: a hand-written copy
+// of the same padded array runs at 6.2–6.3 TB/s with 16 bytes per lane against 5.7–5.9 with 8 (tools/copy_bw.hip), and a tile
+// twice as wide halves the share of the x halo.  Thread (tx, ty) owns nodes (2tx, 2tx+1) of row ty of a 2TX × TY tile and
+// marches like stage_tile (shifting register lines, one barrier per plane, every load of a plane issued before its barrier);
+// node_update runs once per node on the same LDS tile, so the arithmetic — and every bit of the result — is stage_tile's.
+// Plain variants only (FAST build, constants, one output, no band mask), n[0] even; everything else takes stage_tile.
+template <int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST>
+__device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id) {
+    constexpr int NDIM = 3;
+    constexpr int AK = LSM_COEFF_CONST;
+    constexpr int G = halo_of(ADV, NM, CURV, EIK);
+    constexpr int LEAD = CURV ? 1 : 0;
+    constexpr int NSLOT = 2 * LEAD + 2;
+    constexpr int TXN = 2 * TX;
+    constexpr int W = TXN + 2 * G, H = TY + 2 * G, HW = H * W, NT = TX * TY;
+    constexpr int NHX = 2 * G * TY;
+    constexpr int WY = CURV ? W : TXN;
+    constexpr int NHY = 2 * G * WY;
+    constexpr int NH = NHX + NHY;
+    constexpr int HPT = (NH + NT - 1) / NT;
+    __shared__ double tile[NSLOT * HW];
+
+    const unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1], tbm = tile_id / (a.nb[0] * a.nb[1]);
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int bx0 = tbx * TXN, by0 = tby * TY;
+    const int gx = bx0 + 2 * tx, gy = by0 + ty;
+    const int nx = a.n[0], ny = a.n[1], nm = a.n[2];
+    const long long sy = a.s1, sm = a.s2;
+    const bool active = gx < nx && gy < ny;          // n[0] is even: the two nodes of a pair are in range together
+    const int xk0 = a.xkind[0], xk1 = a.xkind[1], yk0 = a.ykind[0], yk1 = a.ykind[1];
+    const bool xmap = a.xredirect && (bx0 < G || bx0 + TXN + G > nx);
+    const bool ymap = a.yredirect && (by0 < G || by0 + TY + G > ny);
+    auto bsrc = [](int i, int n, int k0, int k1) {
+        const bool left = i < 0;
+        const int k = left ? -i : i - (n - 1), kind = left ? k0 : k1;
+        const int per = left ? (n - 1) - k : k, ext = left ? 0 : n - 1, sym = left ? k : (n - 1) - k;
+        return kind == LSM_BC_PERIODIC ? per : (kind == LSM_BC_EXTRAPOLATION ? ext : sym);
+    };
+    auto xsrc = [&](int i) { return (!xmap || (i >= 0 && i < nx)) ? i : bsrc(i, nx, xk0, xk1); };
+    auto ysrc = [&](int i) { return (!ymap || (i >= 0 && i < ny)) ? i : bsrc(i, ny, yk0, yk1); };
+    // a tile whose own columns all lie in the grid loads its pairs in one access; a partial tile (wave-uniform branch) loads the
+    // two nodes of its out-of-range pairs one by one from wherever the ghost layers / the redirect put them
+    const bool whole = bx0 + TXN <= nx;
+    const int lyg = ysrc(gy < ny + G ? gy : ny + G - 1);
+    const int lx0 = xsrc(gx < nx + G ? gx : nx + G - 1), lx1 = xsrc(gx + 1 < nx + G ? gx + 1 : nx + G - 1);
+    const long long corner = a.origin - G - (long long)G * sy;
+    const unsigned orow = (unsigned)(lyg + G) * (unsigned)sy;
+    const unsigned ocole0 = (unsigned)(lx0 + G) + orow, ocole1 = (unsigned)(lx1 + G) + orow;
+    const unsigned ocol0 = (unsigned)sizeof(ST) * ocole0, ocol1 = (unsigned)sizeof(ST) * ocole1, ocold0 = 8u * ocole0;
+    const int mc = a.mc > 0 ? a.mc : MC;
+    const int m0 = a.mb + (int)tbm * mc;
+    const int m1 = m0 + mc < a.me ? m0 + mc : a.me;
+    auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
+    auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
+    auto ldpair = [&](const ST* P, double& x, double& y) {
+        if (whole) ldg2(P, ocol0, x, y);
+        else { x = ldg(P, ocol0); y = ldg(P, ocol1); }
+    };
+
+    int hl[HPT];
+    unsigned hg[HPT];
+    bool hv[HPT];
+#pragma unroll
+    for (int h = 0; h < HPT; ++h) {
+        const int e = tid + h * NT;
+        hv[h] = e < NH;
+        int lx, ly;
+        if (e < NHX) {
+            const int r = e % (2 * G);
+            ly = e / (2 * G) + G;
+            lx = r < G ? r : r + TXN;
+        } else {
+            const int e2 = e - NHX;
+            const int row = e2 / WY;
+            lx = (CURV ? 0 : G) + e2 % WY;
+            ly = row < G ? row : row + TY;
+        }
+        int X = bx0 - G + lx;
+        X = xsrc(X > nx + G - 1 ? nx + G - 1 : X);
+        int Y = by0 - G + ly;
+        Y = ysrc(Y > ny + G - 1 ? ny + G - 1 : Y);
+        hl[h] = ly * W + lx;
+        hg[h] = (unsigned)sizeof(ST) * ((unsigned)(X + G) + (unsigned)(Y + G) * (unsigned)sy);
+        if (!hv[h]) hg[h] = LSM_OOB_OFFSET;
+    }
+    const int lpos = (ty + G) * W + 2 * tx + G;
+
+    double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
+    if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, 0, 0, pre_adv);
+    if constexpr (NM != 0) coeff_prep<NDIM, 1, false, AK>(a.nm, a, 0, 0, pre_nm);
+    if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, AK>(a.curv, a, 0, 0, pre_curv);
+
+    double zA[2 * G + 1], zB[2 * G + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * G; ++j) ldpair(plane(m0 - G + j), zA[j], zB[j]);
+    double hp[2 * LEAD + 1][HPT];
+#pragma unroll
+    for (int pl = -LEAD; pl <= LEAD; ++pl) {
+        const ST* P = plane(m0 + pl);
+#pragma unroll
+        for (int h = 0; h < HPT; ++h) hp[pl + LEAD][h] = ldg(P, hg[h]);
+    }
+#pragma unroll
+    for (int pl = -LEAD; pl <= LEAD; ++pl) {
+        const int slot = pl + LEAD;
+        tile[slot * HW + lpos] = zA[G + pl];
+        tile[slot * HW + lpos + 1] = zB[G + pl];
+#pragma unroll
+        for (int h = 0; h < HPT; ++h)
+            if (hv[h]) tile[slot * HW + hl[h]] = hp[slot][h];
+    }
+    long long po = corner + (long long)m0 * sm;
+    const ST* Pnx = plane(m0 + G);
+    const ST* Pn = plane(m0 + LEAD);
+    const int plast = nm + G - 1;
+    const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
+    const int prange = __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int m = m0; m < m1; ++m) {
+        Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
+        Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
+        double nA, nB;
+        ldpair(Pnx, nA, nB);
+        double hn[HPT];
+#pragma unroll
+        for (int h = 0; h < HPT; ++h) hn[h] = ldg(Pn, hg[h]);
+        // this plane's pointwise operands: consumed after the arithmetic
+        NodeOps opA, opB;
+        opA.u[0] = pre_adv[0]; opA.u[1] = pre_adv[1]; opA.u[2] = pre_adv[2];
+        opA.vnm = pre_nm[0]; opA.bcurv = pre_curv[0]; opA.s0 = 0.0; opA.phin = 0.0; opA.out2 = 0.0; opA.have_negs = false;
+        opA.negs[0] = opA.negs[1] = opA.negs[2] = 0ull;
+        opB = opA;
+        if constexpr (EIK == 1) ldg2(uniform_ptr(a.s0 + po), ocold0, opA.s0, opB.s0);
+        // always issued; when the base is ψ the descriptor's range is 0: the load returns 0 and touches no memory
+        ldg2<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + po), ocol0, opA.phin, opB.phin, prange);
+        LSM_BARRIER();
+        double rA = 0.0, rB = 0.0, r2 = 0.0;
+        if (any_active) {
+            const int rel = m - m0;
+            const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
+            const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
+            const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
+            NodeView<NDIM, G, W> nvB{T0 + 1, Tm + 1, Tp + 1, zB, zB[G]};
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nvB, opB, rB, r2);
+            NodeView<NDIM, G, W> nvA{T0, Tm, Tp, zA, zA[G]};
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nvA, opA, rA, r2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * G; ++j) { zA[j] = zA[j + 1]; zB[j] = zB[j + 1]; }
+        zA[2 * G] = nA; zB[2 * G] = nB;
+        const int wslot = (m - m0 + 1 + 2 * LEAD) % NSLOT;
+        tile[wslot * HW + lpos] = zA[G + LEAD];
+        tile[wslot * HW + lpos + 1] = zB[G + LEAD];
+#pragma unroll
+        for (int h = 0; h < HPT; ++h)
+            if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];
+        if (active) stg2<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + po), ocol0, rA, rB);
+        po += sm;
+    }
+}
+
+template <int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST>
+__global__ void __launch_bounds__(TX* TY, LSM_WAVES_PER_EU) stage_kernel2(const StageArgs a) {
+    const TileOrder ord(a);
+    unsigned tile_id;
+    bool tail_tile;
+    if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail_tile)) return;
+    stage_tile2<ADV, NM, CURV, EIK, TX, TY, MC, ST>(a, tile_id);
+}
+
 template <int NDIM>
 struct TileCfg;
 template <>
@@ -1029,8 +1225,43 @@ struct WideTile3 { static constexpr int TX = 64, TY = 8, MC = LSM_MC3; };
 template <int NDIM, int ADV, int NM, int CURV, int EIK, class T>
 void launch_tiled(const StageArgs& a, hipStream_t s);
 
+// the pair kernels (stage_tile2): which combinations, and the launch
+template <int NDIM, int ADV, int NM, int CURV, int EIK>
+constexpr bool pair_combo() {
+    // (NormalMotion + curvature, config 3's pair, was tried: issue-bound, 0.663 against 0.644 ms per 512³ stage — not taken.  The
+    // single curvature term gained 4 % but its three-plane LDS ring gave wrong values at the even nodes behind the first plane of a
+    // chunk; not found in the time there was, so curvature stays with stage_tile.)
+    return !LSM_STRICT && NDIM == 3 && ADV != 2 && !CURV && (ADV != 0) + (NM != 0) + (EIK != 0) == 1;
+}
+template <int ADV, int NM, int CURV, int EIK>
+bool launch_pairs(const StageArgs& a, hipStream_t s) {
+    const int env = getenv("LSM_PAIRS") ? atoi(getenv("LSM_PAIRS")) : 1;     // A/B switch (read per launch: tests flip it): 0 = one node per thread everywhere
+    const bool consts = (!ADV || a.adv.kind == LSM_COEFF_CONST) && (!NM || a.nm.kind == LSM_COEFF_CONST) && (!CURV || a.curv.kind == LSM_COEFF_CONST);
+    if (!env || a.mask || a.tile_active || a.tile_list || a.mc > 0 || a.out2 || !a.natural || !consts || (a.n[0] & 1) || a.n[0] < 128 || a.me <= a.mb ||
+        getenv("LSM_STAGE_GENERIC"))
+        return false;
+    static_assert(!CURV, "the pair kernels serve the axis-aligned single terms");
+    constexpr int TX = 64, TY = 8, MC = LSM_MC3;
+    StageArgs b = a;
+    b.nb[0] = (a.n[0] + 2 * TX - 1) / (2 * TX);
+    b.nb[1] = (a.n[1] + TY - 1) / TY;
+    int mc = MC;
+    while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
+    b.mc = mc;
+    b.nb[2] = (a.me - a.mb + mc - 1) / mc;
+    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0; b.yfast = 0;
+    const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
+    const dim3 grid(((ntiles + 7u) / 8u) * 8u), block(TX * TY);
+    if (b.f32) hipLaunchKernelGGL((stage_kernel2<ADV, NM, CURV, EIK, TX, TY, MC, float>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((stage_kernel2<ADV, NM, CURV, EIK, TX, TY, MC, double>), grid, block, 0, s, b);
+    return true;
+}
+
 template <int NDIM, int ADV, int NM, int CURV, int EIK>
 void launch_one(const StageArgs& a, hipStream_t s) {
+    if constexpr (pair_combo<NDIM, ADV, NM, CURV, EIK>()) {
+        if (launch_pairs<ADV, NM, CURV, EIK>(a, s)) return;
+    }
     if constexpr (wide_tile_combo<NDIM, ADV, NM, CURV, EIK>()) {
         if (!a.mask && !a.tile_active && !a.tile_list && a.mc <= 0 && a.n[0] >= 64 && !a.out2) {
             launch_tiled<NDIM, ADV, NM, CURV, EIK, WideTile3>(a, s);

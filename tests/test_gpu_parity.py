@@ -384,3 +384,40 @@ def test_plane_range_stages_compose_to_the_full_stage(hip, orc, shape, bcspec):
     c.be.fill_ghosts_planes(part, B, n - B)
     c.be.fill_ghosts(part, 1 << (nd - 1))
     assert np.array_equal(c.to_host(part), c.to_host(full))
+
+
+PAIRS = {
+    "upwind": [("adv", ("const", (0.7, -0.4, 0.9)), "upwind")],
+    "nm": [("nm", ("const", (0.6,)))],
+    "nm_neg": [("nm", ("const", (-0.6,)))],
+    "eik_current": [("eik", None)],
+    "eik_frozen": [("eik", "phi0")],
+}
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,bcspec", [((128, 16, 20), "neumann"), ((256, 11, 70), "periodic"), ((130, 20, 9), ("extrapolation", 2)),
+                                          ((384, 8, 8), "symmetry"), ((200, 13, 30), [("neumann", ("extrapolation", 3)), "periodic", ("symmetry", "linear")])])
+@pytest.mark.parametrize("name", list(PAIRS))
+def test_pair_kernels_match_the_oracle_and_the_one_node_kernels(hip, orc, monkeypatch, name, shape, bcspec, dtype):
+    """The two-nodes-per-thread kernels (stage_tile2: 16-byte accesses, tiles 128 nodes wide) serve the dense FAST
+    launches of a single upwind / NormalMotion / Eikonal term when n1 is even and
+    >= 128.  They call the same node_update on the same LDS tile as the one-node kernels (LSM_PAIRS=0): results bit for bit
+    equal to theirs, and within the stage tolerance of the oracle — whole tiles, partial tiles in x (130, 200, 384 = 3 x 128),
+    partial tiles in y, every base mode, float32 storage."""
+    dt = np.dtype(dtype)
+    c = hip.Case(shape, bcspec, mode="fast", dtype=dt)
+    phi = _rand_field(shape, 7)
+    if dt == np.float32:
+        phi = np.asfortranarray(phi.astype(np.float32).astype(np.float64))
+    specs = _fix_specs(PAIRS[name], 3, phi)
+    for base_mode in (0, 1, 2, 3):
+        monkeypatch.setenv("LSM_PAIRS", "1")
+        got, want, _, _ = _run_stage(c, orc, specs, phi, base_mode)
+        monkeypatch.setenv("LSM_PAIRS", "0")
+        one, _, _, _ = _run_stage(c, orc, specs, phi, base_mode)
+        assert np.array_equal(got, one), (name, base_mode, np.abs(got - one).max())
+        if dt == np.float64:
+            assert np.abs(got - want).max() <= TOL_STAGE * np.abs(want).max(), (name, base_mode)
+        else:
+            assert np.abs(got - want.astype(np.float32).astype(np.float64)).max() <= 2.4e-7 * np.abs(want).max(), (name, base_mode)
