@@ -458,7 +458,7 @@ end
 # ---- NarrowBandMeshField on the device (src/meshfield.jl:314-588): dense padded values + byte masks --------------------
 # The reference steps a band field with the SAME _advance! / compute_cfl / update_band! sequence as a dense one
 # (src/timestepping.jl:101-122,126-202; src/meshfield.jl:555-588); the methods below are that sequence for a device band.
-const BAND_MC = 8             # planes per tile along the last dimension
+const BAND_MC = 16            # planes per tile along the last dimension (8, 12, 16, 24, 32 measured at 768³: 16 is the fastest)
 const BAND_OVERLAP = 10       # planes of each neighbouring rank a slab of a band holds (include/lsm.h, lsm_band_overlap_config)
 mutable struct ROCNarrowBandMeshField{N, T, B, S} <: LSM.AbstractMeshField{N, T, S}
     buf::ROCVector{S}

@@ -592,7 +592,7 @@ class ROCNarrowBandMeshField(ROCMeshField):
     """Device narrow band: dense padded values + a byte mask of active nodes (+ the halo mask and
     tile flags derived from it).  Non-band entries of the value array are scratch: before every
     stage they are refilled, within 3 nodes of the band, with the reference's affine extrapolant."""
-    MC = int(os.environ.get("LSM_BAND_MC", "8"))   # planes per march chunk in band mode (tile = 32 x 8 x MC in 3-D)
+    MC = int(os.environ.get("LSM_BAND_MC", "16"))   # planes per brick in band mode (tile = 32 x 8 x MC in 3-D; 16 measured best at 768^3: tools/band_probe.py)
     HALO = 3
 
     def __init__(self, backend, mesh, bcs, nlayers, buf=None):

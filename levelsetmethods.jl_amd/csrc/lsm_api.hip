@@ -627,7 +627,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             }
             int nlisted = 0;
             if (h->band_mask && N == 3 && a.tile_active && have_lists(h, h->band_tiles, h->band_mc))
-                nlisted = launch_cfl_band_list(a, h->d_act_list, h->nact, nullptr, 1024, cs);   // one workgroup per active tile
+                nlisted = launch_cfl_band_list(a, h->d_act_list, h->nact, nullptr, MAXB, cs);   // one workgroup per active tile
             if (nlisted > 0) {
                 nb = nlisted;
             } else if (cand) {
@@ -1135,6 +1135,7 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
 static bool band_cfl_node_dependent(const LsmTerm& tm) {
     return tm.kind != LSM_TERM_EIKONAL && tm.coeff.kind != LSM_COEFF_CONST;
 }
+static const int PF_PARTIALS = 2048;       // workgroups (partials) per prefetched reduction: 4 slots in the 2·MAXB doubles of d_partial
 static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, int mc) {
     LsmHandle::BandCfl& pf = h->band_cfl;
     pf.pending = false; pf.valid = false;
@@ -1146,13 +1147,13 @@ static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, 
         if (sl < 0) continue;
         CflArgs a;
         cfl_args(h, pf.terms[k], 0.0, a);              // armed terms carry no time factor
-        a.partial = h->d_partial + 1024 * sl;
+        a.partial = h->d_partial + PF_PARTIALS * sl;
         a.nanflag = h->d_pf_flag + sl;
         a.mask = (const unsigned char*)mask;
         a.tile_active = (const unsigned char*)tiles;
         a.tx = ba.tx; a.ty = ba.ty; a.tm = ba.tm; a.nbx = ba.nbx; a.nby = ba.nby;
-        if (launch_cfl_band_list(a, h->d_act_list, 0, h->d_lcounts, 1024, h->stream) != 1024) return LSM_OK;   // tile shape not served: no prefetch
-        launch_cfl_final(a.partial, 1024, a.nanflag, h->d_result + 8 + sl, pf.terms[k].kind, h->dxmin, 1, h->stream);
+        if (launch_cfl_band_list(a, h->d_act_list, 0, h->d_lcounts, PF_PARTIALS, h->stream) != PF_PARTIALS) return LSM_OK;   // tile shape not served: no prefetch
+        launch_cfl_final(a.partial, PF_PARTIALS, a.nanflag, h->d_result + 8 + sl, pf.terms[k].kind, h->dxmin, 1, h->stream);
     }
     LSM_HIP(h, hipGetLastError());
     pf.pending = true;
