@@ -852,17 +852,44 @@ __device__ __forceinline__ void fill_xkey(unsigned* xkey) {
         xkey[p] = k;
     }
 }
-// _nearest_band_node inside the 7^3 cube around box position (lx, r = ly + by·lm): smallest (|off|², o_z, o_y, o_x) among the set bits
-__device__ __forceinline__ unsigned nearest_key(const u64* B, const unsigned* xkey, int by, int r, int lx) {
-    unsigned best = 0xffffffffu;
-#pragma unroll
-    for (int dm = -RL; dm <= RL; ++dm)
-#pragma unroll
-        for (int dy = -RL; dy <= RL; ++dy) {
-            const unsigned pat = (unsigned)(B[r + dy + dm * by] >> (lx - RL)) & 0x7fu;
-            const unsigned key = xkey[pat] + (((unsigned)(dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7));
-            best = key < best ? key : best;
+// _nearest_band_node inside the 7^3 cube around box position (lx, r = ly + by·lm): smallest (|off|², o_z, o_y, o_x) among the set bits.
+// The 49 x-lines of the cube are visited in shells of growing dy² + dm²; once every searching lane of the wave holds a hit nearer than
+// the next shell can be (its |off|² >= that shell's dy² + dm²; ties included: they are only possible inside visited shells) the wave
+// stops — a halo node of the first layer after 5 lines, one of the third after 29 at most.
+struct ShellTab {
+    signed char dy[49], dm[49];
+    int end[10], next_r2[10];
+    constexpr ShellTab() : dy{}, dm{}, end{}, next_r2{} {
+        const int r2s[10] = {0, 1, 2, 4, 5, 8, 9, 10, 13, 18};
+        int n = 0;
+        for (int g = 0; g < 10; ++g) {
+            for (int m = -RL; m <= RL; ++m)
+                for (int y = -RL; y <= RL; ++y)
+                    if (y * y + m * m == r2s[g]) { dy[n] = (signed char)y; dm[n] = (signed char)m; ++n; }
+            end[g] = n;
+            next_r2[g] = g < 9 ? r2s[g + 1] : (1 << 20);
         }
+    }
+};
+__device__ __forceinline__ unsigned nearest_key(const u64* B, const unsigned* xkey, int by, int r, int lx) {
+    constexpr ShellTab S{};
+    static_assert(S.end[9] == 49, "the shells cover the 7 x 7 lines of the cube");
+    unsigned best = 0xffffffffu;
+    bool done = false;
+#pragma unroll
+    for (int g = 0; g < 10; ++g) {
+        if (!done) {
+#pragma unroll
+            for (int i = (g == 0 ? 0 : S.end[g - 1]); i < S.end[g]; ++i) {
+                const int dy = S.dy[i], dm = S.dm[i];
+                const unsigned pat = (unsigned)(B[r + dy + dm * by] >> (lx - RL)) & 0x7fu;   // bit j <-> o_x = j - RL
+                const unsigned key = xkey[pat] + (((unsigned)(dy * dy + dm * dm) << 9) | (unsigned)((dm + RL) * 49 + (dy + RL) * 7));
+                best = key < best ? key : best;
+            }
+            // wave-uniform: nobody can still find a nearer (or an equally near, earlier) node in the shells to come
+            done = __ballot((best >> 9) >= (unsigned)S.next_r2[g]) == 0ull;
+        }
+    }
     return best;
 }
 
@@ -944,10 +971,13 @@ __global__ void __launch_bounds__(256) band_grow_bits_kernel(BandArgs a, void* v
         lm = (int)((float)t * rby); ly = t - lm * by;
         if (ly >= by) { ++lm; ly -= by; } else if (ly < 0) { --lm; ly += by; }
     };
-    int ly_own, lm_own;                         // the box has at most one row per thread when tm = 8: its coordinates once for all passes
+    int ly_own, lm_own, ly_own2, lm_own2;       // a thread's (at most two, tm <= 24) box rows: their coordinates once for all passes
     rowcoords_slow((int)threadIdx.x, ly_own, lm_own);
+    rowcoords_slow((int)threadIdx.x + 256, ly_own2, lm_own2);
     auto rowcoords = [&](int t, int& ly, int& lm) {
-        if (t == (int)threadIdx.x) { ly = ly_own; lm = lm_own; } else rowcoords_slow(t, ly, lm);
+        if (t == (int)threadIdx.x) { ly = ly_own; lm = lm_own; }
+        else if (t == (int)threadIdx.x + 256) { ly = ly_own2; lm = lm_own2; }
+        else rowcoords_slow(t, ly, lm);
     };
     for (int t = threadIdx.x; t < nrows; t += blockDim.x) {      // cut cells (see band_grow3_kernel)
         int ly, lm;
@@ -1102,7 +1132,7 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
     // thread per NODE with lanes waiting for the few that search ran the 49-row scan for almost every wave.  They are listed
     // first (row-major, x ascending: the order of the tile's entries is deterministic) and then searched by full waves.
     unsigned* cnt = reinterpret_cast<unsigned*>(xkey + 128);                      // wpt + 1 words
-    unsigned short* wl = reinterpret_cast<unsigned short*>(cnt + wpt + 1);       // up to 32·wpt entries: (row << 5) | x
+    unsigned short* wl = reinterpret_cast<unsigned short*>(cnt + 2 * wpt + 2);   // up to 32·wpt entries: (row << 5) | x
     for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
         const int ry = t % a.ty, i = t / a.ty;
         const bool ing = y0 + ry < a.n[1] && m0 + i < a.n[2];
@@ -1111,16 +1141,21 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
         cnt[t] = w;
     }
     __syncthreads();
+    // offsets of the rows' entries: one wave scans the counts, two rows per lane (wpt <= 128)
+    unsigned* offs = cnt + wpt + 1;
+    if (threadIdx.x < 64) {
+        const int l = (int)threadIdx.x;
+        const unsigned c0 = 2 * l < wpt ? (unsigned)__builtin_popcount(cnt[2 * l]) : 0u, c1 = 2 * l + 1 < wpt ? (unsigned)__builtin_popcount(cnt[2 * l + 1]) : 0u;
+        unsigned inc = c0 + c1;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned vv = __shfl_up(inc, o, 64); if (l >= o) inc += vv; }
+        const unsigned ex = inc - (c0 + c1);
+        if (2 * l < wpt) offs[2 * l] = ex;
+        if (2 * l + 1 < wpt) offs[2 * l + 1] = ex + c0;
+        if (l == 63) s_cnt = inc;
+    }
+    __syncthreads();
     for (int t = threadIdx.x; t < wpt; t += blockDim.x) {
-        unsigned w = cnt[t], off = 0;
-        if (wpt <= 64) {                          // one wave holds every row: exclusive scan by shuffles (uniform branch)
-            unsigned inc = (unsigned)__builtin_popcount(w);
-            for (int o = 1; o < 64; o <<= 1) { const unsigned vv = __shfl_up(inc, o, 64); if ((int)(threadIdx.x & 63) >= o) inc += vv; }
-            off = inc - (unsigned)__builtin_popcount(w);
-        } else {
-            for (int j = 0; j < t; ++j) off += (unsigned)__builtin_popcount(cnt[j]);
-        }
-        if (t == wpt - 1) s_cnt = off + (unsigned)__builtin_popcount(w);
+        unsigned w = cnt[t], off = offs[t];
         while (w) {
             const int bpos = __builtin_ctz(w);
             wl[off++] = (unsigned short)((t << 5) | bpos);
@@ -1447,7 +1482,7 @@ void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, uns
                        src_mask, ring, nring, nring_lds, src, dst, miss, list, list_count, list_cap);
 }
 bool band_bits_fit(const BandArgs& a, int nl) {
-    return fast3(a, BAP, 5) && nl >= 0 && nl + 1 <= BAP && a.tm >= BAP;
+    return fast3(a, BAP, 5) && nl >= 0 && nl + 1 <= BAP && a.tm >= BAP && a.ty * a.tm <= 128;
 }
 void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE,
                       const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, hipStream_t s) {
@@ -1465,7 +1500,7 @@ void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const 
                            unsigned* list_count, unsigned list_cap, hipStream_t s) {
     if (no_tiles(a)) return;
     const size_t wpt = (size_t)a.ty * a.tm;
-    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + wpt) + 128 * sizeof(unsigned) + (wpt + 2) * sizeof(unsigned) + 64 * wpt;
+    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + wpt) + 128 * sizeof(unsigned) + (2 * wpt + 4) * sizeof(unsigned) + 64 * wpt;
     hipLaunchKernelGGL(band_halo_bits_kernel, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap);
 }
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
