@@ -648,6 +648,9 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #ifndef LSM_WAVES_PER_EU
 #define LSM_WAVES_PER_EU 1
 #endif
+#ifndef LSM_BAND_PATCH
+#define LSM_BAND_PATCH 1    // A/B (build) switch: 8 x 8 patches per wave in band mode
+#endif
 #ifndef LSM_ZROT
 #define LSM_ZROT 1
 #endif
@@ -723,7 +726,15 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     }
 
     const int tid = threadIdx.x;
-    const int tx = tid % TX, ty = tid / TX;
+    int tx = tid % TX, ty = tid / TX;
+    // Narrow band, 32×8 tile: a wave takes an 8 × 8 patch of the plane instead of two 32-node rows.  A wave without a band node
+    // skips the plane's arithmetic, and the band is a shell ~8 nodes thick: where its normal points along x a row crosses it
+    // in 8 of its 32 nodes — every row wave works at a quarter of its lanes — while of the four 8-wide patches one or two hold
+    // all of them.  (Where the normal points along y or the march axis both shapes do the same.)  Dense launches keep the rows:
+    // 256-byte segments per wave load.
+    if constexpr (NDIM == 3 && TX == 32 && TY == 8 && !NOMASK) {
+        if (LSM_BAND_PATCH && a.mask) { tx = 8 * (tid >> 6) + (tid & 7); ty = (tid & 63) >> 3; }
+    }
     const int bx0 = tbx * TX, by0 = HAS_Y ? tby * TY : 0;
     const int gx = bx0 + tx, gy = by0 + ty;
     const int nx = a.n[0], ny = HAS_Y ? a.n[1] : 1;
