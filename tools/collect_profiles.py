@@ -48,7 +48,8 @@ try:
     terms = json.load(open(os.path.join(src, "terms.json")))[0]
 except Exception:   # noqa: BLE001
     terms = {}
-names = {"<3, 1, 0, 0, 0": "upwind adv (const)", "<3, 0, 1, 0, 0": "NormalMotion (const)", "<3, 0, 0, 1, 0": "Curvature (const)",
+names = {"stage_kernel2<1, 0, 0, 0": "upwind adv (const)", "stage_kernel2<0, 1, 0, 0": "NormalMotion (const)", "stage_kernel2<0, 0, 0, 2": "Eikonal (current sign)",
+         "<3, 1, 0, 0, 0": "upwind adv (const)", "<3, 0, 1, 0, 0": "NormalMotion (const)", "<3, 0, 0, 1, 0": "Curvature (const)",
          "<3, 0, 0, 0, 2": "Eikonal (current sign)", "<3, 0, 1, 1, 0": "NormalMotion + Curvature",
          "<3, 2, 0, 1, 0": "WENO5 adv (rotation) + Curvature", "<3, 2, 0, 0, 2": "WENO5 adv (vortex) + Eikonal"}
 alg = 512 ** 3 * 16 / 1e9
@@ -59,9 +60,10 @@ for k in sorted(F):
     key = next((n for n in names if n in k), None)
     if key is None or k not in W:
         continue
-    rd, wr = 2 * F[k] * 1024 / 1e9, W[k] * 1024 / 1e9
+    pair = "stage_kernel2" in k          # own nodes by 16-byte accesses, halo by 8-byte ones: the factor 2 calibrated on 8-byte reads is applied unchanged
+    rd, wr = 2 * F[k] * 1024 / 1e9, W[k] * 1024 / 1e9     # (with factor 1 the reads would come out below the algorithmic 1.07 GB)
     ms = terms.get(names[key], {}).get("stage_ms")
-    tile = "64x8" if ", 64, 8, " in k else "32x8"
+    tile = "128x8, two nodes per thread" if pair else ("64x8" if ", 64, 8, " in k else "32x8")
     lines.append("  %-44s %8.2f %8.2f %8.2f %8.2f %22s %9s" % (names[key] + " [" + tile + "]", rd, wr, rd + wr, (rd + wr) / alg,
                                                               "%.3f" % ms if ms else "-", "%.2f" % ((rd + wr) / ms) if ms else "-"))
 open(os.path.join(dst, "terms_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
