@@ -175,6 +175,11 @@ def run(which, steps=None, warmup=None):
                            "kernel": "stage_kernel<3,NormalMotion,Curvature>", "avg_launch_ms": round(r["stage_ms"], 4)}
     else:
         out["value"], out["ms_per_step"] = r["float32"]["Mcells_s_grid"], r["float32"]["ms_per_step"]
+        # algorithmic bytes of a band step (SURVEY.md §8d with s = 4): 8 s = 32 B per ACTIVE node per RK3 step
+        a = r["float32"]["active_nodes"] * 32.0 / (r["float32"]["ms_per_step"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "bound_actual": "latency / instruction issue of sparse tiles (DESIGN.md §7.1)", "achieved": round(a, 1), "peak": 8000.0,
+                           "unit": "GB/s", "frac": round(a / 8000.0, 4), "traffic": None,
+                           "note": "32 B per active node per RK3 step; the whole step (three stages, three halo fills, update_band!, Δt) is timed"}
     return out
 
 
