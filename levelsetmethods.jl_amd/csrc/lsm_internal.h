@@ -224,6 +224,8 @@ struct Combo {
     int curv;  // 0/1
     int eik;   // 0 none, 1 frozen S0, 2 current sign
 };
+// stage_brick.hip: the band stage with one lane per band node; -1 = not its case (the tiled kernels take the launch)
+int launch_stage_brick(const Combo& c, const StageArgs& a, hipStream_t s);
 
 // launchers implemented in stage_{fast,strict}.hip; return 0 if the combo is instantiated
 int launch_stage_fast(int ndim, const Combo& c, const StageArgs& a, hipStream_t s);

@@ -1,0 +1,209 @@
+// stage_brick.h — the RK stage of a narrow band, brick by brick (round 3).
+//
+// stage_tile (stage_kernel.h) marches a 32 x 8 tile through the planes of a listed brick with one thread per NODE OF THE
+// TILE: a wave computes a plane when any of its 64 nodes belongs to the band, every lane at full price.  On a band that is
+// a shell a few nodes thick, 25 % of the lanes that execute the stencil arithmetic are band nodes (profiles/r3/band_step:
+// 41 M vector instructions per 768³ stage against 10 M for the band's 3.6 M nodes), and every plane of every brick pays
+// the march's loads, LDS writes and barrier whether it holds a band node or not.
+//
+// Here a workgroup (512 threads) takes a listed piece and, for every 16 planes (8 for fp64 fields) of it,
+//   1. copies the brick with its halo — (16 + 2G) x (8 + 2G) rows of 40 elements, 16-byte loads from x0 - 4 — into LDS in
+//      the field's storage type,
+//   2. turns the brick's mask bytes into a list of its band nodes (wave scans of the per-thread counts; x fastest),
+//   3. deals the list to its waves 64 nodes at a time: ONE LANE PER BAND NODE.  A lane reads its stencil from the LDS
+//      brick through BrickView — the interface node_update expects of a NodeView, with the march axis as a third LDS
+//      stride — so the arithmetic, and every bit of the result, is stage_tile's.
+// Lanes are idle only in the last batch of a wave.  Plain variants of the FAST build (constant or ROTATION advection
+// coefficient, constant speed / curvature coefficient, one output, terms in slot order) on the aligned layout; everything
+// else stays with stage_tile.  LSM_BAND_BRICKS=0 is the A/B switch.
+#pragma once
+#include "stage_kernel.h"
+
+namespace lsm {
+namespace LSM_NS {
+
+template <class LT>
+struct LdsElems {              // a position in the LDS brick; reads widen exactly to double
+    const LT* p;
+    LSM_DEV double operator[](int i) const { return (double)p[i]; }
+};
+template <int W, int HW, class LT>
+struct BrickView {
+    LdsElems<LT> T0;
+    double c;
+    LSM_DEV double z(int k) const { return T0[k * HW]; }
+    template <int D>
+    LSM_DEV double at(int k) const { return T0[k * (D == 0 ? 1 : (D == 1 ? W : HW))]; }
+    template <int A, int B>
+    LSM_DEV double corner(int sa, int sb) const { return T0[sa * (A == 0 ? 1 : W) + sb * (B == 1 ? W : HW)]; }
+};
+
+struct BrickCfg {
+    static constexpr int TX = 32, TY = 8, NT = 512, XL = 4;     // XL: elements in front of the tile's first node (>= G, rows start 16-byte aligned)
+    static constexpr int W = TX + 2 * XL;
+};
+
+template <int ADV, int NM, int CURV, int EIK, class ST, int AK>
+__global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) {
+    constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, NT = BrickCfg::NT, XL = BrickCfg::XL, W = BrickCfg::W;
+    constexpr int G = halo_of(ADV, NM, CURV, EIK);
+    constexpr int BZ = sizeof(ST) == 4 ? 16 : 8;          // planes per pass
+    constexpr int SEG = 16 / (int)sizeof(ST), NSEG = W / SEG;
+    constexpr int H = TY + 2 * G, HW = H * W, D = BZ + 2 * G;
+    constexpr int NV4 = D * H * NSEG, LPT = (NV4 + NT - 1) / NT;
+    constexpr int BPT = TX * TY * BZ / NT;                // mask bytes per thread: 8 or 4
+    static_assert(XL >= G && XL % SEG == 0 && W % SEG == 0 && (BPT == 8 || BPT == 4), "");
+    __shared__ lsm_v4u vbrick[NV4];
+    __shared__ unsigned short nodes[TX * TY * BZ];
+    __shared__ int wsum[NT / 64];
+    const ST* brick = reinterpret_cast<const ST*>(vbrick);
+
+    const TileOrder ord(a);
+    unsigned tile_id;
+    bool tail;
+    if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail)) return;
+    const unsigned ent = (unsigned)a.tile_list[tile_id];
+    tile_id = ent & 0x00ffffffu;
+    const int nbricks = (int)(ent >> 24) + 1;
+    const unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1], tbm = tile_id / (a.nb[0] * a.nb[1]);
+    const int bx0 = tbx * TX, by0 = tby * TY;
+    const int nx = a.n[0], ny = a.n[1], nm = a.n[2];
+    const long long sy = a.s1, sm = a.s2;
+    const int m0 = a.mb + (int)tbm * a.mc;
+    const int m1 = m0 + a.mc * nbricks < a.me ? m0 + a.mc * nbricks : a.me;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // what does not change from pass to pass: the thread's segments of the brick copy, its piece of a mask row
+    unsigned goff[LPT];
+#pragma unroll
+    for (int k = 0; k < LPT; ++k) {
+        const int i = tid + k * NT, row = i / NSEG, seg = i - row * NSEG, yr = row % H;
+        int Y = by0 - G + yr;
+        Y = Y > ny + G - 1 ? ny + G - 1 : Y;
+        const int X0 = bx0 - XL + seg * SEG;
+        // element offset from the pass's corner (bx0 - XL, by0 - G, zb - G), without the plane part (clamped per pass)
+        goff[k] = (unsigned)((Y - (by0 - G)) * (int)sy + seg * SEG);
+        if (i >= NV4 || X0 > nx + G - 1) goff[k] = 0xffffffffu;     // nothing a band node reads: zeros, no access
+    }
+    // NT threads x BPT mask bytes = the brick's 32 x 8 x BZ nodes
+    const int mrow = tid / (TX / BPT), mq = tid % (TX / BPT), mzr = mrow / TY, myr = mrow % TY;
+
+    for (int zb = m0; zb < m1; zb += BZ) {
+        const int nz = m1 - zb < BZ ? m1 - zb : BZ;
+        __syncthreads();                      // the previous pass has read its last stencil
+        // ---- 1. the brick with its halo
+        {
+            const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+            lsm_v4u v[LPT];
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                const int i = tid + k * NT, zr = i / (NSEG * H);
+                int Z = zb - G + zr;
+                Z = Z > nm + G - 1 ? nm + G - 1 : Z;
+                const unsigned off = goff[k] == 0xffffffffu ? LSM_OOB_OFFSET
+                                                            : (unsigned)sizeof(ST) * (goff[k] + (unsigned)(Z - (zb - G)) * (unsigned)sm);
+                v[k] = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(cb), off, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < LPT; ++k)
+                if (tid + k * NT < NV4) vbrick[tid + k * NT] = v[k];
+        }
+        // ---- 2. the band nodes of the brick, x fastest
+        int N;
+        {
+            const unsigned char* mb_ = uniform_ptr(a.mask + (a.origin + (long long)zb * sm + (long long)by0 * sy + bx0));
+            const bool rv = mzr < nz && by0 + myr < ny;
+            const unsigned moff = rv ? (unsigned)mzr * (unsigned)sm + (unsigned)myr * (unsigned)sy + (unsigned)(mq * BPT) : LSM_OOB_OFFSET;
+            unsigned long long mbytes;
+            if constexpr (BPT == 8) mbytes = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(mb_), moff, 0, 0));
+            else mbytes = __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(mb_), moff, 0, 0);
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j)
+                if (((mbytes >> (8 * j)) & 0xffull) != 0 && bx0 + mq * BPT + j < nx) bits |= 1u << j;
+            const int cnt = __builtin_popcount(bits);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();                  // also: the brick is in LDS
+            int base = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) {
+                const int s = wsum[w];
+                base += w < wv ? s : 0;
+                tot += s;
+            }
+            N = tot;
+            int pos = base + incl - cnt;
+            const unsigned code0 = ((unsigned)mzr << 8) | ((unsigned)myr << 5) | (unsigned)(mq * BPT);
+            while (bits) {
+                const int j = __builtin_ctz(bits);
+                bits &= bits - 1;
+                nodes[pos++] = (unsigned short)(code0 + j);
+            }
+            __syncthreads();
+        }
+        // ---- 3. one lane per band node
+        const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
+        PlaneTab pt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pt.adv[k] = pt.nm[k] = pt.curv[k] = 1.0;               // no SEPARABLE coefficients here
+        for (int b0 = wv * 64; b0 < N; b0 += NT) {
+            const int i = b0 + lane;
+            const bool on = i < N;
+            const unsigned code = nodes[on ? i : N - 1];
+            const int x = code & 31, y = (code >> 5) & 7, z = code >> 8;
+            const int l = ((z + G) * H + (y + G)) * W + x + XL;
+            const unsigned eo = (unsigned)z * (unsigned)sm + (unsigned)y * (unsigned)sy + (unsigned)x;
+            const NodeIO io{po, (unsigned)sizeof(ST) * eo, 8u * eo, zb + z + a.goff[2]};
+            double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
+            const int gi0 = bx0 + x + a.goff[0], gi1 = by0 + y + a.goff[1];
+            if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, gi0, gi1, pre_adv);
+            if constexpr (NM != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.nm, a, gi0, gi1, pre_nm);
+            if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.curv, a, gi0, gi1, pre_curv);
+            NodeOps op;
+            node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
+            const BrickView<W, HW, ST> nv{{brick + l}, (double)brick[l]};
+            double r1 = 0.0, r2 = 0.0;
+            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nv, op, r1, r2);
+            node_store<ST, true>(a, io, on, r1, r2);
+        }
+    }
+}
+
+// 0 = launched, -1 = not a case for the brick kernel (the caller goes on to stage_tile)
+template <int ADV, int NM, int CURV, int EIK>
+int launch_bricks(const StageArgs& a, hipStream_t s) {
+    const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
+    if (env && env[0] == '0') return -1;
+    if (!a.mask || !a.tile_list || a.mc <= 0 || a.ntile_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return -1;
+    if ((NM && a.nm.kind != LSM_COEFF_CONST) || (CURV && a.curv.kind != LSM_COEFF_CONST)) return -1;
+    const int ak = ADV ? a.adv.kind : (int)LSM_COEFF_CONST;
+    if (ak != LSM_COEFF_CONST && ak != LSM_COEFF_ROTATION) return -1;
+    if (a.me <= a.mb || getenv("LSM_STAGE_GENERIC")) return -1;
+    // 16-byte rows: the aligned layout (lsm_create), 16-byte aligned arrays; 32-bit byte offsets inside a pass
+    const long long seg = a.f32 ? 4 : 2, lead = a.origin - LSM_GHOST * a.s2 - LSM_GHOST * a.s1;
+    if (lead < BrickCfg::XL || lead % seg || a.s1 % 8 || a.s2 % 8 || a.origin % 8) return -1;
+    if (((unsigned long long)a.psi | (unsigned long long)a.mask) % 16ull) return -1;
+    if ((long long)(16 + 2 * LSM_GHOST + 1) * a.s2 * 8 >= (1ll << 31)) return -1;
+    StageArgs b = a;
+    b.nb[0] = (a.n[0] + BrickCfg::TX - 1) / BrickCfg::TX;
+    b.nb[1] = (a.n[1] + BrickCfg::TY - 1) / BrickCfg::TY;
+    b.nb[2] = (a.me - a.mb + a.mc - 1) / a.mc;
+    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0; b.yfast = 0;
+    const dim3 grid(((a.ntile_list + 7u) / 8u) * 8u), block(BrickCfg::NT);
+#define LSM_BRICK(STT, AKK) hipLaunchKernelGGL((brick_kernel<ADV, NM, CURV, EIK, STT, AKK>), grid, block, 0, s, b)
+    if constexpr (ADV != 0) {
+        if (ak == LSM_COEFF_ROTATION) { if (b.f32) LSM_BRICK(float, LSM_COEFF_ROTATION); else LSM_BRICK(double, LSM_COEFF_ROTATION); return 0; }
+    }
+    if (b.f32) LSM_BRICK(float, LSM_COEFF_CONST); else LSM_BRICK(double, LSM_COEFF_CONST);
+#undef LSM_BRICK
+    return 0;
+}
+
+}  // namespace LSM_NS
+}  // namespace lsm

@@ -1382,6 +1382,12 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
 
 template <int NDIM>
 int launch_ndim(const Combo& c, const StageArgs& a, hipStream_t s) {
+#if !LSM_STRICT
+    // narrow band on a compact piece list: one lane per band node (stage_brick.h) where that kernel applies
+    if constexpr (NDIM == 3) {
+        if (a.mask && a.tile_list && launch_stage_brick(c, a, s) == 0) return 0;
+    }
+#endif
 #define LSM_X(ADV, NM, CURV, EIK)                                         \
     if (c.adv == ADV && c.nm == NM && c.curv == CURV && c.eik == EIK) { \
         launch_one<NDIM, ADV, NM, CURV, EIK>(a, s);                       \

@@ -303,6 +303,39 @@ def test_fallback_band_paths_give_the_same_band_and_values(lsm, monkeypatch, env
     assert np.array_equal(a.values()[m], b.values()[m])
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", ["rot_weno_curv", "const_upwind", "nm", "weno_nm", "eik", "weno_eik", "nm_curv"])
+def test_brick_stage_equals_the_tiled_band_stage_bitwise(lsm, monkeypatch, case, dtype):
+    """The band stage with one lane per band node (csrc/stage_brick.h, the default for the plain FAST cases) against the tiled
+    march over the same pieces (LSM_BAND_BRICKS=0): the same node_update on the same values, so every band value must agree
+    bitwise after several RK3 steps — on a band that runs into the faces of a grid that is no multiple of the 32 x 8 x 16 brick."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (70, 37, 45))
+    phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.3) ** 2 + (x[1] + 0.2) ** 2 + (x[2] - 0.25) ** 2) - 0.8, grid, dtype=np.dtype(dtype))
+    terms = {
+        "rot_weno_curv": (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02)),
+        "const_upwind": (lsm.AdvectionTerm((0.6, -0.8, 0.3), lsm.Upwind()),),
+        "nm": (lsm.NormalMotionTerm(0.7),),
+        "weno_nm": (lsm.AdvectionTerm((-0.5, 0.4, 0.9), lsm.WENO5()), lsm.NormalMotionTerm(-0.3)),
+        "eik": (lsm.EikonalReinitializationTerm(),),
+        "weno_eik": (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
+        "nm_curv": (lsm.NormalMotionTerm(0.4), lsm.CurvatureTerm(-0.03)),
+    }[case]
+    mk = lambda: lsm.LevelSetEquation(terms=terms, ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2),
+                                      integrator=lsm.RK3())
+    out = []
+    for bricks in ("1", "0"):
+        monkeypatch.setenv("LSM_BAND_BRICKS", bricks)
+        eq = mk()
+        lsm.integrate_(eq, 0.02)
+        st = eq.current_state()
+        out.append((st.active_mask(), st.values()))
+    monkeypatch.delenv("LSM_BAND_BRICKS")
+    (ma, va), (mb, vb) = out
+    assert ma.sum() > 5000 and np.array_equal(ma, mb)
+    assert ma[0].any() or ma[:, 0].any() or ma[:, :, -1].any()          # the band reaches a face
+    assert np.array_equal(va[ma], vb[mb])
+
+
 # ---- the reference's band integration tests with their reinitialize! hooks (test/test-levelsetequation.jl:144-222)
 
 def _reinit(lsm):
