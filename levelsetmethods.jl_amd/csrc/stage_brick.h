@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) 
     constexpr int BZ = sizeof(ST) == 4 ? 16 : 8;          // planes per pass
     constexpr int SEG = 16 / (int)sizeof(ST), NSEG = W / SEG;
     constexpr int H = TY + 2 * G, HW = H * W, D = BZ + 2 * G;
-    constexpr int NV4 = D * H * NSEG, LPT = (NV4 + NT - 1) / NT;
+    constexpr int NV4 = D * H * NSEG;
     constexpr int BPT = TX * TY * BZ / NT;                // mask bytes per thread: 8 or 4
     static_assert(XL >= G && XL % SEG == 0 && W % SEG == 0 && (BPT == 8 || BPT == 4), "");
     __shared__ lsm_v4u vbrick[NV4];
@@ -73,17 +73,18 @@ __global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) 
     const int m1 = m0 + a.mc * nbricks < a.me ? m0 + a.mc * nbricks : a.me;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    // what does not change from pass to pass: the thread's segments of the brick copy, its piece of a mask row
-    unsigned goff[LPT];
-#pragma unroll
-    for (int k = 0; k < LPT; ++k) {
-        const int i = tid + k * NT, row = i / NSEG, seg = i - row * NSEG, yr = row % H;
-        int Y = by0 - G + yr;
+    // what does not change from pass to pass.  The brick copy goes plane by plane: PSEG 16-byte segments per plane, PPI planes
+    // per round of the workgroup — one division per thread instead of two per segment
+    constexpr int PSEG = H * NSEG, PPI = NT / PSEG, NIT = (D + PPI - 1) / PPI;
+    static_assert(PPI >= 1, "");
+    const int cpl = tid / PSEG, cidx = tid - cpl * PSEG, cyr = cidx / NSEG, cseg = cidx - cyr * NSEG;
+    unsigned goff0;
+    {
+        int Y = by0 - G + cyr;
         Y = Y > ny + G - 1 ? ny + G - 1 : Y;
-        const int X0 = bx0 - XL + seg * SEG;
         // element offset from the pass's corner (bx0 - XL, by0 - G, zb - G), without the plane part (clamped per pass)
-        goff[k] = (unsigned)((Y - (by0 - G)) * (int)sy + seg * SEG);
-        if (i >= NV4 || X0 > nx + G - 1) goff[k] = 0xffffffffu;     // nothing a band node reads: zeros, no access
+        goff0 = (unsigned)((Y - (by0 - G)) * (int)sy + cseg * SEG);
+        if (cpl >= PPI || bx0 - XL + cseg * SEG > nx + G - 1) goff0 = 0xffffffffu;     // nothing a band node reads: zeros, no access
     }
     // NT threads x BPT mask bytes = the brick's 32 x 8 x BZ nodes
     const int mrow = tid / (TX / BPT), mq = tid % (TX / BPT), mzr = mrow / TY, myr = mrow % TY;
@@ -91,32 +92,32 @@ __global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) 
     for (int zb = m0; zb < m1; zb += BZ) {
         const int nz = m1 - zb < BZ ? m1 - zb : BZ;
         __syncthreads();                      // the previous pass has read its last stencil
-        // ---- 1. the brick with its halo
-        {
-            const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
-            lsm_v4u v[LPT];
-#pragma unroll
-            for (int k = 0; k < LPT; ++k) {
-                const int i = tid + k * NT, zr = i / (NSEG * H);
-                int Z = zb - G + zr;
-                Z = Z > nm + G - 1 ? nm + G - 1 : Z;
-                const unsigned off = goff[k] == 0xffffffffu ? LSM_OOB_OFFSET
-                                                            : (unsigned)sizeof(ST) * (goff[k] + (unsigned)(Z - (zb - G)) * (unsigned)sm);
-                v[k] = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(cb), off, 0, 0));
-            }
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if (tid + k * NT < NV4) vbrick[tid + k * NT] = v[k];
-        }
-        // ---- 2. the band nodes of the brick, x fastest
-        int N;
+        // ---- 1. loads: the mask bytes first (vector loads return in order: the node list is built while the brick is in flight),
+        //         then the brick with its halo
+        unsigned long long mbytes;
         {
             const unsigned char* mb_ = uniform_ptr(a.mask + (a.origin + (long long)zb * sm + (long long)by0 * sy + bx0));
             const bool rv = mzr < nz && by0 + myr < ny;
             const unsigned moff = rv ? (unsigned)mzr * (unsigned)sm + (unsigned)myr * (unsigned)sy + (unsigned)(mq * BPT) : LSM_OOB_OFFSET;
-            unsigned long long mbytes;
             if constexpr (BPT == 8) mbytes = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(mb_), moff, 0, 0));
             else mbytes = __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(mb_), moff, 0, 0);
+        }
+        lsm_v4u v[NIT];
+        {
+            const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int zr = k * PPI + cpl;
+                int Z = zb - G + zr;
+                Z = Z > nm + G - 1 ? nm + G - 1 : Z;
+                const unsigned off = (goff0 == 0xffffffffu || zr >= D) ? LSM_OOB_OFFSET
+                                                                       : (unsigned)sizeof(ST) * (goff0 + (unsigned)(Z - (zb - G)) * (unsigned)sm);
+                v[k] = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(cb), off, 0, 0));
+            }
+        }
+        // ---- 2. the band nodes of the brick, x fastest
+        int N;
+        {
             unsigned bits = 0;
 #pragma unroll
             for (int j = 0; j < BPT; ++j)
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) 
                 if (lane >= d) incl += t;
             }
             if (lane == 63) wsum[wv] = incl;
-            __syncthreads();                  // also: the brick is in LDS
+            __syncthreads();
             int base = 0, tot = 0;
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) {
@@ -145,8 +146,11 @@ __global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) 
                 bits &= bits - 1;
                 nodes[pos++] = (unsigned short)(code0 + j);
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (cpl < PPI && k * PPI + cpl < D) vbrick[(k * PPI + cpl) * PSEG + cidx] = v[k];
+        __syncthreads();
         // ---- 3. one lane per band node
         const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
         PlaneTab pt;
