@@ -363,6 +363,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     for (int d = 1; d < h->grid.ndim; ++d) a.uniform_h = a.uniform_h && h->inv_h2[d] == h->inv_h2[0];
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
+    if (h->band_list) { a.brick_list = h->d_act_list; a.nbrick_list = h->nact; }
     a.f32 = is_f32(h);
     a.tail_ctr = nullptr; a.tail_wgs = 0;
     a.tail_ring = h->d_tail_ctr;          // stage_impl withdraws it from launches on a caller's stream

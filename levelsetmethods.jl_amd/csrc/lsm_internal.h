@@ -93,6 +93,8 @@ struct StageArgs {
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)
     unsigned ntile_list;
+    const int* brick_list;             // narrow band: the active tiles, one brick of `mc` planes each (stage_brick.h; NULL = none)
+    unsigned nbrick_list;
     int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
     unsigned long long* stamp;         // diagnostic build (-DLSM_STAMP, `make stamp`): per-workgroup {Δs_memtime, Δs_memrealtime} of the plane loop
 };

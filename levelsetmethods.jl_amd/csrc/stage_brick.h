@@ -6,7 +6,7 @@
 // 41 M vector instructions per 768³ stage against 10 M for the band's 3.6 M nodes), and every plane of every brick pays
 // the march's loads, LDS writes and barrier whether it holds a band node or not.
 //
-// Here a workgroup (512 threads) takes a listed piece and, for every 16 planes (8 for fp64 fields) of it,
+// Here a workgroup takes 8 (or 16) planes of a brick of the band's active-tile list and
 //   1. copies the brick with its halo — (16 + 2G) x (8 + 2G) rows of 40 elements, 16-byte loads from x0 - 4 — into LDS in
 //      the field's storage type,
 //   2. turns the brick's mask bytes into a list of its band nodes (wave scans of the per-thread counts; x fastest),
@@ -39,143 +39,134 @@ struct BrickView {
 };
 
 struct BrickCfg {
-    static constexpr int TX = 32, TY = 8, NT = 512, XL = 4;     // XL: elements in front of the tile's first node (>= G, rows start 16-byte aligned)
+    static constexpr int TX = 32, TY = 8, XL = 4;     // XL: elements in front of the tile's first node (>= G, rows start 16-byte aligned)
     static constexpr int W = TX + 2 * XL;
 };
 
-template <int ADV, int NM, int CURV, int EIK, class ST, int AK>
-__global__ void __launch_bounds__(BrickCfg::NT) brick_kernel(const StageArgs a) {
-    constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, NT = BrickCfg::NT, XL = BrickCfg::XL, W = BrickCfg::W;
+// NT threads take BZ planes of a listed brick (StageArgs::brick_list: the band's active tiles, one brick of `mc` planes each;
+// ceil(mc / BZ) workgroups per brick).  float fields: 256 threads x 8 planes — 35 KB of LDS, four workgroups per CU in
+// different phases (copy / list / arithmetic) — measured against 512 x 16 (57 KB, two per CU).
+template <int ADV, int NM, int CURV, int EIK, class ST, int AK, int NT, int BZ>
+__global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsigned sub_per) {
+    constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, XL = BrickCfg::XL, W = BrickCfg::W;
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
-    constexpr int BZ = sizeof(ST) == 4 ? 16 : 8;          // planes per pass
     constexpr int SEG = 16 / (int)sizeof(ST), NSEG = W / SEG;
     constexpr int H = TY + 2 * G, HW = H * W, D = BZ + 2 * G;
-    constexpr int NV4 = D * H * NSEG;
+    constexpr int NROW = D * H, NV4 = NROW * NSEG;
     constexpr int BPT = TX * TY * BZ / NT;                // mask bytes per thread: 8 or 4
-    static_assert(XL >= G && XL % SEG == 0 && W % SEG == 0 && (BPT == 8 || BPT == 4), "");
+    static_assert(XL >= G && XL % SEG == 0 && W % SEG == 0 && (BPT == 8 || BPT == 4) && NT % 64 == 0, "");
     __shared__ lsm_v4u vbrick[NV4];
     __shared__ unsigned short nodes[TX * TY * BZ];
     __shared__ int wsum[NT / 64];
     const ST* brick = reinterpret_cast<const ST*>(vbrick);
 
-    const TileOrder ord(a);
-    unsigned tile_id;
-    bool tail;
-    if (!ord.entry(blockIdx.x % 8u, blockIdx.x / 8u, tile_id, tail)) return;
-    const unsigned ent = (unsigned)a.tile_list[tile_id];
-    tile_id = ent & 0x00ffffffu;
-    const int nbricks = (int)(ent >> 24) + 1;
+    // the launch's workgroups in list order, dealt to the XCDs in contiguous ranges (TileOrder): the BZ-plane parts of a brick
+    // and the bricks of a neighbourhood meet in one L2
+    const unsigned nwg = a.nbrick_list * sub_per, per = (nwg + 7u) / 8u;
+    const unsigned wg = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    if (blockIdx.x / 8u >= per || wg >= nwg) return;
+    const unsigned tile_id = (unsigned)a.brick_list[wg / sub_per], sub = wg % sub_per;
     const unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1], tbm = tile_id / (a.nb[0] * a.nb[1]);
     const int bx0 = tbx * TX, by0 = tby * TY;
     const int nx = a.n[0], ny = a.n[1], nm = a.n[2];
     const long long sy = a.s1, sm = a.s2;
     const int m0 = a.mb + (int)tbm * a.mc;
-    const int m1 = m0 + a.mc * nbricks < a.me ? m0 + a.mc * nbricks : a.me;
+    const int m1 = m0 + a.mc < a.me ? m0 + a.mc : a.me;
+    const int zb = m0 + (int)sub * BZ;
+    if (zb >= m1) return;
+    const int nz = m1 - zb < BZ ? m1 - zb : BZ;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    // what does not change from pass to pass.  The brick copy goes plane by plane: PSEG 16-byte segments per plane, PPI planes
-    // per round of the workgroup — one division per thread instead of two per segment
-    constexpr int PSEG = H * NSEG, PPI = NT / PSEG, NIT = (D + PPI - 1) / PPI;
-    static_assert(PPI >= 1, "");
-    const int cpl = tid / PSEG, cidx = tid - cpl * PSEG, cyr = cidx / NSEG, cseg = cidx - cyr * NSEG;
-    unsigned goff0;
+    // ---- 1. loads: the mask bytes first (vector loads return in order: the node list is built while the brick is in flight),
+    //         then the brick with its halo, row by row: RPI rows of NSEG 16-byte segments per round of the workgroup
+    unsigned long long mbytes;
+    const int mrow = tid / (TX / BPT), mq = tid % (TX / BPT), mzr = mrow / TY, myr = mrow % TY;   // NT x BPT mask bytes = the 32 x 8 x BZ nodes
     {
-        int Y = by0 - G + cyr;
-        Y = Y > ny + G - 1 ? ny + G - 1 : Y;
-        // element offset from the pass's corner (bx0 - XL, by0 - G, zb - G), without the plane part (clamped per pass)
-        goff0 = (unsigned)((Y - (by0 - G)) * (int)sy + cseg * SEG);
-        if (cpl >= PPI || bx0 - XL + cseg * SEG > nx + G - 1) goff0 = 0xffffffffu;     // nothing a band node reads: zeros, no access
+        const unsigned char* mb_ = uniform_ptr(a.mask + (a.origin + (long long)zb * sm + (long long)by0 * sy + bx0));
+        const bool rv = mzr < nz && by0 + myr < ny;
+        const unsigned moff = rv ? (unsigned)mzr * (unsigned)sm + (unsigned)myr * (unsigned)sy + (unsigned)(mq * BPT) : LSM_OOB_OFFSET;
+        if constexpr (BPT == 8) mbytes = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(mb_), moff, 0, 0));
+        else mbytes = __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(mb_), moff, 0, 0);
     }
-    // NT threads x BPT mask bytes = the brick's 32 x 8 x BZ nodes
-    const int mrow = tid / (TX / BPT), mq = tid % (TX / BPT), mzr = mrow / TY, myr = mrow % TY;
-
-    for (int zb = m0; zb < m1; zb += BZ) {
-        const int nz = m1 - zb < BZ ? m1 - zb : BZ;
-        __syncthreads();                      // the previous pass has read its last stencil
-        // ---- 1. loads: the mask bytes first (vector loads return in order: the node list is built while the brick is in flight),
-        //         then the brick with its halo
-        unsigned long long mbytes;
-        {
-            const unsigned char* mb_ = uniform_ptr(a.mask + (a.origin + (long long)zb * sm + (long long)by0 * sy + bx0));
-            const bool rv = mzr < nz && by0 + myr < ny;
-            const unsigned moff = rv ? (unsigned)mzr * (unsigned)sm + (unsigned)myr * (unsigned)sy + (unsigned)(mq * BPT) : LSM_OOB_OFFSET;
-            if constexpr (BPT == 8) mbytes = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(mb_), moff, 0, 0));
-            else mbytes = __builtin_amdgcn_raw_buffer_load_b32(plane_rsrc(mb_), moff, 0, 0);
+    constexpr int RPI = NT / NSEG, NIT = (NROW + RPI - 1) / RPI, QZ = RPI / H, RY = RPI % H;
+    lsm_v4u v[NIT];
+    const int crow = tid / NSEG, cseg = tid - crow * NSEG;
+    {
+        const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+        const bool cv = crow < RPI && bx0 - XL + cseg * SEG <= nx + G - 1;     // beyond: nothing a band node reads (zeros, no access)
+        int zr = crow / H, yr = crow - zr * H;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int Y = by0 - G + yr, Z = zb - G + zr;
+            Y = Y > ny + G - 1 ? ny + G - 1 : Y;
+            Z = Z > nm + G - 1 ? nm + G - 1 : Z;
+            const unsigned eo = (unsigned)(Z - (zb - G)) * (unsigned)sm + (unsigned)(Y - (by0 - G)) * (unsigned)sy + (unsigned)(cseg * SEG);
+            const unsigned off = (cv && zr < D) ? (unsigned)sizeof(ST) * eo : LSM_OOB_OFFSET;
+            v[k] = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(cb), off, 0, 0));
+            yr += RY; zr += QZ;
+            if (yr >= H) { yr -= H; ++zr; }
         }
-        lsm_v4u v[NIT];
-        {
-            const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+    }
+    // ---- 2. the band nodes of the brick, x fastest
+    int N;
+    {
+        unsigned bits = 0;
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int zr = k * PPI + cpl;
-                int Z = zb - G + zr;
-                Z = Z > nm + G - 1 ? nm + G - 1 : Z;
-                const unsigned off = (goff0 == 0xffffffffu || zr >= D) ? LSM_OOB_OFFSET
-                                                                       : (unsigned)sizeof(ST) * (goff0 + (unsigned)(Z - (zb - G)) * (unsigned)sm);
-                v[k] = __builtin_bit_cast(lsm_v4u, __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc(cb), off, 0, 0));
-            }
+        for (int j = 0; j < BPT; ++j)
+            if (((mbytes >> (8 * j)) & 0xffull) != 0 && bx0 + mq * BPT + j < nx) bits |= 1u << j;
+        const int cnt = __builtin_popcount(bits);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
         }
-        // ---- 2. the band nodes of the brick, x fastest
-        int N;
-        {
-            unsigned bits = 0;
-#pragma unroll
-            for (int j = 0; j < BPT; ++j)
-                if (((mbytes >> (8 * j)) & 0xffull) != 0 && bx0 + mq * BPT + j < nx) bits |= 1u << j;
-            const int cnt = __builtin_popcount(bits);
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            if (lane == 63) wsum[wv] = incl;
-            __syncthreads();
-            int base = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < NT / 64; ++w) {
-                const int s = wsum[w];
-                base += w < wv ? s : 0;
-                tot += s;
-            }
-            N = tot;
-            int pos = base + incl - cnt;
-            const unsigned code0 = ((unsigned)mzr << 8) | ((unsigned)myr << 5) | (unsigned)(mq * BPT);
-            while (bits) {
-                const int j = __builtin_ctz(bits);
-                bits &= bits - 1;
-                nodes[pos++] = (unsigned short)(code0 + j);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k)
-            if (cpl < PPI && k * PPI + cpl < D) vbrick[(k * PPI + cpl) * PSEG + cidx] = v[k];
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        // ---- 3. one lane per band node
-        const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
-        PlaneTab pt;
+        int base = 0, tot = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pt.adv[k] = pt.nm[k] = pt.curv[k] = 1.0;               // no SEPARABLE coefficients here
-        for (int b0 = wv * 64; b0 < N; b0 += NT) {
-            const int i = b0 + lane;
-            const bool on = i < N;
-            const unsigned code = nodes[on ? i : N - 1];
-            const int x = code & 31, y = (code >> 5) & 7, z = code >> 8;
-            const int l = ((z + G) * H + (y + G)) * W + x + XL;
-            const unsigned eo = (unsigned)z * (unsigned)sm + (unsigned)y * (unsigned)sy + (unsigned)x;
-            const NodeIO io{po, (unsigned)sizeof(ST) * eo, 8u * eo, zb + z + a.goff[2]};
-            double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
-            const int gi0 = bx0 + x + a.goff[0], gi1 = by0 + y + a.goff[1];
-            if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, gi0, gi1, pre_adv);
-            if constexpr (NM != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.nm, a, gi0, gi1, pre_nm);
-            if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.curv, a, gi0, gi1, pre_curv);
-            NodeOps op;
-            node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
-            const BrickView<W, HW, ST> nv{{brick + l}, (double)brick[l]};
-            double r1 = 0.0, r2 = 0.0;
-            node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nv, op, r1, r2);
-            node_store<ST, true>(a, io, on, r1, r2);
+        for (int w = 0; w < NT / 64; ++w) {
+            const int s = wsum[w];
+            base += w < wv ? s : 0;
+            tot += s;
         }
+        N = tot;
+        int pos = base + incl - cnt;
+        const unsigned code0 = ((unsigned)mzr << 8) | ((unsigned)myr << 5) | (unsigned)(mq * BPT);
+        while (bits) {
+            const int j = __builtin_ctz(bits);
+            bits &= bits - 1;
+            nodes[pos++] = (unsigned short)(code0 + j);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+        if (crow < RPI && crow + k * RPI < NROW) vbrick[(crow + k * RPI) * NSEG + cseg] = v[k];
+    __syncthreads();
+    // ---- 3. one lane per band node
+    const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
+    PlaneTab pt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pt.adv[k] = pt.nm[k] = pt.curv[k] = 1.0;               // no SEPARABLE coefficients here
+    for (int b0 = wv * 64; b0 < N; b0 += NT) {
+        const int i = b0 + lane;
+        const bool on = i < N;
+        const unsigned code = nodes[on ? i : N - 1];
+        const int x = code & 31, y = (code >> 5) & 7, z = code >> 8;
+        const int l = ((z + G) * H + (y + G)) * W + x + XL;
+        const unsigned eo = (unsigned)z * (unsigned)sm + (unsigned)y * (unsigned)sy + (unsigned)x;
+        const NodeIO io{po, (unsigned)sizeof(ST) * eo, 8u * eo, zb + z + a.goff[2]};
+        double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
+        const int gi0 = bx0 + x + a.goff[0], gi1 = by0 + y + a.goff[1];
+        if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, gi0, gi1, pre_adv);
+        if constexpr (NM != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.nm, a, gi0, gi1, pre_nm);
+        if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.curv, a, gi0, gi1, pre_curv);
+        NodeOps op;
+        node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
+        const BrickView<W, HW, ST> nv{{brick + l}, (double)brick[l]};
+        double r1 = 0.0, r2 = 0.0;
+        node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nv, op, r1, r2);
+        node_store<ST, true>(a, io, on, r1, r2);
     }
 }
 
@@ -184,7 +175,7 @@ template <int ADV, int NM, int CURV, int EIK>
 int launch_bricks(const StageArgs& a, hipStream_t s) {
     const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
     if (env && env[0] == '0') return -1;
-    if (!a.mask || !a.tile_list || a.mc <= 0 || a.ntile_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return -1;
+    if (!a.mask || !a.brick_list || a.mc <= 0 || a.nbrick_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return -1;
     if ((NM && a.nm.kind != LSM_COEFF_CONST) || (CURV && a.curv.kind != LSM_COEFF_CONST)) return -1;
     const int ak = ADV ? a.adv.kind : (int)LSM_COEFF_CONST;
     if (ak != LSM_COEFF_CONST && ak != LSM_COEFF_ROTATION) return -1;
@@ -199,12 +190,20 @@ int launch_bricks(const StageArgs& a, hipStream_t s) {
     b.nb[1] = (a.n[1] + BrickCfg::TY - 1) / BrickCfg::TY;
     b.nb[2] = (a.me - a.mb + a.mc - 1) / a.mc;
     b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0; b.yfast = 0;
-    const dim3 grid(((a.ntile_list + 7u) / 8u) * 8u), block(BrickCfg::NT);
-#define LSM_BRICK(STT, AKK) hipLaunchKernelGGL((brick_kernel<ADV, NM, CURV, EIK, STT, AKK>), grid, block, 0, s, b)
+    // planes per workgroup and workgroup size (A/B: LSM_BRICK_SHAPE=0 takes 512 threads x 16 planes for float fields)
+    const char* shp = getenv("LSM_BRICK_SHAPE");
+    const bool small = !(shp && shp[0] == '0');
+    const int bz = (b.f32 && !small) ? 16 : 8;
+    const unsigned sub_per = (unsigned)((a.mc + bz - 1) / bz);
+    const unsigned nwg = a.nbrick_list * sub_per;
+    const dim3 grid(((nwg + 7u) / 8u) * 8u);
+#define LSM_BRICK(STT, AKK, NTT, BZZ) hipLaunchKernelGGL((brick_kernel<ADV, NM, CURV, EIK, STT, AKK, NTT, BZZ>), grid, dim3(NTT), 0, s, b, sub_per)
+#define LSM_BRICK_ST(AKK) do { if (!b.f32) LSM_BRICK(double, AKK, 512, 8); else if (small) LSM_BRICK(float, AKK, 256, 8); else LSM_BRICK(float, AKK, 512, 16); } while (0)
     if constexpr (ADV != 0) {
-        if (ak == LSM_COEFF_ROTATION) { if (b.f32) LSM_BRICK(float, LSM_COEFF_ROTATION); else LSM_BRICK(double, LSM_COEFF_ROTATION); return 0; }
+        if (ak == LSM_COEFF_ROTATION) { LSM_BRICK_ST(LSM_COEFF_ROTATION); return 0; }
     }
-    if (b.f32) LSM_BRICK(float, LSM_COEFF_CONST); else LSM_BRICK(double, LSM_COEFF_CONST);
+    LSM_BRICK_ST(LSM_COEFF_CONST);
+#undef LSM_BRICK_ST
 #undef LSM_BRICK
     return 0;
 }

@@ -1385,7 +1385,7 @@ int launch_ndim(const Combo& c, const StageArgs& a, hipStream_t s) {
 #if !LSM_STRICT
     // narrow band on a compact piece list: one lane per band node (stage_brick.h) where that kernel applies
     if constexpr (NDIM == 3) {
-        if (a.mask && a.tile_list && launch_stage_brick(c, a, s) == 0) return 0;
+        if (a.mask && a.brick_list && launch_stage_brick(c, a, s) == 0) return 0;
     }
 #endif
 #define LSM_X(ADV, NM, CURV, EIK)                                         \
