@@ -101,6 +101,13 @@ __global__ void __launch_bounds__(256) k(double* out, unsigned long long* cyc, u
         if constexpr (OP == 19) asm volatile(R8(S19) OPS_D);
 #define S20(n) "v_mul_f64 %" #n ", %" #n ", %" #n "\n"
         if constexpr (OP == 20) asm volatile(R8(S20) OPS_D);
+        // widening a float (the Float32 storage format): is v_cvt_f64_f32 a full-rate instruction?
+#define S21(n) "v_cvt_f64_f32 %" #n ", %8\n"
+        if constexpr (OP == 21)
+            asm volatile(R8(S21) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(ib));
+#define S22(n) "v_cvt_f32_f64 %" #n ", %8\n"
+        if constexpr (OP == 22)
+            asm volatile(R8(S22) : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(b));
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (i0 ^ i1 ^ i2 ^ i3 ^ i4 ^ i5 ^ i6 ^ i7);
@@ -148,6 +155,7 @@ int main(int argc, char** argv) {
         run<7>("v_mov_b32 dpp wave_shr", w, secs); run<8>("v_rcp_f64", w, secs); run<9>("v_rsq_f64", w, secs);
         run<10>("v_pk_fma_f32", w, secs); run<11>("v_fma_f32", w, secs); run<12>("v_add_u32", w, secs);
         run<13>("ds_read_b64 x8", w, secs); run<14>("8 fma_f64 + 4 ds_read", w, secs); run<15>("8 fma_f64 + 8 ds_read", w, secs);
+        run<21>("v_cvt_f64_f32", w, secs); run<22>("v_cvt_f32_f64", w, secs);
         run<16>("8 fma_f64 + 4 ds_write", w, secs); run<17>("4 fma_f64 + 4 mov_b32", w, secs); run<18>("4 fma_f64 + 4 dpp", w, secs);
     }
     for (int w : {1, 2, 6}) { run<0>("v_fma_f64", w, secs); run<5>("v_mov_b32", w, secs); run<14>("8 fma_f64 + 4 ds_read", w, secs); }
