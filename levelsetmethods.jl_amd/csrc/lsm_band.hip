@@ -1239,7 +1239,9 @@ __global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandE
                     c = e[u].d[d] == 0 ? 0u : (src_mask[qp + sdv[d]] ? 1u : (src_mask[qp - sdv[d]] ? 2u : 0u));
                     e[u].d[3] = (signed char)((unsigned char)e[u].d[3] | (c << (2 * d)));
                 }
-                nbv[u][d] = ld_val(src, c == 1u ? qp + sdv[d] : (c == 2u ? qp - sdv[d] : qp), a.f32);
+                // only the slopes the entry uses are fetched (an axis-aligned halo node needs one): the gathers are bound by the L1's look-ups
+                nbv[u][d] = phiP[u];
+                if (c != 0u && e[u].d[d] != 0) nbv[u][d] = ld_val(src, c == 1u ? qp + sdv[d] : qp - sdv[d], a.f32);
             }
         }
 #pragma unroll
@@ -1533,7 +1535,8 @@ void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const 
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s) {
     if (n_host == 0) return;
-    constexpr int U = 1;      // entries per thread and round (4 measured at 768³: 0.724 against 0.694 ms per step — the gathers saturate, more of them in flight only queue)
+    constexpr int U = 1;      // entries per thread and round (4 measured at 768³: 0.724 against 0.694 ms per step — the gathers saturate, more of them in flight only queue;
+                              // fewer, longer-lived workgroups — 8192 / 4096 / 2048 / 1024 instead of 9.2 k — are slower too: 0.536 / 0.538 / 0.541 / 0.549 against 0.534)
     // the length known on the host: U entries per thread, one round; else a grid-stride loop over the capacity
     unsigned blocks = n_host > 0 ? (unsigned)((n_host + 256 * U - 1) / (256 * U)) : (list_cap + 256 * U - 1) / (256 * U);
     const unsigned cap = n_host > 0 ? 65536u : 4096u;
