@@ -45,7 +45,8 @@ struct BrickCfg {
 
 // NT threads take BZ planes of a listed brick (StageArgs::brick_list: the band's active tiles, one brick of `mc` planes each;
 // ceil(mc / BZ) workgroups per brick).  float fields: 256 threads x 8 planes — 35 KB of LDS, four workgroups per CU in
-// different phases (copy / list / arithmetic) — measured against 512 x 16 (57 KB, two per CU).
+// different phases (copy / list / arithmetic) — measured against 512 x 16 (57 KB, two per CU).  fp64 fields: 512 x 8 (67 KB, two per CU;
+// 256 x 4 — 47 KB, three per CU, 2.5-fold halo — measured slower: 0.665 against 0.642 ms per 768³ step).
 template <int ADV, int NM, int CURV, int EIK, class ST, int AK, int NT, int BZ>
 __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsigned sub_per) {
     constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, XL = BrickCfg::XL, W = BrickCfg::W;

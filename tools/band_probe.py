@@ -13,7 +13,7 @@ import lsm_amd as lsm
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-dt = np.float32
+dt = np.float64 if os.environ.get("LSM_PROBE_F64") else np.float32
 grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
 f = lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5
 vals = lsm.LazyMeshField(f, grid).local_values(None).astype(dt)
