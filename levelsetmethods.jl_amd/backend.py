@@ -389,7 +389,8 @@ class HipBackend:
         L.check(self.h, self.lib.lsm_sync(self.h), "lsm_sync")
 
     def profile_enable(self, on=True):
-        L.check(self.h, self.lib.lsm_profile_enable(self.h, 1 if on else 0), "lsm_profile_enable")
+        """on = True / 1: time every stage launch; N > 1: every N-th (lsm_profile_read scales); False / 0: off."""
+        L.check(self.h, self.lib.lsm_profile_enable(self.h, int(on)), "lsm_profile_enable")
 
     def profile_read(self):
         n, ms = C.c_int64(), C.c_double()

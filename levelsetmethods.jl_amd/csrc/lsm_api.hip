@@ -110,7 +110,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->grid = *grid;
     memcpy(h->bc, bc, sizeof(h->bc));
     h->dtype = dtype; h->mode = mode; h->device = device;
-    h->prof = false; h->ev_used = 0;
+    h->prof = false; h->ev_used = 0; h->prof_every = 1; h->prof_seen = 0;
     h->comm = nullptr;
     h->ghost_depth = LSM_GHOST;
     h->d_pf_flag = nullptr;
@@ -466,14 +466,15 @@ static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void
         default: a.base_a = 1.0; a.base_b = 0.0; break;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->prof) { int r = profile_pair(h, &e0, &e1); if (r) return r; LSM_HIP(h, hipEventRecord(e0, s)); }
+        const bool timed = h->prof && (h->prof_seen++ % (unsigned long long)h->prof_every) == 0;
+        if (timed) { int r = profile_pair(h, &e0, &e1); if (r) return r; LSM_HIP(h, hipEventRecord(e0, s)); }
         int r;
         if (h->mode == LSM_MODE_STRICT)
             r = N == 1 ? launch_stage_strict_1d(c, a, s) : (N == 2 ? launch_stage_strict_2d(c, a, s) : launch_stage_strict_3d(c, a, s));
         else
             r = N == 1 ? launch_stage_fast_1d(c, a, s) : (N == 2 ? launch_stage_fast_2d(c, a, s) : launch_stage_fast_3d(c, a, s));
         if (r) return fail(h, LSM_ERR_INVALID, "lsm_stage: kernel combination not instantiated");
-        if (h->prof) LSM_HIP(h, hipEventRecord(e1, s));
+        if (timed) LSM_HIP(h, hipEventRecord(e1, s));
         first = false;
     }
     LSM_HIP(h, hipGetLastError());
@@ -1588,6 +1589,8 @@ int lsm_cfl_cache(LsmHandle* h, int enable) {
 int lsm_profile_enable(LsmHandle* h, int on) {
     if (!h) return LSM_ERR_INVALID;
     h->prof = on != 0;
+    h->prof_every = on > 1 ? on : 1;
+    h->prof_seen = 0;
     h->ev_used = 0;
     return LSM_OK;
 }
@@ -1601,9 +1604,11 @@ int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_t
         LSM_HIP(h, hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i]));
         tot += ms;
     }
-    *n_stage_launches = (int64_t)h->ev_used;
-    *stage_ms_total = tot;
+    // every launch counts; with a sampling period the time of the sampled launches stands for all of them
+    *n_stage_launches = (int64_t)h->prof_seen;
+    *stage_ms_total = h->ev_used ? tot * ((double)h->prof_seen / (double)h->ev_used) : 0.0;
     h->ev_used = 0;
+    h->prof_seen = 0;
     return LSM_OK;
 }
 

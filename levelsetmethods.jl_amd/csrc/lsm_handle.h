@@ -82,6 +82,8 @@ struct LsmHandle {
     int* c_flag;
     std::vector<const void*> cfl_seen;   // coefficient tables known to have landed
     bool prof;
+    int prof_every;              // lsm_profile_enable(h, N): every N-th stage launch is timed
+    unsigned long long prof_seen;   // stage launches since lsm_profile_enable / lsm_profile_read
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used;
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
