@@ -405,3 +405,26 @@ def test_whole_grid_stages_of_one_handle_on_two_streams(lsm):
         b.stage(arr, nt, psi, None, o, None, L.BASE_PSI, 1e-3 * (rep % 2 + 1), 0.0, 0.0)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+
+
+def test_profile_sampling_counts_every_launch_and_scales_the_time(lsm):
+    """lsm_profile_enable(h, N) (include/lsm.h): HIP-event pairs around every N-th stage launch only — the timing must not pay for
+    itself — while lsm_profile_read still reports every launch and a total time scaled from the sampled ones."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (96, 96, 96))
+    phi = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5, grid)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm((1.0, 0.5, -0.25), lsm.WENO5()),), ic=phi, bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    be = eq.backend
+    out = {}
+    for _ in range(30):                                 # past the first launches' one-off costs
+        eq._advance(0.0, 1e-3)
+    for every in (1, 4):
+        be.profile_enable(every)
+        for _ in range(8):
+            eq._advance(0.0, 1e-3)
+        n, ms = be.profile_read()
+        out[every] = (n, ms)
+    be.profile_enable(False)
+    eq._advance(0.0, 1e-3)
+    assert be.profile_read() == (0, 0.0)
+    assert out[1][0] == 24 and out[4][0] == 24          # three stage launches per RK3 step, sampled or not
+    assert out[1][1] > 0 and 0.4 < out[4][1] / out[1][1] < 2.5
