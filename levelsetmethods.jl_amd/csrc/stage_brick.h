@@ -6,10 +6,11 @@
 // 41 M vector instructions per 768³ stage against 10 M for the band's 3.6 M nodes), and every plane of every brick pays
 // the march's loads, LDS writes and barrier whether it holds a band node or not.
 //
-// Here a workgroup takes 8 (or 16) planes of a brick of the band's active-tile list and
-//   1. copies the brick with its halo — (16 + 2G) x (8 + 2G) rows of 40 elements, 16-byte loads from x0 - 4 — into LDS in
-//      the field's storage type,
-//   2. turns the brick's mask bytes into a list of its band nodes (wave scans of the per-thread counts; x fastest),
+// Here a workgroup takes BZ = 8 (or 16) planes of a brick of the band's active-tile list and
+//   1. issues its loads — the mask bytes of its nodes first, then the planes with their halo: (BZ + 2G) x (8 + 2G) rows of 40
+//      elements, 16-byte loads from x0 - 4,
+//   2. turns the mask bytes into a list of its band nodes while the values are in flight (wave scans of the per-thread
+//      counts; x fastest), then writes the values to LDS in the field's storage type,
 //   3. deals the list to its waves 64 nodes at a time: ONE LANE PER BAND NODE.  A lane reads its stencil from the LDS
 //      brick through BrickView — the interface node_update expects of a NodeView, with the march axis as a third LDS
 //      stride — so the arithmetic, and every bit of the result, is stage_tile's.
