@@ -393,6 +393,13 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
 int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_mask, const void* tiles, int mc,
                   void* halo_list, int64_t halo_cap, void* halo_count);
 int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc);   /* tile flags + lists of a mask changed from outside */
+/* The handle keys what it knows about a band (the compact tile lists of `tiles`, the length of halo_list as lsm_band_status
+ * last read it, a prefetched dt) by the ADDRESSES of the caller's buffers.  After rewriting mask / tiles / halo_list /
+ * halo_count IN PLACE (copy! of another band into the same buffers) call lsm_band_retile + lsm_band_status — which rebuild that
+ * state — or at least lsm_band_invalidate, after which the band kernels run over all tiles and take the list's length from
+ * the device until the next lsm_band_status.  (The gather of lsm_band_fill_list is bounded by the device counter in any case.)
+ * The prefetched dt of a band obeys lsm_cfl_cache's contract: tables rewritten in place -> lsm_cfl_cache(h, 0). */
+int lsm_band_invalidate(LsmHandle* h);
 int lsm_band_fill_list(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,
                        const void* halo_count);
 int lsm_band_prepare(LsmHandle* h, void* vals, const void* mask, const void* halo_list, int64_t halo_cap,

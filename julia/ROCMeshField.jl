@@ -527,6 +527,10 @@ end
 function Base.copy!(dst::ROCNarrowBandMeshField, src::ROCNarrowBandMeshField)      # src/meshfield.jl:282-292: values AND keys
     copyto!(dst.buf, src.buf); copyto!(dst.mask, src.mask); copyto!(dst.halo, src.halo); copyto!(dst.tiles, src.tiles)
     dst.hlist = copy(src.hlist); copyto!(dst.hcount, src.hcount)
+    # the handle's compact tile lists, the halo list's length as the host knows it and a prefetched Δt describe the band these
+    # buffers held BEFORE: rebuild them from the new contents (api.py's copy_ does the same; include/lsm.h, lsm_band_invalidate)
+    _check(dst.h.ptr, ccall((:lsm_band_retile, libhiplsm), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), dst.h.ptr, pointer(dst.mask), pointer(dst.tiles), BAND_MC), "lsm_band_retile")
+    _band_status(dst)
     return dst
 end
 function Base.values(ϕ::ROCNarrowBandMeshField{N, T, B, S}) where {N, T, B, S}

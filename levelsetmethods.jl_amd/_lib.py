@@ -133,6 +133,7 @@ _SIGS = [
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_band_halo", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_band_retile", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
+    ("lsm_band_invalidate", C.c_int, [_H]),
     ("lsm_band_fill_list", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_reinitialize", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

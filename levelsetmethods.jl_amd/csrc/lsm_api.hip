@@ -48,6 +48,8 @@ int lsm_fail(LsmHandle* h, int code, const std::string& msg) { return fail(h, co
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) return fail(h, LSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
+// host wait for the handle's stream (lsm_host_sync: cannot be hung by a silent RCCL peer)
+#define LSM_SYNC(h) do { int rs_ = lsm_host_sync(h, __func__); if (rs_) return rs_; } while (0)
 
 // storage of a field value: 8 bytes, or 4 for LSM_DTYPE_F32 handles (coefficient fields, frozen signs and every
 // reduction stay fp64)
@@ -250,7 +252,7 @@ int lsm_set_stream(LsmHandle* h, void* stream) {
 
 int lsm_sync(LsmHandle* h) {
     if (!h) return LSM_ERR_INVALID;
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     return LSM_OK;
 }
 
@@ -271,7 +273,7 @@ static int copy_interior(LsmHandle* h, void* dev, void* host, bool to_dev, size_
         else
             LSM_HIP(h, hipMemcpy2DAsync(s, row, d, es * h->lay.stride[1], row, h->nloc[1], hipMemcpyDeviceToHost, h->stream));
     }
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     return LSM_OK;
 }
 int lsm_upload(LsmHandle* h, void* dev_padded, const void* host_dense) {
@@ -567,7 +569,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
                     bool seen = false;
                     for (const void* q : h->cfl_seen) seen = seen || q == tp;
                     if (!seen) {
-                        LSM_HIP(h, hipStreamSynchronize(h->stream));
+                        LSM_SYNC(h);
                         if (h->cfl_seen.size() > 64) h->cfl_seen.clear();
                         h->cfl_seen.push_back(tp);
                     }
@@ -616,7 +618,7 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
                     int flag = 0;
                     LSM_HIP(h, hipMemcpyAsync(&cnt, h->d_cand_count, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
                     LSM_HIP(h, hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
-                    LSM_HIP(h, hipStreamSynchronize(h->stream));
+                    LSM_SYNC(h);
                     LSM_HIP(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
                     if (!flag && cnt >= 1 && cnt <= cap) {     // NaN tables or a flat maximum: keep sweeping the grid
                         if (h->cfl_cand.size() > 16) { for (auto& e : h->cfl_cand) (void)hipFree(e.d_cand); h->cfl_cand.clear(); }
@@ -674,7 +676,7 @@ static bool is_slab(const LsmHandle* h) {
 }
 static int run_hook(LsmHandle* h, LsmStageHook hook, void* user, int stage, const void* field, double t) {
     if (!hook) return LSM_OK;
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     if (hook(user, stage, field, t)) return fail(h, LSM_ERR_INVALID, "stage hook requested abort");
     return LSM_OK;
 }
@@ -832,7 +834,7 @@ int lsm_extrema(LsmHandle* h, const void* phi, double* vmin, double* vmax) {
     launch_extrema(h->grid.ndim, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, phi, is_f32(h), h->d_partial,
                    h->d_partial + MAXB, nb, h->d_result, h->stream);
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     *vmin = h->h_result[0];
     *vmax = h->h_result[1];
     return LSM_OK;
@@ -852,7 +854,7 @@ int lsm_debug_stamp(LsmHandle* h, int enable, double* clock_ghz, double* loop_us
     }
     if (!h->d_stamp || !clock_ghz) return LSM_ERR_INVALID;
     std::vector<unsigned long long> v(4 * 16384);
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     LSM_HIP(h, hipMemcpy(v.data(), h->d_stamp, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
     std::vector<double> clk, us;
     for (int i = 0; i < 16384; ++i)
@@ -868,7 +870,7 @@ int lsm_debug_stamp(LsmHandle* h, int enable, double* clock_ghz, double* loop_us
 int lsm_debug_stamp_raw(LsmHandle* h, unsigned long long* out) {
     if (!h || !h->d_stamp || !out) return LSM_ERR_INVALID;
     LSM_HIP(h, hipSetDevice(h->device));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     LSM_HIP(h, hipMemcpy(out, h->d_stamp, sizeof(unsigned long long) * 4 * 16384, hipMemcpyDeviceToHost));
     return LSM_OK;
 }
@@ -897,7 +899,7 @@ static int measure(LsmHandle* h, int mode, void* phi, double* out) {
     launch_measure(mode, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, h->dxmin, scale,
                    phi, is_f32(h), h->d_partial, nb, h->d_result, h->stream);
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     *out = h->h_result[0];
     return LSM_OK;
 }
@@ -915,7 +917,7 @@ int lsm_band_volume(LsmHandle* h, const void* phi, const void* mask, double* out
                            (const unsigned char*)mask, h->d_result, h->stream))
         return fail(h, LSM_ERR_HIP, "lsm_band_volume: device error");
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     *out = h->h_result[0];
     return LSM_OK;
 }
@@ -930,7 +932,7 @@ int lsm_band_perimeter(LsmHandle* h, const void* phi, const void* mask, double* 
     launch_measure(1, N, h->nloc, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->h, h->dxmin, scale, phi, is_f32(h), h->d_partial, nb,
                    h->d_result, h->stream, (const unsigned char*)mask);
     LSM_HIP(h, hipMemcpyAsync(h->h_result, h->d_result, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     *out = h->h_result[0];
     return LSM_OK;
 }
@@ -1289,6 +1291,18 @@ int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
     return LSM_OK;
 }
 
+// What the handle remembers about caller-owned band buffers — the compact tile lists of `tiles`, the halo list's length as the
+// host last read it, a prefetched Δt — is keyed by their ADDRESSES.  A caller that rewrites mask / tiles / halo_list /
+// halo_count in place (copy! of another band into these buffers) calls this, or lsm_band_retile + lsm_band_status, which rebuild
+// that state; until then the band kernels run over all tiles and read the list's length on the device.
+int lsm_band_invalidate(LsmHandle* h) {
+    if (!h) return LSM_ERR_INVALID;
+    h->lists_tiles = nullptr; h->lists_host_valid = false;
+    h->halo_n_key = nullptr; h->halo_n = 0;
+    h->band_cfl.valid = false; h->band_cfl.pending = false;
+    return LSM_OK;
+}
+
 // ϕ[I] for the non-band nodes flagged in `targets`: _extrapolate_to_ghost materialised
 // (src/meshfield.jl:481-511) by a fresh nearest-node search over the whole grid (scalar getindex path).
 int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* targets, const void* tiles, int mc) {
@@ -1336,7 +1350,7 @@ int lsm_band_count(LsmHandle* h, const void* mask, int64_t* count) {
     launch_band_count(band_args(h, 8, nullptr), (const unsigned char*)mask, h->d_count, h->stream);
     unsigned long long c = 0;
     LSM_HIP(h, hipMemcpyAsync(&c, h->d_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     *count = (int64_t)c;
     return LSM_OK;
 }
@@ -1347,7 +1361,7 @@ int lsm_band_missed(LsmHandle* h, int* missed) {
     if (!h || !missed) return LSM_ERR_INVALID;
     LSM_TRY(ensure_ring(h));
     LSM_HIP(h, hipMemcpyAsync(missed, h->d_miss, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
     return LSM_OK;
 }
@@ -1360,7 +1374,7 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
     // the kernel writes into the host's pinned page itself ([2..7] status, [8..11] prefetched Δt): no copy, one synchronisation
     launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->band_cfl.pending ? h->d_result + 8 : nullptr,
                        h->h_result_dev + 2, h->stream);
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     if (h->band_cfl.pending) {
         for (int k = 0; k < h->band_cfl.nterms; ++k)
             if (h->band_cfl.slot[k] >= 0) h->band_cfl.dt[k] = h->h_result[8 + h->band_cfl.slot[k]];
@@ -1498,6 +1512,7 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
     // a slab is fine for a band whose slab carries its neighbours' planes (every node's samples and patches lie
     // within the band's reach; the caller refreshes the overlap planes afterwards); a dense slab is not
     if (!mask) LSM_TRY(check_single_device(h));
+    if (h->comm) LSM_SYNC(h);           // the pipeline's own host waits follow a stream an exchange can no longer hold up
     const int N = h->grid.ndim;
     double lc[3] = {0, 0, 0};
     for (int d = 0; d < N; ++d) lc[d] = h->grid.lc[d];
@@ -1597,7 +1612,7 @@ int lsm_profile_enable(LsmHandle* h, int on) {
 
 int lsm_profile_read(LsmHandle* h, int64_t* n_stage_launches, double* stage_ms_total) {
     if (!h || !n_stage_launches || !stage_ms_total) return LSM_ERR_INVALID;
-    LSM_HIP(h, hipStreamSynchronize(h->stream));
+    LSM_SYNC(h);
     double tot = 0;
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0;

@@ -1209,9 +1209,13 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
 // _extrapolate_to_ghost from a precomputed (node, nearest band node) list: one thread per entry.  n_host >= 0: the list's
 // length as the host knows it (lsm_band_status) — every wave reading the device counter is 16 k requests for ONE cache line.
 template <int NDIM, int U>
-__global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* list_count, long long n_host,
+__global__ void __launch_bounds__(256) band_apply_kernel(BandArgs a, const BandEntry* list, const unsigned* __restrict__ list_count, long long n_host,
                                                          unsigned list_cap, const unsigned char* src_mask, const void* src, void* dst) {
-    unsigned n = n_host >= 0 ? (unsigned)n_host : *list_count;
+    // the host's length sizes the launch (lsm_band_status read it anyway); the device counter still bounds the entries (one
+    // scalar load per wave): a host that rewrote the list in place and kept a stale length cannot make the kernel gather
+    // through entries that do not exist
+    const unsigned n_dev = *list_count;
+    unsigned n = n_host >= 0 && (unsigned long long)n_host < n_dev ? (unsigned)n_host : n_dev;
     n = n < list_cap ? n : list_cap;
     // U entries per thread and round, a block apart (coalesced): the entries, then all their value loads, are in flight together —
     // the kernel is a chain of two memory round trips per entry and nothing else

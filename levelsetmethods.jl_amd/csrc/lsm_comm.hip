@@ -138,6 +138,7 @@ struct LsmComm {
     bool overlap;              // stages update the interface planes first and overlap the exchange with the interior
     std::atomic<bool> failed;  // a call failed half-way, a peer is gone, or lsm_comm_abort was called: LSM_ERR_COMM from now on
     ncclComm_t nccl;
+    std::atomic<bool> nccl_aborted;   // ncclCommAbort has run (once): `nccl` is gone — never used again, never destroyed
     double* d_dt;              // device scalar of the Δt all-reduce
     double* h_dt;              // pinned host scalar
     LocalGroup* grp;
@@ -195,6 +196,14 @@ void mark_failed(LsmComm* c, const std::string& why) {
     }
 }
 
+// RCCL: release this rank's queued send / receive / all-reduce kernels (a peer that never posts would keep them, and every
+// host wait behind them, for ever).  Runs at most once per communicator; any thread.  After it `nccl` is never touched again.
+void rccl_abort(LsmComm* c) {
+    if (c->transport != LSM_COMM_RCCL || !c->nccl) return;
+    if (c->nccl_aborted.exchange(true)) return;
+    if (rccl().CommAbort) (void)rccl().CommAbort(c->nccl);
+}
+
 void free_local_group(LocalGroup* g) {
     for (auto& r : g->ranks) {
         (void)hipSetDevice(r.device);
@@ -227,7 +236,7 @@ int make_comm(LsmHandle* h, int transport, int rank, int world, LsmComm** out) {
     c->wrap_dn = face_dn && rank == 0;
     c->wrap_up = face_up && rank == world - 1;
     c->overlap = !(getenv("LSM_SLAB_OVERLAP") && getenv("LSM_SLAB_OVERLAP")[0] == '0');
-    c->seq = 0; c->pending = false; c->failed.store(false); c->nccl = nullptr; c->d_dt = nullptr; c->h_dt = nullptr; c->grp = nullptr;
+    c->seq = 0; c->pending = false; c->failed.store(false); c->nccl = nullptr; c->nccl_aborted.store(false); c->d_dt = nullptr; c->h_dt = nullptr; c->grp = nullptr;
     c->stream = nullptr;
     for (auto& e : c->ev_ready) e = nullptr;
     for (auto& e : c->ev_done) e = nullptr;
@@ -271,9 +280,12 @@ void free_comm(LsmHandle* h, LsmComm* c) {
             if (nb >= 0 && g->ranks[nb].stream) { (void)hipSetDevice(g->ranks[nb].device); (void)hipStreamSynchronize(g->ranks[nb].stream); }
         (void)hipSetDevice(h->device);
     } else {
+        // a failed communicator may still have an unmatched send / receive / all-reduce kernel queued: abort first, or the
+        // synchronisations below (and ncclCommDestroy) would wait for a peer that never comes
+        if (c->failed.load()) rccl_abort(c);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(h->stream);            // the Δt all-reduce runs on the handle's stream
-        if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+        if (c->nccl && !c->nccl_aborted.load()) (void)rccl().CommDestroy(c->nccl);
         for (auto e : c->ev_ready) if (e) (void)hipEventDestroy(e);
         for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -297,8 +309,11 @@ void free_comm(LsmHandle* h, LsmComm* c) {
 // stream, behind the neighbours' and its own "buffers final" events.
 int local_enqueue(LsmHandle* h, LocalGroup* g, unsigned long long seq) {
     const int par = (int)(seq & 1);
-    int cur = -1;
-    (void)hipGetDevice(&cur);
+    struct DeviceGuard {      // the posting thread leaves on the device it came with, whatever happens below
+        int cur = -1;
+        DeviceGuard() { (void)hipGetDevice(&cur); }
+        ~DeviceGuard() { if (cur >= 0) (void)hipSetDevice(cur); }
+    } guard;
     for (int r = 0; r < g->world; ++r) {
         LocalRank& me = g->ranks[r];
         COMM_HIP(h, hipSetDevice(me.device));
@@ -317,7 +332,6 @@ int local_enqueue(LsmHandle* h, LocalGroup* g, unsigned long long seq) {
         }
         COMM_HIP(h, hipEventRecord(me.ev_done[par], me.stream));
     }
-    if (cur >= 0) (void)hipSetDevice(cur);
     return LSM_OK;
 }
 
@@ -425,7 +439,7 @@ int stream_wait(LsmHandle* h, LsmComm* c, const char* what) {
         if (c->failed.load() || now > deadline) {
             const bool timed_out = !c->failed.load();
             c->failed.store(true);
-            if (c->nccl && rccl().CommAbort) { (void)rccl().CommAbort(c->nccl); c->nccl = nullptr; }   // releases the kernels waiting for the peer
+            rccl_abort(c);                            // releases the kernels waiting for the peer
             return lsm_fail(h, LSM_ERR_COMM, std::string(what) + (timed_out ? ": timed out waiting for the other ranks (LSM_COMM_TIMEOUT_MS)"
                                                                            : ": the communicator was aborted"));
         }
@@ -527,6 +541,16 @@ void band_ranges(const LsmHandle* h, const LsmComm* c, int first[4]) {
 }  // namespace
 
 bool lsm_comm_overlap(const LsmHandle* h) { return h->comm && h->comm->overlap; }
+// Host wait for the handle's stream.  Behind an RCCL exchange the stream may hold a send / receive kernel whose peer never
+// posts: the wait then ends with LSM_ERR_COMM on lsm_comm_abort or after LSM_COMM_TIMEOUT_MS (and aborts the communicator, which
+// releases the kernel) instead of hanging.  LOCAL copies are only enqueued once every rank has posted: a plain wait ends.
+int lsm_host_sync(LsmHandle* h, const char* what) {
+    LsmComm* c = h->comm;
+    if (c && c->transport == LSM_COMM_RCCL && c->world > 1) return stream_wait(h, c, what);
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return lsm_fail(h, LSM_ERR_HIP, std::string(what) + ": hipStreamSynchronize: " + hipGetErrorString(e));
+    return LSM_OK;
+}
 int lsm_comm_band_overlap(const LsmHandle* h) { return h->comm ? h->comm->band_W : 0; }
 
 extern "C" {
@@ -620,12 +644,14 @@ int lsm_comm_detach(LsmHandle* h) {
 
 // Fail the communicator of this handle — and, LOCAL, its whole group: every rank blocked in (or later entering) an exchange
 // wait or the Δt all-reduce returns LSM_ERR_COMM instead of waiting for a rank that will not come.  Callable from any
-// thread.  RCCL: ncclCommAbort releases this rank's kernels; the other processes notice through their own timeout.
+// thread — but not concurrently with lsm_comm_detach / lsm_destroy of the same handle (the communicator must outlive the call).
+// RCCL: ncclCommAbort releases this rank's queued kernels here and now; the other processes notice through their own timeout.
 int lsm_comm_abort(LsmHandle* h) {
     if (!h) return LSM_ERR_INVALID;
     LsmComm* c = h->comm;
     if (!c) return LSM_OK;
     mark_failed(c, "aborted by rank " + std::to_string(c->rank) + " (lsm_comm_abort)");
+    rccl_abort(c);
     return LSM_OK;
 }
 
@@ -778,7 +804,8 @@ int lsm_band_overlap_mask(LsmHandle* h, void* mask) {
         hipLaunchKernelGGL(nz_scan_kernel, dim3(1), dim3(1024), 0, h->stream, c->d_nz_counts + (size_t)k * nchunks, nchunks, c->d_nz_total + k);
     }
     COMM_HIP(h, hipMemcpyAsync(c->h_nz_total, c->d_nz_total, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    COMM_HIP(h, hipStreamSynchronize(h->stream));
+    rc = stream_wait(h, c, "lsm_band_overlap_mask");      // behind the mask exchange: a peer that never posts must not hang the host
+    if (rc) return rc;
     const size_t es = esize(h);
     for (int k = 0; k < 4; ++k) {
         c->n_idx[k] = first[k] >= 0 ? c->h_nz_total[k] : 0u;

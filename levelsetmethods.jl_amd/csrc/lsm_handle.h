@@ -99,4 +99,5 @@ struct LsmHandle {
 int lsm_fail(LsmHandle* h, int code, const std::string& msg);
 // lsm_comm.hip: the attached communicator wants boundary-first stages (lsm_comm_set_overlap; LSM_SLAB_OVERLAP=0 at attach time)
 bool lsm_comm_overlap(const LsmHandle* h);
+int lsm_host_sync(LsmHandle* h, const char* what);   // host wait for h->stream that an RCCL peer's silence cannot hang (lsm_comm.hip)
 int lsm_comm_band_overlap(const LsmHandle* h);   // overlap depth declared by lsm_band_overlap_config (0 = none)

@@ -60,6 +60,9 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     __shared__ lsm_v4u vbrick[NV4];
     __shared__ unsigned short nodes[TX * TY * BZ];
     __shared__ int wsum[NT / 64];
+    // gfx950 has 160 KB of LDS per CU (64 KB per workgroup on its predecessors: the fp64 instance would not launch there);
+    // two workgroups of the largest instance must fit a CU
+    static_assert(2 * (sizeof(lsm_v4u) * NV4 + sizeof(unsigned short) * TX * TY * BZ + 64) <= 160 * 1024, "brick kernel: LDS budget of a gfx950 CU");
     const ST* brick = reinterpret_cast<const ST*>(vbrick);
 
     // the launch's workgroups in list order, dealt to the XCDs in contiguous ranges (TileOrder): the BZ-plane parts of a brick
@@ -202,12 +205,12 @@ int launch_bricks(const StageArgs& a, hipStream_t s) {
 #define LSM_BRICK(STT, AKK, NTT, BZZ) hipLaunchKernelGGL((brick_kernel<ADV, NM, CURV, EIK, STT, AKK, NTT, BZZ>), grid, dim3(NTT), 0, s, b, sub_per)
 #define LSM_BRICK_ST(AKK) do { if (!b.f32) LSM_BRICK(double, AKK, 512, 8); else if (small) LSM_BRICK(float, AKK, 256, 8); else LSM_BRICK(float, AKK, 512, 16); } while (0)
     if constexpr (ADV != 0) {
-        if (ak == LSM_COEFF_ROTATION) { LSM_BRICK_ST(LSM_COEFF_ROTATION); return 0; }
+        if (ak == LSM_COEFF_ROTATION) { LSM_BRICK_ST(LSM_COEFF_ROTATION); return hipGetLastError() == hipSuccess ? 0 : -1; }
     }
     LSM_BRICK_ST(LSM_COEFF_CONST);
 #undef LSM_BRICK_ST
 #undef LSM_BRICK
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -1;     // a launch the device refuses (LDS, grid) goes to the tiled kernel
 }
 
 }  // namespace LSM_NS

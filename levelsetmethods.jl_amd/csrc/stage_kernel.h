@@ -1037,13 +1037,18 @@ template <int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST>
 __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id) {
     constexpr int NDIM = 3;
     constexpr int AK = LSM_COEFF_CONST;
+    // No curvature here.  A variant with the three-plane LDS ring curvature's edge diagonals need (planes m-1, m, m+1 resident, as in
+    // stage_tile) was written in round 3 and gave wrong values at the FIRST node of each pair from the second plane of a chunk
+    // on: that node kept the chunk's first centre value — the compiled march held no move into its z(+1) register, although the
+    // source shifted both nodes' lines alike, and splitting the shift per node did not change the code.  Source or compiler was
+    // not decided; the variant gained 4 % on a kernel that is not on any BASELINE config's path.  It is fenced, not carried:
+    static_assert(!CURV, "stage_tile2 serves the axis-aligned single terms; curvature stays with stage_tile (see the comment above)");
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
-    constexpr int LEAD = CURV ? 1 : 0;
-    constexpr int NSLOT = 2 * LEAD + 2;
+    constexpr int NSLOT = 2;
     constexpr int TXN = 2 * TX;
     constexpr int W = TXN + 2 * G, H = TY + 2 * G, HW = H * W, NT = TX * TY;
     constexpr int NHX = 2 * G * TY;
-    constexpr int WY = CURV ? W : TXN;
+    constexpr int WY = TXN;
     constexpr int NHY = 2 * G * WY;
     constexpr int NH = NHX + NHY;
     constexpr int HPT = (NH + NT - 1) / NT;
@@ -1101,7 +1106,7 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
         } else {
             const int e2 = e - NHX;
             const int row = e2 / WY;
-            lx = (CURV ? 0 : G) + e2 % WY;
+            lx = G + e2 % WY;
             ly = row < G ? row : row + TY;
         }
         int X = bx0 - G + lx;
@@ -1114,40 +1119,34 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
     }
     const int lpos = (ty + G) * W + 2 * tx + G;
 
-    double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
+    double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0};
     if constexpr (ADV != 0) coeff_prep<NDIM, NDIM, ADV_SCALED, AK>(a.adv, a, 0, 0, pre_adv);
     if constexpr (NM != 0) coeff_prep<NDIM, 1, false, AK>(a.nm, a, 0, 0, pre_nm);
-    if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, AK>(a.curv, a, 0, 0, pre_curv);
 
     double zA[2 * G + 1], zB[2 * G + 1];
 #pragma unroll
     for (int j = 0; j <= 2 * G; ++j) ldpair(plane(m0 - G + j), zA[j], zB[j]);
-    double hp[2 * LEAD + 1][HPT];
+    double hp[HPT];
+    {
+        const ST* P = plane(m0);
 #pragma unroll
-    for (int pl = -LEAD; pl <= LEAD; ++pl) {
-        const ST* P = plane(m0 + pl);
-#pragma unroll
-        for (int h = 0; h < HPT; ++h) hp[pl + LEAD][h] = ldg(P, hg[h]);
+        for (int h = 0; h < HPT; ++h) hp[h] = ldg(P, hg[h]);
     }
+    tile[lpos] = zA[G];
+    tile[lpos + 1] = zB[G];
 #pragma unroll
-    for (int pl = -LEAD; pl <= LEAD; ++pl) {
-        const int slot = pl + LEAD;
-        tile[slot * HW + lpos] = zA[G + pl];
-        tile[slot * HW + lpos + 1] = zB[G + pl];
-#pragma unroll
-        for (int h = 0; h < HPT; ++h)
-            if (hv[h]) tile[slot * HW + hl[h]] = hp[slot][h];
-    }
+    for (int h = 0; h < HPT; ++h)
+        if (hv[h]) tile[hl[h]] = hp[h];
     long long po = corner + (long long)m0 * sm;
     const ST* Pnx = plane(m0 + G);
-    const ST* Pn = plane(m0 + LEAD);
+    const ST* Pn = plane(m0);
     const int plast = nm + G - 1;
     const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
     const int prange = __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int m = m0; m < m1; ++m) {
         Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
-        Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
+        Pn = uniform_ptr(m + 1 <= plast ? Pn + sm : Pn);
         double nA, nB;
         ldpair(Pnx, nA, nB);
         double hn[HPT];
@@ -1156,7 +1155,7 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
         // this plane's pointwise operands: consumed after the arithmetic
         NodeOps opA, opB;
         opA.u[0] = pre_adv[0]; opA.u[1] = pre_adv[1]; opA.u[2] = pre_adv[2];
-        opA.vnm = pre_nm[0]; opA.bcurv = pre_curv[0]; opA.s0 = 0.0; opA.phin = 0.0; opA.out2 = 0.0; opA.have_negs = false;
+        opA.vnm = pre_nm[0]; opA.bcurv = 0.0; opA.s0 = 0.0; opA.phin = 0.0; opA.out2 = 0.0; opA.have_negs = false;
         opA.negs[0] = opA.negs[1] = opA.negs[2] = 0ull;
         opB = opA;
         if constexpr (EIK == 1) ldg2(uniform_ptr(a.s0 + po), ocold0, opA.s0, opB.s0);
@@ -1166,20 +1165,18 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
         double rA = 0.0, rB = 0.0, r2 = 0.0;
         if (any_active) {
             const int rel = m - m0;
-            const double* T0 = tile + ((rel + LEAD) % NSLOT) * HW + lpos;
-            const double* Tm = tile + ((rel + LEAD + NSLOT - 1) % NSLOT) * HW + lpos;
-            const double* Tp = tile + ((rel + LEAD + 1) % NSLOT) * HW + lpos;
-            NodeView<NDIM, G, W> nvB{T0 + 1, Tm + 1, Tp + 1, zB, zB[G]};
+            const double* T0 = tile + (rel % NSLOT) * HW + lpos;
+            NodeView<NDIM, G, W> nvB{T0 + 1, T0 + 1, T0 + 1, zB, zB[G]};
             node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nvB, opB, rB, r2);
-            NodeView<NDIM, G, W> nvA{T0, Tm, Tp, zA, zA[G]};
+            NodeView<NDIM, G, W> nvA{T0, T0, T0, zA, zA[G]};
             node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nvA, opA, rA, r2);
         }
 #pragma unroll
         for (int j = 0; j < 2 * G; ++j) { zA[j] = zA[j + 1]; zB[j] = zB[j + 1]; }
         zA[2 * G] = nA; zB[2 * G] = nB;
-        const int wslot = (m - m0 + 1 + 2 * LEAD) % NSLOT;
-        tile[wslot * HW + lpos] = zA[G + LEAD];
-        tile[wslot * HW + lpos + 1] = zB[G + LEAD];
+        const int wslot = (m - m0 + 1) % NSLOT;
+        tile[wslot * HW + lpos] = zA[G];
+        tile[wslot * HW + lpos + 1] = zB[G];
 #pragma unroll
         for (int h = 0; h < HPT; ++h)
             if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];

@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblsm_oracle.so")
+# LSM_ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle asan`, tools/oracle_asan.sh)
+_LIB_PATH = os.environ.get("LSM_ORACLE_LIB") or os.path.join(_HERE, "liblsm_oracle.so")
 
 GHOST = 3
 BC_PERIODIC, BC_EXTRAPOLATION, BC_SYMMETRY, BC_NONE = 0, 1, 2, 3

@@ -258,7 +258,10 @@ def test_768_cubed_config5_float32_band_is_symmetric_and_matches_the_dense_run(l
       * one RK3 step on the band against the same step on the dense field: the band's edge nodes read extrapolated values
         (src/meshfield.jl:481-511) and every stage carries their influence one stencil further in, so nothing is bitwise;
         nodes whose own stencil lies inside the band agree to 1e-6, every band node within 1.5 h of the interface to 1e-5
-        (config 5's stated tolerance is 1e-4)."""
+        (config 5's stated tolerance is 1e-4).  Both bounds are TOLERANCES, not pins: an nlayers = 3 band is about seven nodes
+        thick and an RK3 step carries the edge's extrapolated values three stencils (9 nodes) inward, so NO node of this band is
+        free of them — "deep" only means one stencil further from the edge; a first version that asked those nodes to agree with
+        the dense run to an ulp failed for that reason, not for a defect."""
     import torch
     n = 768
     grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))

@@ -126,3 +126,37 @@ def test_padded_stage_equals_dense_advance(orc):
     orc.fill_ghosts_padded(grid, bc, lay, b2)
     orc.stage_padded(grid, bc, lay, terms, b2, P, P, None, orc.BASE_RK3_S3, (2 / 3) * dt, 0.0, tc + 0.5 * dt)
     assert np.array_equal(orc.from_padded(lay, 3, P), ref)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """the CPU restatement runs clean under ASan + UBSan (`make -C oracle asan`; tools/oracle_asan.sh runs the whole
+    oracle-only suite against that build).  Here: a fresh interpreter with the sanitizer runtime preloaded takes one RK3 step of the
+    headline equation with partial tiles and one ghost fill with every boundary-condition kind — any out-of-bounds read of the
+    padded array or signed overflow in the index arithmetic aborts the child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    code = (
+        "import numpy as np\n"
+        "from oracle import oracle as orc\n"
+        "n = (13, 9, 11)\n"
+        "g = orc.Grid((0, 0, 0), (1, 1, 1), n)\n"
+        "x, y, z = g.coords()\n"
+        "s2 = lambda a: np.sin(np.pi * a) ** 2\n"
+        "s = lambda a: np.sin(2 * np.pi * a)\n"
+        "terms = [orc.advection(orc.separable([[2 * s2(x), s(y), s(z)], [-s(x), s2(y), s(z)], [-s(x), s(y), s2(z)]], orc.TIME_COS, 3.0)), orc.eikonal()]\n"
+        "phi = g.sample(lambda X, Y, Z: np.sqrt((X - 0.35) ** 2 + (Y - 0.35) ** 2 + (Z - 0.35) ** 2) - 0.15)\n"
+        "for kind in ('neumann', 'periodic'):\n"
+        "    bc = orc.make_bc(kind, 3)\n"
+        "    p = phi.copy(order='F')\n"
+        "    dt = 0.5 * orc.compute_cfl(g, bc, p, terms, 0.0)\n"
+        "    orc.advance(orc.RK3, g, bc, p, terms, 0.0, dt)\n"
+        "    assert np.isfinite(p).all()\n"
+        "print('ok')\n")
+    env = dict(os.environ, LSM_ORACLE_LIB=os.path.join(root, "oracle", "liblsm_oracle_asan.so"), LD_PRELOAD=rt,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
