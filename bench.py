@@ -10,6 +10,10 @@ slab-decomposed along the last dimension (every rank owns 1024 × 1024 × 128 = 
 scaling), ghost planes exchanged over RCCL/xGMI after every stage and Δt all-reduced INSIDE libhiplsm
 (lsm_comm_attach_rccl; torch.distributed only carries the RCCL unique id to the ranks).
 
+`--transport local --gpus N` rehearses the N-rank run on ONE device: N rank threads of this process, every rank a handle of an
+in-process group (lsm_comm_attach_local: peer copies stand in for xGMI), through the same code below — slab construction, the
+self-check of the two stage orders, the timed loop, the JSON line.  It measures the decomposition's own cost, not a transfer.
+
 A "step" is one pass of the reference's step loop body (src/timestepping.jl:104-116):
 compute_cfl + the 3 fused RK3 stage kernels + ghost fills (hooks = identity).  Inputs are resident
 in HBM when the timed region starts.  One JSON line is printed by rank 0.
@@ -86,6 +90,60 @@ def committed_profile(n, world, mode):
     return None
 
 
+class DistCtx:
+    """The ranks of a torch.distributed.run launch (one process per GPU, RCCL)."""
+    transport = "rccl"
+
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.device = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.device)
+        self.comm = None
+        if self.world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            self.comm = dist.group.WORLD
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+class LocalCtx:
+    """Rank `r` of `world` rank threads on one device (api.LocalGroup: lsm_comm_attach_local)."""
+    transport = "local"
+
+    def __init__(self, torch, group, r, device=0):
+        self.torch, self.group = torch, group
+        self.world, self.rank, self.device = group.world, r, device
+        self.comm = group.rank(r)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        self.group.exchange(self.rank, None)
+        self.torch.cuda.synchronize()
+
+    def gather(self, obj):
+        return self.group.exchange(self.rank, obj)
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +156,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="side of the single-thread oracle sample")
     ap.add_argument("--cpu-full", action="store_true", help="SURVEY.md §8d's full CPU sample: 10 steps at 256^3 on one core, 2 at 512^3 on all (minutes)")
     ap.add_argument("--profile-every", type=int, default=4, help="HIP-event pairs around every N-th stage launch of the timed region (1 = all)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
+                    help="rccl: one process per GPU (torch.distributed.run); local: --gpus N rank THREADS on device 0 over the in-process transport (rehearsal)")
     ap.add_argument("--config", default="headline", choices=["headline", "2", "3", "5"],
                     help="headline = BASELINE config 4's equation at 512^3 on one GPU (the metric); 2, 3, 5: the other single-GPU BASELINE configs (tools/configs.py)")
     args = ap.parse_args()
@@ -112,16 +172,39 @@ def main():
 
     import lsm_amd as lsm
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    comm = None
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = dist.group.WORLD
+    if args.transport == "local" and args.gpus > 1:
+        import threading
+        torch.cuda.set_device(0)
+        group = lsm.LocalGroup(args.gpus)
+        errs = [None] * args.gpus
+
+        def rank_main(r):
+            try:
+                torch.cuda.set_device(0)
+                run(args, lsm, torch, LocalCtx(torch, group, r))
+            except BaseException as e:   # noqa: BLE001 - a rank that dies must not leave the others at a barrier
+                errs[r] = e
+                group.abort()
+        threads = [threading.Thread(target=rank_main, args=(r,), name=f"rank{r}") for r in range(args.gpus)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = next((e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or next((e for e in errs if e is not None), None)
+        if first is not None:
+            raise first
+        return
+    ctx = DistCtx(torch, dist)
+    if args.gpus > 1 and ctx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={ctx.world})")
+    run(args, lsm, torch, ctx)
+    ctx.close()
+
+
+def run(args, lsm, torch, ctx):
+    """One rank of the benchmark (the only rank at N = 1)."""
+    world, rank, local_rank, comm = ctx.world, ctx.rank, ctx.device, ctx.comm
+    barrier = ctx.barrier
 
     if world == 1:
         n = (args.n, args.n, args.n)
@@ -134,12 +217,6 @@ def main():
     cells = n[0] * n[1] * n[2]
 
     eq, grid, vel = build_equation(lsm, n, comm, local_rank, args.mode)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # multi-GPU self-check (outside the timed region): one step with the exchange overlapped behind the
     # interior update must equal one step with the plain stage -> halo sequence BIT FOR BIT; otherwise
@@ -166,8 +243,9 @@ def main():
             one_step(eq, 0.0)        # the second step's Δt all-reduce waits (with a timeout) behind the first step's exchanges
         except Exception as e:   # noqa: BLE001 - reported in config.exchange
             err = repr(e)
-        errs = [None] * world
-        dist.all_gather_object(errs, err)
+        errs = ctx.gather(err)
+        if any(errs) and ctx.transport == "local":
+            raise RuntimeError(f"the in-process slab step failed: {next(x for x in errs if x)}")      # no other exchange to fall back to
         if any(errs):
             os.environ["LSM_LIB_COMM"] = "0"
             del eq, keep
@@ -184,11 +262,14 @@ def main():
         eq.state.ghosts_dirty = True
         set_overlap(False)
         one_step(eq, 0.0)
-        same = torch.tensor([1.0 if torch.equal(a_res, eq.state.buf) else 0.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        # the nodes of the slab, not its padded buffer: in FAST mode the ghost rows of dimensions 1 and 2 are never read (the loads are
+        # redirected) nor written inside a step, and the two orders fill different never-read corners of the ghost planes
+        lay = eq.backend.lay
+        nd = len(n)
+        view = lambda t: torch.as_strided(t, tuple(int(lay.n[d]) for d in range(nd)), tuple(int(lay.stride[d]) for d in range(nd)), int(lay.origin))
+        ok = all(ctx.gather(bool(torch.equal(view(a_res), view(eq.state.buf)))))
         eq.state.buf.copy_(keep)
         eq.state.ghosts_dirty = True
-        ok = bool(same.item() == 1.0)
         set_overlap(ok)
         overlap_note = "on (self-check passed)" if ok else "off (self-check mismatch)"
         del keep, a_res
@@ -213,10 +294,7 @@ def main():
     el = time.perf_counter() - t0
     n_launch, stage_ms = eq.backend.profile_read()
     eq.backend.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = max(ctx.gather(el))
 
     ms_per_step = el / args.steps * 1e3
     mcells = cells * args.steps / el / 1e6
@@ -244,7 +322,8 @@ def main():
         "config": {"workload": workload, "grid": list(n), "cells": cells, "integrator": "RK3", "cfl": 0.5,
                    "arithmetic_mode": args.mode, "parallelism": f"slab{world}" if world > 1 else "single",
                    "halo_overlap": overlap_note, "prewarm_steps": args.prewarm,
-                   "exchange": "n/a" if world == 1 else ("libhiplsm RCCL (lsm_advance_rk3 on a slab)" if eq.lib_comm else
+                   "exchange": "n/a" if world == 1 else ("libhiplsm in-process transport (lsm_advance_rk3 on a slab)" if eq.lib_comm and ctx.transport == "local" else
+                                                             "libhiplsm RCCL (lsm_advance_rk3 on a slab)" if eq.lib_comm else
                                                              "torch.distributed fallback" + (f" (library communicator failed: {overlap_fallback})" if overlap_fallback else ""))},
         # `bound` names the roofline BASELINE.json asks this metric to be priced against (HBM); the resource that actually holds
         # this kernel is the fp64 vector pipe (bound_actual; the roofline_compute block below)
@@ -302,10 +381,13 @@ def main():
                                          f"reference runs; {t1:.1f} s)",
                                "all_cores": {"value": round(vN, 4), "cores": nthr, "seconds": round(tN, 2),
                                              "sample": f"2 RK3 steps on {args.n}^3, OpenMP over the outer dimension"}}
+    if ctx.transport == "local" and world > 1:
+        # a rehearsal on ONE device: say so where a reader of the line looks first
+        out["n_gpus"] = 1
+        out["config"]["ranks"] = world
+        out["config"]["transport"] = f"in-process ({world} rank threads sharing device 0; device-to-device copies stand in for xGMI)"
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

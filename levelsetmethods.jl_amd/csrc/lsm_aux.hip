@@ -530,7 +530,13 @@ __global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, con
             // the in-plane rotation's speed does not depend on the march index: one evaluation per column that holds a band node
             // (same operations on the same operands as the per-node form below: the maximum is bit-identical)
             unsigned anyb = 0;
-            for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) anyb |= a.mask[cbase + m * a.s2];
+            if (a.rowbits) {
+                const unsigned* wr = a.rowbits + (size_t)tile * (size_t)(a.ty * a.tm) + ly;
+                for (int i = 0; i < a.tm && mlo + i < a.n[2]; ++i) anyb |= wr[a.ty * i];
+                anyb = (anyb >> lx) & 1u;
+            } else {
+                for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) anyb |= a.mask[cbase + m * a.s2];
+            }
             if (!anyb) continue;
             const double u0 = -(c.v[0] * ((a.lc[1] + (double)g1 * a.h[1]) - c.v[2]));
             const double u1 = c.v[0] * ((a.lc[0] + (double)g0 * a.h[0]) - c.v[1]);
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(256) cfl_band_list_kernel(const CflArgs a, con
         }
         for (int m = mlo; m < mlo + a.tm && m < a.n[2]; ++m) {
             const long long q = cbase + m * a.s2;
-            if (!a.mask[q]) continue;
+            if (a.rowbits ? !((a.rowbits[(size_t)tile * (size_t)(a.ty * a.tm) + ly + a.ty * (m - mlo)] >> lx) & 1u) : !a.mask[q]) continue;
             double u[3] = {0, 0, 0};
             if constexpr (CKIND == LSM_COEFF_CONST) {
 #pragma unroll

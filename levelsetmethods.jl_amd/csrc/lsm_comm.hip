@@ -179,7 +179,6 @@ Planes planes_of(const LsmHandle* h, size_t es) {
 }
 // first plane this rank sends up / down (src/boundaryconditions.jl:107-119: nodes 1 and n coincide on a periodic
 // dimension, so across the wrap the sender skips its duplicate end node)
-inline int send_up_from(const LsmComm* c, const Planes& p) { return p.nloc - p.G - (c->wrap_up ? 1 : 0); }
 inline int send_dn_from(const LsmComm* c) { return c->wrap_dn ? 1 : 0; }
 
 int comm_failed(LsmHandle* h, LsmComm* c, const char* what) {
@@ -677,10 +676,16 @@ int lsm_halo_start(LsmHandle* h, void* field) {
     LsmComm* c = h->comm;
     if (!c) return lsm_fail(h, LSM_ERR_INVALID, "lsm_halo_start: no communicator attached (lsm_comm_attach_rccl / _local)");
     const Planes p = planes_of(h, esize(h));
+    // Only the planes a stencil of the step in progress reads travel (g = 3 for WENO5, 2 for the ENO2 terms, 1 for
+    // upwind / curvature — src/derivatives.jl:89-121, src/levelsetterms.jl:156-170, src/levelsetops.jl:234-244): the d planes
+    // nearest the interface, into the d ghost planes nearest the receiver's interior.  d = LsmHandle::ghost_depth: set from the
+    // term list by lsm_advance_* on every rank alike, LSM_GHOST outside a step (lsm_halo_exchange called by the host).
+    const int d = h->ghost_depth >= 1 && h->ghost_depth <= p.G ? h->ghost_depth : p.G;
+    if (d == p.G) h->slab_depth_valid = p.G;        // a full-depth exchange (any call from outside a step) makes every layer valid again
     Msg m;
-    const size_t nb = p.bytes(p.G);
-    if (c->up >= 0) { m.send_up = p.at(field, send_up_from(c, p)); m.n_send_up = nb; m.recv_up = p.at(field, p.nloc); m.n_recv_up = nb; }
-    if (c->dn >= 0) { m.recv_dn = p.at(field, -p.G); m.n_recv_dn = nb; m.send_dn = p.at(field, send_dn_from(c)); m.n_send_dn = nb; }
+    const size_t nb = p.bytes(d);
+    if (c->up >= 0) { m.send_up = p.at(field, p.nloc - d - (c->wrap_up ? 1 : 0)); m.n_send_up = nb; m.recv_up = p.at(field, p.nloc); m.n_recv_up = nb; }
+    if (c->dn >= 0) { m.recv_dn = p.at(field, -d); m.n_recv_dn = nb; m.send_dn = p.at(field, send_dn_from(c)); m.n_send_dn = nb; }
     return exchange_start(h, m, h->dtype == LSM_DTYPE_F32 ? ncclFloat : ncclDouble, esize(h), "lsm_halo_start");
 }
 

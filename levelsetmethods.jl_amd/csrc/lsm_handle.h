@@ -37,6 +37,9 @@ struct LsmHandle {
     // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
     int* d_act_list;
     int* d_work_list;
+    int* d_work_list_alt;              // lsm_band_update writes the new work list here while its halo kernel still walks the old one, then the two swap
+    hipStream_t band_stream;           // lsm_band_update: tile flags -> lists -> Δt prefetch run here, beside the halo search on the main stream
+    hipEvent_t band_ev[2];             // fork / join of that side chain
     int* d_stage_list;                 // stage pieces: tile | (bricks - 1) << 24 (lsm_band.hip, band_work_kernel)
     unsigned char* d_head;             // per tile: bricks of the stage piece starting there
     unsigned* d_lcounts;
@@ -46,6 +49,21 @@ struct LsmHandle {
     const void* halo_n_key;            // the device counter whose value lsm_band_status last read (NULL: unknown on the host)
     long long halo_n;
     unsigned nact, nwork, nface, nstage;   // list lengths; work tiles on a face of the grid; stage pieces
+    // Brick stage with the extrapolation folded in (stage_brick.h): band_halo_bits_kernel deals every halo-list entry to the brick
+    // parts (tile, 8 planes) that read it — a slab of `cap` codes and a counter per part.  Valid for exactly the band buffers named
+    // by the keys (lsm_band_update's arguments); void after anything else touched the list or the band (lsm_band_halo,
+    // lsm_band_retile, lsm_band_invalidate), and when a slab overflowed (lsm_band_status reads the flag).
+    struct BandFold {
+        unsigned* d_cnt; size_t cnt_cap;       // parts
+        unsigned* d_codes; size_t codes_cap;   // parts · cap words
+        int* d_ovf;
+        unsigned cap;
+        const void *key_count, *key_list, *key_mask, *key_tiles;
+        int key_mc;
+        long long key_cap;             // halo_cap of the list the slabs mirror
+        bool valid, pending;           // pending: dealt by the last update, overflow flag not yet read
+    } fold;
+    bool band_fold;                    // set around a stage of lsm_advance_band_*: the stage extrapolates the off-band nodes itself
     bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
     bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
@@ -53,6 +71,7 @@ struct LsmHandle {
     double* d_result;    // 16 doubles: [0..1] reductions, [2..6] lsm_band_status, [8..11] Δt of the next step prefetched by lsm_band_update
     double* h_result;    // pinned, 16 doubles
     double* h_result_dev;   // the same page as the device sees it: lsm_band_status's kernel writes its numbers there directly
+    unsigned long long status_ticket;   // lsm_band_status: the kernel's last store is the call's ticket ([13]); the host spins on it
     // Δt of a band, prefetched: when the terms of the last lsm_compute_cfl_band depend neither on t nor on a field (constants,
     // ROTATION, SEPARABLE without time factor, Eikonal), lsm_band_update runs their reductions over the NEW band right behind
     // its own kernels and lsm_band_status brings the results home in the read it does anyway — the next lsm_compute_cfl_band
@@ -88,7 +107,8 @@ struct LsmHandle {
     size_t ev_used;
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
-    int ghost_depth;               // ghost layers the fills write: LSM_GHOST, or what the step in progress reads (XRedirect)
+    int ghost_depth;               // ghost layers the fills write and the slab exchange sends: LSM_GHOST, or what the step in progress reads (XRedirect)
+    int slab_depth_valid;          // slab steps: ghost layers of ϕ (boundary conditions + neighbours' planes) the last step left valid
     unsigned* d_tail_ctr;          // ring of LSM_TAIL_SLOTS ticket counters of the dynamic tail (each launch resets its own)
     unsigned tail_ticket;          // host: launches that took a slot so far
     bool xredirect;                // set around the stages of a whole-grid lsm_advance_*: x ghosts are resolved by the stage kernel's loads

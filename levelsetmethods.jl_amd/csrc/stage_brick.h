@@ -39,9 +39,20 @@ struct BrickView {
     LSM_DEV double corner(int sa, int sb) const { return T0[sa * (A == 0 ? 1 : W) + sb * (B == 1 ? W : HW)]; }
 };
 
+#ifndef LSM_BRICK_PITCH
+#define LSM_BRICK_PITCH 44
+#endif
 struct BrickCfg {
     static constexpr int TX = 32, TY = 8, XL = 4;     // XL: elements in front of the tile's first node (>= G, rows start 16-byte aligned)
-    static constexpr int W = TX + 2 * XL;
+    static constexpr int W = TX + 2 * XL;             // elements of a row that are loaded
+    // Row pitch of the LDS brick.  A lane reads ITS band node's stencil: the 32 lanes of a half-wave are consecutive entries of the
+    // brick's node list (x fastest), i.e. runs of 8-12 nodes of three or four successive rows where the band's normal has an x
+    // component — and a run of row r + 1 lands on the banks of row r's run shifted by the pitch mod 32 (32 banks of 4 bytes for
+    // ds_read_b32, 64 for ds_read_b64 with 8-byte elements: the same in elements).  Pitch 40 (= 8 mod 32) stacks runs of more
+    // than 8 nodes onto each other's banks (profiles/r3/band_step: SQ_LDS_BANK_CONFLICT 4.48 M > SQ_ACTIVE_INST_LDS 3.41 M cycles);
+    // 44 (= 12 mod 32) keeps runs of up to 12 nodes of four successive rows apart: 0, 12, 24, 4 (+ 8 = 12 again).
+    static constexpr int WP = LSM_BRICK_PITCH;
+    static_assert(WP >= W && WP % 4 == 0, "rows hold the loaded elements and start on 16-byte boundaries");
 };
 
 // NT threads take BZ planes of a listed brick (StageArgs::brick_list: the band's active tiles, one brick of `mc` planes each;
@@ -50,11 +61,11 @@ struct BrickCfg {
 // 256 x 4 — 47 KB, three per CU, 2.5-fold halo — measured slower: 0.665 against 0.642 ms per 768³ step).
 template <int ADV, int NM, int CURV, int EIK, class ST, int AK, int NT, int BZ>
 __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsigned sub_per) {
-    constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, XL = BrickCfg::XL, W = BrickCfg::W;
+    constexpr int NDIM = 3, TX = BrickCfg::TX, TY = BrickCfg::TY, XL = BrickCfg::XL, W = BrickCfg::W, WP = BrickCfg::WP;
     constexpr int G = halo_of(ADV, NM, CURV, EIK);
-    constexpr int SEG = 16 / (int)sizeof(ST), NSEG = W / SEG;
-    constexpr int H = TY + 2 * G, HW = H * W, D = BZ + 2 * G;
-    constexpr int NROW = D * H, NV4 = NROW * NSEG;
+    constexpr int SEG = 16 / (int)sizeof(ST), NSEG = W / SEG, PSEG = WP / SEG;      // 16-byte segments of a row: loaded / pitch
+    constexpr int H = TY + 2 * G, HW = H * WP, D = BZ + 2 * G;
+    constexpr int NROW = D * H, NV4 = NROW * PSEG;
     constexpr int BPT = TX * TY * BZ / NT;                // mask bytes per thread: 8 or 4
     static_assert(XL >= G && XL % SEG == 0 && W % SEG == 0 && (BPT == 8 || BPT == 4) && NT % 64 == 0, "");
     __shared__ lsm_v4u vbrick[NV4];
@@ -62,7 +73,7 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     __shared__ int wsum[NT / 64];
     // gfx950 has 160 KB of LDS per CU (64 KB per workgroup on its predecessors: the fp64 instance would not launch there);
     // two workgroups of the largest instance must fit a CU
-    static_assert(2 * (sizeof(lsm_v4u) * NV4 + sizeof(unsigned short) * TX * TY * BZ + 64) <= 160 * 1024, "brick kernel: LDS budget of a gfx950 CU");
+    static_assert(2 * (sizeof(lsm_v4u) * NV4 + sizeof(unsigned short) * TX * TY * BZ + 512) <= 160 * 1024, "brick kernel: LDS budget of a gfx950 CU");
     const ST* brick = reinterpret_cast<const ST*>(vbrick);
 
     // the launch's workgroups in list order, dealt to the XCDs in contiguous ranges (TileOrder): the BZ-plane parts of a brick
@@ -81,7 +92,16 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     if (zb >= m1) return;
     const int nz = m1 - zb < BZ ? m1 - zb : BZ;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
+    // ---- 0. (fold) this part's entries: how many, and the first NT of them — the first loads issued (vector loads return in order)
+    const bool fold = a.fold_cnt != nullptr;
+    unsigned fcnt = 0, fcode0 = 0;
+    const unsigned* fslab = nullptr;
+    if (fold) {
+        const size_t part = (size_t)tile_id * sub_per + sub;
+        fslab = a.fold_codes + part * a.fold_cap;
+        fcnt = a.fold_cnt[part];
+        fcode0 = fslab[tid];            // independent of the count (a slab holds at least NT words; words beyond the count are stale, not used)
+    }
     // ---- 1. loads: the mask bytes first (vector loads return in order: the node list is built while the brick is in flight),
     //         then the brick with its halo, row by row: RPI rows of NSEG 16-byte segments per round of the workgroup
     unsigned long long mbytes;
@@ -96,8 +116,9 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     constexpr int RPI = NT / NSEG, NIT = (NROW + RPI - 1) / RPI, QZ = RPI / H, RY = RPI % H;
     lsm_v4u v[NIT];
     const int crow = tid / NSEG, cseg = tid - crow * NSEG;
+    const ST* cb;
     {
-        const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+        cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
         const bool cv = crow < RPI && bx0 - XL + cseg * SEG <= nx + G - 1;     // beyond: nothing a band node reads (zeros, no access)
         int zr = crow / H, yr = crow - zr * H;
 #pragma unroll
@@ -146,8 +167,70 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
-        if (crow < RPI && crow + k * RPI < NROW) vbrick[(crow + k * RPI) * NSEG + cseg] = v[k];
+        if (crow < RPI && crow + k * RPI < NROW) vbrick[(crow + k * RPI) * PSEG + cseg] = v[k];
     __syncthreads();
+    // ---- 2b. (fold) ϕ[I] of the off-band nodes this part's stencils read (src/meshfield.jl:481-511), straight into the LDS brick: what
+    //          lsm_band_prepare's gather (band_apply_kernel) would have stored in the stage input — the same list entries (nearest band
+    //          node and the slope neighbours _axis_slope picks, found once per band by band_halo_bits_kernel and dealt to the parts
+    //          that read them), the same arithmetic in the same order, rounded to the storage type as the store would.  The nearest
+    //          node and its slope neighbours are band nodes: their values are read from the brick when they lie inside it (almost
+    //          always), from the stage input otherwise.  The stage input's off-band entries in HBM stay stale: nothing else reads them
+    //          (lsm_api.hip, advance_band).
+    if (fold) {
+        ST* bw = reinterpret_cast<ST*>(vbrick);
+        // a nearest node lies within 3 nodes of its entry and the slope neighbour one further: a base 4 planes, rows and elements
+        // below the brick's corner keeps every offset of the fall-back loads non-negative
+        const ST* gb = uniform_ptr(cb - (4 * sm + 4 * sy + 4));
+        fcnt = fcnt < a.fold_cap ? fcnt : a.fold_cap;
+        for (unsigned k = (unsigned)tid; k < fcnt; k += NT) {
+            const unsigned code = k < (unsigned)NT ? fcode0 : fslab[k];
+            const int X = (int)(code & 63u) - 4, Y = (int)((code >> 6) & 15u) - 3, Z = (int)((code >> 10) & 15u) - 3;
+            // (the dealer assumes the widest stencil: this kernel's box may be smaller)
+            if (X < -G || X >= TX + G || Y < -G || Y >= TY + G || Z < -G || Z >= BZ + G) continue;
+            const int o[3] = {(int)((code >> 14) & 7u) - 3, (int)((code >> 17) & 7u) - 3, (int)((code >> 20) & 7u) - 3};
+            const unsigned sc = (code >> 23) & 63u;
+            const int PX = X + o[0], PY = Y + o[1], PZ = Z + o[2];
+            const bool inbox = PX >= 1 - XL && PX <= TX + XL - 2 && PY >= 1 - G && PY <= TY + G - 2 && PZ >= 1 - G && PZ <= BZ + G - 2;
+            double phiP, nbv[3];
+            if (inbox) {
+                const int lp = ((PZ + G) * H + (PY + G)) * WP + PX + XL;
+                const int ld[3] = {1, WP, HW};
+                phiP = (double)bw[lp];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned c = (sc >> (2 * d)) & 3u;
+                    nbv[d] = phiP;
+                    if (c != 0u && o[d] != 0) nbv[d] = (double)bw[c == 1u ? lp + ld[d] : lp - ld[d]];
+                }
+            } else {
+                const unsigned eo = (unsigned)(PZ + G + 4) * (unsigned)sm + (unsigned)(PY + G + 4) * (unsigned)sy + (unsigned)(PX + XL + 4);
+                const unsigned sdv[3] = {1u, (unsigned)sy, (unsigned)sm};
+                phiP = ldg<ST>(gb, (unsigned)sizeof(ST) * eo);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned c = (sc >> (2 * d)) & 3u;
+                    nbv[d] = phiP;
+                    if (c != 0u && o[d] != 0) nbv[d] = ldg<ST>(gb, (unsigned)sizeof(ST) * (c == 1u ? eo + sdv[d] : eo - sdv[d]));
+                }
+            }
+            double val = phiP;
+            {
+#pragma clang fp contract(off)          // band_apply_kernel's translation unit is built without contraction: the same roundings here
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned c = (sc >> (2 * d)) & 3u;
+                    const int delta = -o[d];                      // I - P
+                    if (delta == 0) continue;
+                    const double slope = c == 1u ? nbv[d] - phiP : (c == 2u ? phiP - nbv[d] : 0.0);
+                    const double t = (double)delta * slope;
+                    val = val + t;
+                }
+            }
+            const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
+            bw[((Z + G) * H + (Y + G)) * WP + X + XL] = (ST)((phiP == 0.0 || sv == sp) ? val : phiP);
+        }
+        __syncthreads();
+    }
     // ---- 3. one lane per band node
     const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
     PlaneTab pt;
@@ -158,7 +241,7 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
         const bool on = i < N;
         const unsigned code = nodes[on ? i : N - 1];
         const int x = code & 31, y = (code >> 5) & 7, z = code >> 8;
-        const int l = ((z + G) * H + (y + G)) * W + x + XL;
+        const int l = ((z + G) * H + (y + G)) * WP + x + XL;
         const unsigned eo = (unsigned)z * (unsigned)sm + (unsigned)y * (unsigned)sy + (unsigned)x;
         const NodeIO io{po, (unsigned)sizeof(ST) * eo, 8u * eo, zb + z + a.goff[2]};
         double pre_adv[3] = {0, 0, 0}, pre_nm[3] = {0, 0, 0}, pre_curv[3] = {0, 0, 0};
@@ -168,28 +251,37 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
         if constexpr (CURV != 0) coeff_prep<NDIM, 1, false, LSM_COEFF_CONST>(a.curv, a, gi0, gi1, pre_curv);
         NodeOps op;
         node_operands<NDIM, ADV, NM, CURV, EIK, ST, AK>(a, io, pre_adv, pre_nm, pre_curv, pt, op);
-        const BrickView<W, HW, ST> nv{{brick + l}, (double)brick[l]};
+        const BrickView<WP, HW, ST> nv{{brick + l}, (double)brick[l]};
         double r1 = 0.0, r2 = 0.0;
-        node_update<NDIM, ADV, NM, CURV, EIK, G, W, ST, true>(a, nv, op, r1, r2);
+        node_update<NDIM, ADV, NM, CURV, EIK, G, WP, ST, true>(a, nv, op, r1, r2);
         node_store<ST, true>(a, io, on, r1, r2);
     }
+}
+
+// is this launch a case for the brick kernel?  (adv / nm / curv: the pass's combination; asked by lsm_api.hip before it decides
+// whether the stage input's off-band nodes are extrapolated inside the brick kernel or by a launch of their own)
+inline bool bricks_applicable(int ADV, int NM, int CURV, const StageArgs& a) {
+    const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
+    if (env && env[0] == '0') return false;
+    if (!a.mask || !a.brick_list || a.mc <= 0 || a.nbrick_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return false;
+    if ((NM && a.nm.kind != LSM_COEFF_CONST) || (CURV && a.curv.kind != LSM_COEFF_CONST)) return false;
+    const int ak = ADV ? a.adv.kind : (int)LSM_COEFF_CONST;
+    if (ak != LSM_COEFF_CONST && ak != LSM_COEFF_ROTATION) return false;
+    if (a.me <= a.mb || getenv("LSM_STAGE_GENERIC")) return false;
+    // 16-byte rows: the aligned layout (lsm_create), 16-byte aligned arrays; 32-bit byte offsets inside a pass
+    const long long seg = a.f32 ? 4 : 2, lead = a.origin - LSM_GHOST * a.s2 - LSM_GHOST * a.s1;
+    if (lead < BrickCfg::XL || lead % seg || a.s1 % 8 || a.s2 % 8 || a.origin % 8) return false;
+    if (((unsigned long long)a.psi | (unsigned long long)a.mask) % 16ull) return false;
+    if ((long long)(16 + 2 * LSM_GHOST + 1 + 8) * a.s2 * 8 >= (1ll << 31)) return false;      // + 8: the fold's gathers reach 4 planes beyond the brick's box
+    if (a.fold_cnt && a.mc != 8 && a.mc != 16) return false;          // the fold deals the entries to parts of 8 planes of 8- or 16-plane tiles
+    return true;
 }
 
 // 0 = launched, -1 = not a case for the brick kernel (the caller goes on to stage_tile)
 template <int ADV, int NM, int CURV, int EIK>
 int launch_bricks(const StageArgs& a, hipStream_t s) {
-    const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
-    if (env && env[0] == '0') return -1;
-    if (!a.mask || !a.brick_list || a.mc <= 0 || a.nbrick_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return -1;
-    if ((NM && a.nm.kind != LSM_COEFF_CONST) || (CURV && a.curv.kind != LSM_COEFF_CONST)) return -1;
+    if (!bricks_applicable(ADV, NM, CURV, a)) return -1;
     const int ak = ADV ? a.adv.kind : (int)LSM_COEFF_CONST;
-    if (ak != LSM_COEFF_CONST && ak != LSM_COEFF_ROTATION) return -1;
-    if (a.me <= a.mb || getenv("LSM_STAGE_GENERIC")) return -1;
-    // 16-byte rows: the aligned layout (lsm_create), 16-byte aligned arrays; 32-bit byte offsets inside a pass
-    const long long seg = a.f32 ? 4 : 2, lead = a.origin - LSM_GHOST * a.s2 - LSM_GHOST * a.s1;
-    if (lead < BrickCfg::XL || lead % seg || a.s1 % 8 || a.s2 % 8 || a.origin % 8) return -1;
-    if (((unsigned long long)a.psi | (unsigned long long)a.mask) % 16ull) return -1;
-    if ((long long)(16 + 2 * LSM_GHOST + 1) * a.s2 * 8 >= (1ll << 31)) return -1;
     StageArgs b = a;
     b.nb[0] = (a.n[0] + BrickCfg::TX - 1) / BrickCfg::TX;
     b.nb[1] = (a.n[1] + BrickCfg::TY - 1) / BrickCfg::TY;

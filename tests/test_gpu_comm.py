@@ -297,3 +297,125 @@ except L.LsmCommError as e:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "COMM_ERROR" in r.stdout and "timed out" in r.stdout, (r.stdout, r.stderr[-2000:])
     assert 0.3 < float(r.stdout.split()[1]) < 3.0
+
+
+def _run_ranks(lsm, world, body, timeout=600):
+    """One thread per rank over an in-process group; returns what body(rank, comm) returned, rank by rank."""
+    import threading
+    import traceback
+    g = lsm.LocalGroup(world)
+    got, errs = [None] * world, []
+
+    def run(r):
+        try:
+            got[r] = body(r, g.rank(r))
+        except BaseException:   # noqa: BLE001 - reported by the main thread
+            errs.append((r, traceback.format_exc()))
+            g.abort()
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout)
+    assert not errs, errs
+    return got
+
+
+@pytest.mark.parametrize("case", ["upwind_periodic", "curvature", "normal_motion", "eikonal_periodic", "nm_curv_mixed"])
+@pytest.mark.parametrize("integ", ["rk3", "fe"])
+def test_slab_exchange_sends_only_the_planes_the_stencils_read(lsm, case, integ):
+    """the exchange depth is the reach of the step's stencils — 1 plane for upwind and curvature
+    (src/levelsetops.jl:234-244), 2 for the ENO2 terms (src/levelsetterms.jl:156-170), 3 for WENO5 (src/derivatives.jl:89-121).
+    Slab steps through the library (lsm_advance_* on LOCAL groups of 3 ranks, periodic ring included) with depth-1 and depth-2
+    term lists equal the single-device run bit for bit, over several steps (the ghost planes beyond the depth stay stale and
+    must never be read)."""
+    from lsm_amd import _lib as L
+    n, world = (22, 18, 41), 3
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), n)
+    ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.45) ** 2 + (x[1] - 0.5) ** 2 + (x[2] - 0.4) ** 2) - 0.27, grid)
+    terms, bc = {
+        "upwind_periodic": (lambda: (lsm.AdvectionTerm((0.6, -0.3, 0.9), lsm.Upwind()),), lsm.PeriodicBC()),
+        "curvature": (lambda: (lsm.CurvatureTerm(-0.05),), lsm.ExtrapolationBC(1)),
+        "normal_motion": (lambda: (lsm.NormalMotionTerm(0.8),), lsm.NeumannBC()),
+        "eikonal_periodic": (lambda: (lsm.EikonalReinitializationTerm(),), lsm.PeriodicBC()),
+        "nm_curv_mixed": (lambda: (lsm.NormalMotionTerm(-0.5), lsm.CurvatureTerm(-0.03)), (lsm.NeumannBC(), lsm.ExtrapolationBC(2), lsm.SymmetryBC())),
+    }[case]
+    I = {"rk3": lsm.RK3, "fe": lsm.ForwardEuler}[integ]
+    mk = lambda **kw: lsm.LevelSetEquation(terms=terms(), ic=ic, bc=bc, integrator=I(), **kw)
+    ref = mk()
+    tf = 4.2 * 0.5 * ref.compute_cfl(0.0)                 # a handful of steps, the last one cut
+    lsm.integrate_(ref, tf)
+    want = ref.current_state().values()
+
+    def body(r, comm):
+        eq = mk(comm=comm)
+        assert eq.lib_comm and eq.backend.comm_info() == (r, world, L.COMM_LOCAL)
+        lsm.integrate_(eq, tf)
+        return eq.current_state().values()
+
+    got = np.concatenate(_run_ranks(lsm, world, body), axis=2)
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+def test_slab_step_refreshes_its_ghosts_when_the_term_list_gets_deeper(lsm):
+    """A step leaves ϕ with as many valid ghost planes as its own stencils read.  A host that then steps the same field with a
+    deeper term list (curvature: 1 plane, then WENO5 advection: 3) must get the single-device result: the slab step notices
+    and refreshes all layers first."""
+    n, world = (20, 16, 36), 3
+    grid = lsm.CartesianGrid((0, 0, 0), (1, 1, 1), n)
+    ic = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.5) ** 2 + (x[1] - 0.5) ** 2 + (x[2] - 0.45) ** 2) - 0.3, grid)
+    shallow = lambda: (lsm.CurvatureTerm(-0.04),)
+    deep = lambda: (lsm.AdvectionTerm((0.5, 0.2, -0.8), lsm.WENO5()),)
+
+    # Δt of the two phases: node-independent (constant coefficients), the same on every rank
+    dt1 = 0.5 * lsm.LevelSetEquation(terms=shallow(), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3()).compute_cfl(0.0)
+    dt2 = 0.5 * lsm.LevelSetEquation(terms=deep(), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3()).compute_cfl(0.0)
+
+    def two_phases(**kw):
+        eq = lsm.LevelSetEquation(terms=shallow(), ic=ic, bc=lsm.NeumannBC(), integrator=lsm.RK3(), **kw)
+        eq._advance(0.0, dt1)
+        eq._advance(dt1, dt1)
+        # the SAME handle and field step on with the deep list, as a host that edits the equation's terms would
+        eq.terms = deep()
+        for t in eq.terms:
+            t._bind(grid, eq.backend, eq.slab)
+        eq._advance(2 * dt1, dt2)
+        return eq.current_state().values()
+
+    want = two_phases()
+    got = np.concatenate(_run_ranks(lsm, world, lambda r, comm: two_phases(comm=comm)), axis=2)
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+def test_eight_rank_local_group_on_the_scaling_runs_plane_shape(lsm):
+    """The 8-rank decomposition the driver's scaling run uses (1024 x 1024 planes, `bench.py --gpus 8`), rehearsed on one device:
+    eight rank threads over an in-process group, 12 planes each (the boundary-first order needs 2·(3+1)+1), two RK3 steps of the
+    headline equation through lsm_advance_rk3 — bit for bit the single-device step, the all-reduced Δt included."""
+    n, world = (1024, 1024, 96), 8
+    h = 1.0 / (n[0] - 1)
+    grid = lsm.CartesianGrid((0.0, 0.0, 0.0), tuple((k - 1) * h for k in n), n)
+    ic = lsm.LazyMeshField(lambda x: np.sqrt((x[0] - 0.35) ** 2 + (x[1] - 0.35) ** 2 + (x[2] - 0.04) ** 2) - 0.15, grid)
+
+    def steps(**kw):
+        eq = _equation(lsm, grid, ic, **kw)
+        tc, dts = 0.0, []
+        for _ in range(2):
+            eq._update_terms(eq.state, tc)
+            dt = 0.5 * eq.compute_cfl(tc)
+            eq._advance(tc, dt)
+            tc += dt
+            dts.append(dt)
+        return eq, dts
+
+    ref, want_dts = steps()
+    want = ref.current_state().values()
+    del ref
+
+    def body(r, comm):
+        eq, dts = steps(comm=comm)
+        assert eq.lib_comm and dts == want_dts, (dts, want_dts)
+        return eq.current_state().values()
+
+    got = np.concatenate(_run_ranks(lsm, world, body), axis=2)
+    assert got.shape == want.shape and np.array_equal(got, want), float(np.abs(got - want).max())
