@@ -119,8 +119,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->ghost_depth = LSM_GHOST;
     h->slab_depth_valid = LSM_GHOST;     // a slab's ghosts are the host's to make valid before its first step (include/lsm.h)
     h->status_ticket = 0;
-    memset(&h->fold, 0, sizeof(h->fold));
-    h->band_fold = false;
+    h->reinit_ws = nullptr;
     h->d_pf_flag = nullptr;
     memset(&h->band_cfl, 0, sizeof(h->band_cfl));
     h->cfl_prefetched = false;
@@ -132,7 +131,6 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->d_tiles_old = nullptr; h->work_cap = 0; h->halo_n_key = nullptr; h->halo_n = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
-    h->d_work_list_alt = nullptr; h->band_stream = nullptr; h->band_ev[0] = h->band_ev[1] = nullptr;
     h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_stage_list = nullptr; h->d_head = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
     h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
     h->no_lists = getenv("LSM_BAND_NO_LISTS") != nullptr;
@@ -243,12 +241,7 @@ void lsm_destroy(LsmHandle* h) {
     if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
     (void)hipFree(h->d_result);
     if (h->d_pf_flag) (void)hipFree(h->d_pf_flag);
-    if (h->d_work_list_alt) (void)hipFree(h->d_work_list_alt);
-    if (h->band_stream) { (void)hipStreamSynchronize(h->band_stream); (void)hipStreamDestroy(h->band_stream); }
-    for (auto e : h->band_ev) if (e) (void)hipEventDestroy(e);
-    if (h->fold.d_cnt) (void)hipFree(h->fold.d_cnt);
-    if (h->fold.d_codes) (void)hipFree(h->fold.d_codes);
-    if (h->fold.d_ovf) (void)hipFree(h->fold.d_ovf);
+    reinit_workspace_free(h->reinit_ws);
     (void)hipHostFree(h->h_result);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -379,7 +372,6 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.mask = h->band_mask; a.tile_active = h->band_tiles; a.mc = h->band_mc;
     a.tile_list = h->band_list; a.ntile_list = h->band_nlist;
     if (h->band_list) { a.brick_list = h->d_act_list; a.nbrick_list = h->nact; }
-    if (h->band_fold && h->band_list) { a.fold_cnt = h->fold.d_cnt; a.fold_codes = h->fold.d_codes; a.fold_cap = h->fold.cap; }
     a.f32 = is_f32(h);
     a.tail_ctr = nullptr; a.tail_wgs = 0;
     a.tail_ring = h->d_tail_ctr;          // stage_impl withdraws it from launches on a caller's stream
@@ -483,14 +475,6 @@ static int stage_impl(LsmHandle* h, const LsmTerm* terms, int nterms, const void
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = h->prof && (h->prof_seen++ % (unsigned long long)h->prof_every) == 0;
-        if (a.fold_cnt && !(h->mode != LSM_MODE_STRICT && N == 3 && stage_brick_applicable(c, a))) {
-            // this pass goes to the tiled stage, which reads its stencils from the stage input: extrapolate the off-band nodes there,
-            // once (lsm_band_fill_list), and let the passes that follow find them
-            const int rf = lsm_band_fill_list(h, const_cast<void*>(psi), h->band_mask, h->fold.key_list, h->fold.key_cap, h->fold.key_count);
-            if (rf) return rf;
-            h->band_fold = false;
-            a.fold_cnt = nullptr; a.fold_codes = nullptr;
-        }
         if (timed) { int r = profile_pair(h, &e0, &e1); if (r) return r; LSM_HIP(h, hipEventRecord(e0, s)); }
         int r;
         if (h->mode == LSM_MODE_STRICT)
@@ -1110,8 +1094,6 @@ static int ensure_ring(LsmHandle* h) {
 static int ensure_work(LsmHandle* h, int64_t ntiles) {
     if (h->work_cap >= ntiles) return LSM_OK;
     if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
-    if (h->d_work_list_alt) { (void)hipFree(h->d_work_list_alt); h->d_work_list_alt = nullptr; }
-    LSM_HIP(h, hipMalloc((void**)&h->d_work_list_alt, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_tiles_old, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_act_list, (size_t)ntiles * sizeof(int)));
@@ -1173,7 +1155,6 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
             launch_band_halo_bc(a, bc, d, LSM_GHOST, (const unsigned char*)mask, (unsigned char*)halo_mask, h->stream);
     if (halo_count) LSM_HIP(h, hipMemsetAsync(halo_count, 0, sizeof(unsigned), h->stream));
     h->halo_n_key = nullptr;
-    h->fold.valid = false; h->fold.pending = false;            // the list is re-made without its slabs
     launch_band_extrapolate(a, nullptr, (unsigned char*)halo_mask, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
                             vals, nullptr, h->d_miss, halo_count ? (BandEntry*)halo_list : nullptr,
                             (unsigned*)halo_count, halo_list && halo_count ? (unsigned)halo_cap : 0u, h->stream);
@@ -1187,8 +1168,8 @@ static bool band_cfl_node_dependent(const LsmTerm& tm) {
     return tm.kind != LSM_TERM_EIKONAL && tm.coeff.kind != LSM_COEFF_CONST;
 }
 static const int PF_PARTIALS = 2048;       // workgroups (partials) per prefetched reduction: 4 slots in the 2·MAXB doubles of d_partial
-static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, int mc, hipStream_t s = nullptr, const unsigned* rowbits = nullptr) {
-    if (!s) s = h->stream;
+static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, int mc, const unsigned* rowbits = nullptr) {
+    hipStream_t s = h->stream;
     LsmHandle::BandCfl& pf = h->band_cfl;
     pf.pending = false; pf.valid = false;
     static const bool off = getenv("LSM_BAND_CFL_PREFETCH") && getenv("LSM_BAND_CFL_PREFETCH")[0] == '0';   // A/B switch
@@ -1206,7 +1187,7 @@ static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, 
         a.rowbits = rowbits;                            // the new band's row words, still in the update's scratch (NULL: the byte mask)
         a.tx = ba.tx; a.ty = ba.ty; a.tm = ba.tm; a.nbx = ba.nbx; a.nby = ba.nby;
         if (launch_cfl_band_list(a, h->d_act_list, 0, h->d_lcounts, PF_PARTIALS, s) != PF_PARTIALS) return LSM_OK;   // tile shape not served: no prefetch
-        launch_cfl_final(a.partial, PF_PARTIALS, a.nanflag, h->d_result + 8 + sl, pf.terms[k].kind, h->dxmin, 1, s);
+        // (the second stage of the reduction is lsm_band_status's kernel)
     }
     LSM_HIP(h, hipGetLastError());
     pf.pending = true;
@@ -1258,78 +1239,28 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
         else act.work = (const unsigned char*)tiles;           // unchanged until the grow kernel
         const bool interior_b = listed && h->nface == 0;     // the new band lies in the old work tiles: none on a face
         const bool halo_bits = interior_b && halo_list && halo_count;
-        // the entries dealt to the brick parts that read them (lsm_band.hip, band_halo_bits_kernel; stage_brick.h): handle-owned slabs,
-        // FOLD_CAP codes per part of 8 planes — 8 KB per part, 1.8 GB at 768³ with 16-plane tiles: sized for a 288 GB device
-        LsmHandle::BandFold& f = h->fold;
-        f.valid = false; f.pending = false;
-        static const bool fold_env = !(getenv("LSM_BAND_FOLD") && getenv("LSM_BAND_FOLD")[0] == '0');     // A/B switch
-        const unsigned FOLD_CAP = 2048;           // >= 512 (the brick kernel reads a workgroup's worth of words unconditionally)
-        const size_t parts = (size_t)ntiles * (size_t)((mc + 7) / 8);
-        bool want_fold = fold_env && halo_bits && h->mode != LSM_MODE_STRICT && band_fold_fits(a);
-        if (want_fold && (f.cnt_cap < parts || f.cap != FOLD_CAP)) {
-            if (f.d_cnt) (void)hipFree(f.d_cnt);
-            if (f.d_codes) (void)hipFree(f.d_codes);
-            f.d_cnt = nullptr; f.d_codes = nullptr; f.cnt_cap = 0; f.codes_cap = 0; f.cap = FOLD_CAP;
-            if (!f.d_ovf && hipMalloc((void**)&f.d_ovf, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); f.d_ovf = nullptr; }
-            if (f.d_ovf && hipMalloc((void**)&f.d_cnt, parts * sizeof(unsigned)) == hipSuccess &&
-                hipMalloc((void**)&f.d_codes, parts * FOLD_CAP * sizeof(unsigned)) == hipSuccess) {
-                f.cnt_cap = parts; f.codes_cap = parts * FOLD_CAP;
-            } else {
-                (void)hipGetLastError();
-                if (f.d_cnt) (void)hipFree(f.d_cnt);
-                f.d_cnt = nullptr;
-                want_fold = false;                                  // no memory for the slabs: the gather launch stays
-            }
-        }
-        want_fold = want_fold && f.d_cnt && f.d_codes && f.d_ovf;
         launch_band_bits(act, vals, (const unsigned char*)mask, OB, LE, GE, (const unsigned char*)tiles, h->d_tiles_old,
-                         halo_bits ? (unsigned*)halo_count : nullptr, want_fold ? f.d_cnt : nullptr, (unsigned)parts, want_fold ? f.d_ovf : nullptr, h->stream);
+                         halo_bits ? (unsigned*)halo_count : nullptr, h->stream);
         launch_band_grow_bits(a, vals, (unsigned char*)mask, nlayers, h->d_tiles_old, (unsigned char*)tiles, OB, LE, GE, NB, h->d_miss, h->stream);
         LSM_HIP(h, hipGetLastError());
         h->lists_host_valid = false;                          // from here on the lists describe the previous band
-        h->fold.valid = false;
-        // What follows the grow kernel is two independent chains: the halo search of the new band (one VALU-bound launch over the
-        // OLD work list) and tile flags -> work flags -> compact lists -> Δt prefetch (four small latency-bound launches that
-        // read the new tile flags and row words).  With the old work list kept aside (the lists kernel writes the new one into the
-        // other buffer) the second chain runs on a stream of its own beside the first.  LSM_BAND_SIDE=0: one stream (A/B).
-        static const bool side_env = !(getenv("LSM_BAND_SIDE") && getenv("LSM_BAND_SIDE")[0] == '0');
-        hipStream_t side = h->stream;
-        if (side_env && listed && halo_bits) {
-            if (!h->band_stream) {
-                LSM_HIP(h, hipStreamCreateWithFlags(&h->band_stream, hipStreamNonBlocking));
-                for (auto& e : h->band_ev) LSM_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-            side = h->band_stream;
-            LSM_HIP(h, hipEventRecord(h->band_ev[0], h->stream));
-            LSM_HIP(h, hipStreamWaitEvent(side, h->band_ev[0], 0));
-        }
-        int* const new_work_list = side != h->stream ? h->d_work_list_alt : h->d_work_list;
-        auto lists_chain = [&]() -> int {
-            BandArgs full = band_args(h, mc, nullptr);
-            launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, side);
-            launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, new_work_list, h->d_stage_list, h->d_lcounts, side);
-            LSM_HIP(h, hipGetLastError());
-            return band_cfl_prefetch(h, mask, tiles, mc, side, NB);
-        };
-        if (side != h->stream) LSM_TRY(lists_chain());
+        // (Measured in round 4 and not kept: the chain below — four small latency-bound launches — on a stream of its own beside the
+        // halo search, with the old work list kept aside: 0.533 against 0.524 ms per 768³ step.  The 1024-thread workgroups of the
+        // lists kernel find no room while the search fills every CU, and the fork / join events cost what the overlap gives.)
         if (halo_bits) {
             h->halo_n_key = nullptr;                          // (the counter was cleared by band_bits_kernel)
             launch_band_halo_bits(a, (const unsigned char*)tiles, NB, (unsigned char*)halo_mask, h->d_miss, (BandEntry*)halo_list,
-                                  (unsigned*)halo_count, (unsigned)halo_cap, want_fold ? f.d_cnt : nullptr, f.d_codes, f.cap, f.d_ovf, h->stream);
+                                  (unsigned*)halo_count, (unsigned)halo_cap, h->stream);
             LSM_HIP(h, hipGetLastError());
-            if (want_fold) { f.key_count = halo_count; f.key_list = halo_list; f.key_mask = mask; f.key_tiles = tiles; f.key_mc = mc; f.key_cap = halo_cap; f.pending = true; }
         } else {
             LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior_b ? 1 : 0));
         }
-        if (side != h->stream) {
-            LSM_HIP(h, hipEventRecord(h->band_ev[1], side));
-            LSM_HIP(h, hipStreamWaitEvent(h->stream, h->band_ev[1], 0));
-            int* t = h->d_work_list; h->d_work_list = h->d_work_list_alt; h->d_work_list_alt = t;
-        } else {
-            LSM_TRY(lists_chain());
-        }
+        BandArgs full = band_args(h, mc, nullptr);
+        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
+        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
         h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
-        return LSM_OK;
+        LSM_HIP(h, hipGetLastError());
+        return band_cfl_prefetch(h, mask, tiles, mc, NB);
     }
     unsigned char *A = (unsigned char*)scratch_a, *B = (unsigned char*)scratch_b;
     const unsigned char* old_mask = from_dense ? nullptr : (const unsigned char*)mask;
@@ -1382,7 +1313,6 @@ int lsm_band_halo(LsmHandle* h, const void* vals, const void* mask, void* halo_m
 int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
     if (!h || !mask || !tiles || mc < 1) return LSM_ERR_INVALID;
     h->band_cfl.valid = false; h->band_cfl.pending = false;      // the mask was changed from outside
-    h->fold.valid = false; h->fold.pending = false;
     LSM_TRY(ensure_ring(h));
     BandArgs a = band_args(h, mc, nullptr);
     LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
@@ -1403,7 +1333,6 @@ int lsm_band_invalidate(LsmHandle* h) {
     h->lists_tiles = nullptr; h->lists_host_valid = false;
     h->halo_n_key = nullptr; h->halo_n = 0;
     h->band_cfl.valid = false; h->band_cfl.pending = false;
-    h->fold.valid = false; h->fold.pending = false;
     return LSM_OK;
 }
 
@@ -1476,9 +1405,15 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
     LSM_TRY(ensure_ring(h));
     // one gather kernel and ONE copy into pinned memory instead of three small copies into pageable memory (a host round trip each)
     // the kernel writes into the host's pinned page itself ([2..7] status, [8..11] prefetched Δt): no copy, one synchronisation
-    const bool fold_pending = h->fold.pending && h->fold.key_count == halo_count;
-    launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, h->band_cfl.pending ? h->d_result + 8 : nullptr,
-                       fold_pending ? h->fold.d_ovf : nullptr, h->h_result_dev + 2, (double)++h->status_ticket, h->stream);
+    BandStatusCfl sc;
+    memset(&sc, 0, sizeof(sc));
+    if (h->band_cfl.pending) {
+        sc.npartials = PF_PARTIALS; sc.partial = h->d_partial; sc.nanflag = h->d_pf_flag; sc.dxmin = h->dxmin;
+        for (int k = 0; k < h->band_cfl.nterms; ++k)
+            if (h->band_cfl.slot[k] >= 0) { sc.kind[h->band_cfl.slot[k]] = h->band_cfl.terms[k].kind; sc.n = h->band_cfl.slot[k] + 1 > sc.n ? h->band_cfl.slot[k] + 1 : sc.n; }
+    }
+    launch_band_status((const unsigned*)halo_count, h->d_miss, h->lists_tiles ? h->d_lcounts : nullptr, sc, h->h_result_dev + 2, (double)++h->status_ticket,
+                       h->stream);
     LSM_HIP(h, hipGetLastError());
     // The kernel writes its numbers into the host's pinned page and its ticket last: spin on the ticket (the stream is in order: all
     // that was queued before has finished when it appears) — a stream synchronisation costs the step tens of microseconds of
@@ -1501,11 +1436,6 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
             if (h->band_cfl.slot[k] >= 0) h->band_cfl.dt[k] = h->h_result[8 + h->band_cfl.slot[k]];
         h->band_cfl.pending = false;
         h->band_cfl.valid = true;
-    }
-    if (fold_pending) {      // every slab held its entries?
-        h->fold.valid = h->h_result[12] == 0.0; h->fold.pending = false;
-        static const bool dbg = getenv("LSM_BAND_FOLD_DEBUG") != nullptr;
-        if (dbg && !h->fold.valid) fprintf(stderr, "lsm: a fold slab overflowed (%u codes per part): the gather launch serves this band\n", h->fold.cap);
     }
     *missed = (int)h->h_result[3];
     if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->nstage = (unsigned)h->h_result[7]; h->lists_host_valid = true; }
@@ -1574,27 +1504,13 @@ static int band_check(LsmHandle* h, const LsmBand* b, const char* what) {
         return fail(h, LSM_ERR_INVALID, std::string(what) + ": incomplete LsmBand (mask, tiles, mc, halo_list, halo_count)");
     return LSM_OK;
 }
-// `fold`: the stage extrapolates the off-band nodes its bricks read itself (stage_brick.h) — band_ready then left them alone
 static int band_stage(LsmHandle* h, const LsmBand* b, const LsmTerm* terms, int nterms, const void* psi, const void* phin, void* out,
-                      void* out2, int base_mode, double cdt, double cdt2, double t, bool fold) {
-    h->band_fold = fold;
-    const int r = lsm_stage_band(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, b->mask, b->tiles, b->mc, nullptr);
-    h->band_fold = false;
-    return r;
+                      void* out2, int base_mode, double cdt, double cdt2, double t) {
+    return lsm_stage_band(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, b->mask, b->tiles, b->mc, nullptr);
 }
-static int band_ready(LsmHandle* h, const LsmBand* b, void* field, bool refresh, bool fold) {
+static int band_ready(LsmHandle* h, const LsmBand* b, void* field, bool refresh) {
     if (refresh && lsm_comm_band_overlap(h) > 0) LSM_TRY(lsm_band_overlap_values(h, field));
-    if (fold) return LSM_OK;
     return lsm_band_prepare(h, field, b->mask, b->halo_list, b->halo_cap, b->halo_count, b->tiles, b->mc);
-}
-// May the stages of this step fold the extrapolation in?  The codes must mirror exactly this band's list (keys), its length must
-// be known and within the capacity, no stencil may reach a ghost layer (the boundary fill reads extrapolated values from the
-// field itself), and no hook may look at a stage input.
-static bool band_can_fold(const LsmHandle* h, const LsmBand* b, LsmStageHook hook) {
-    const LsmHandle::BandFold& f = h->fold;
-    return !hook && f.valid && f.key_count == b->halo_count && f.key_list == b->halo_list && f.key_mask == b->mask && f.key_tiles == b->tiles &&
-           f.key_mc == b->mc && f.key_cap == b->halo_cap && h->grid.ndim == 3 && h->mode != LSM_MODE_STRICT && have_lists(h, b->tiles, b->mc) &&
-           h->nface == 0 && h->halo_n_key == b->halo_count && h->halo_n <= f.key_cap;
 }
 static int advance_band(LsmHandle* h, int integ, const LsmTerm* terms, int nterms, const LsmBand* b, void* phi, void* buf1, void* buf2,
                         double tc, double dt, LsmStageHook hook, void* user) {
@@ -1602,29 +1518,28 @@ static int advance_band(LsmHandle* h, int integ, const LsmTerm* terms, int nterm
     LSM_TRY(band_check(h, b, "lsm_advance_band"));
     const bool slabbed = lsm_comm_band_overlap(h) > 0;
     if (!slabbed) LSM_TRY(check_single_device(h));
-    const bool fold = band_can_fold(h, b, hook);
-    LSM_TRY(band_ready(h, b, phi, false, fold));
+    LSM_TRY(band_ready(h, b, phi, false));
     LSM_TRY(run_hook(h, hook, user, 0, phi, tc));
     if (integ == 0) {           // ForwardEuler: dst = copy of ϕ, updated on the band, copied back (:128-137) — only band entries matter
-        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
         BandArgs a = band_args(h, b->mc, nullptr);
         if (have_lists(h, b->tiles, b->mc)) { a.list = h->d_act_list; a.nlist = h->nact; }
         else a.work = (const unsigned char*)b->tiles;
         launch_band_copy_values(a, (const unsigned char*)b->mask, buf1, phi, h->stream);
         LSM_HIP(h, hipGetLastError());
     } else if (integ == 1) {    // RK2 (:143-164)
-        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc, fold));
-        LSM_TRY(band_ready(h, b, buf1, true, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, buf2, LSM_BASE_PSI, dt, 0.5 * dt, tc));
+        LSM_TRY(band_ready(h, b, buf1, true));
         LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
-        LSM_TRY(band_stage(h, b, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf1, buf2, phi, nullptr, LSM_BASE_OTHER, 0.5 * dt, 0.0, tc + dt));
     } else {                    // RK3 (:170-202)
-        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc, fold));
-        LSM_TRY(band_ready(h, b, buf1, true, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, phi, nullptr, buf1, nullptr, LSM_BASE_PSI, dt, 0.0, tc));
+        LSM_TRY(band_ready(h, b, buf1, true));
         LSM_TRY(run_hook(h, hook, user, 1, buf1, tc + dt));
-        LSM_TRY(band_stage(h, b, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt, fold));
-        LSM_TRY(band_ready(h, b, buf2, true, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf1, phi, buf2, nullptr, LSM_BASE_RK3_S2, 0.25 * dt, 0.0, tc + dt));
+        LSM_TRY(band_ready(h, b, buf2, true));
         LSM_TRY(run_hook(h, hook, user, 2, buf2, tc + 0.5 * dt));
-        LSM_TRY(band_stage(h, b, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt, fold));
+        LSM_TRY(band_stage(h, b, terms, nterms, buf2, phi, phi, nullptr, LSM_BASE_RK3_S3, (2.0 / 3) * dt, 0.0, tc + 0.5 * dt));
     }
     if (slabbed) LSM_TRY(lsm_band_overlap_values(h, phi));
     return LSM_OK;
@@ -1660,7 +1575,7 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
     long long counts[3] = {0, 0, 0};
     const char* err = nullptr;
     const int r = reinit_run(N, h->nloc, h->goff, h->lay.stride[1], h->lay.stride[2], h->lay.origin, h->lay.total, lc, h->h, order, upsample, maxiters, xtol, ftol,
-                             phi, is_f32(h), (const unsigned char*)mask, work, h->stream, counts, &err);
+                             phi, is_f32(h), (const unsigned char*)mask, work, h->stream, counts, &err, &h->reinit_ws);
     if (r == 1) return fail(h, LSM_ERR_INVALID, err ? err : "lsm_reinitialize");
     if (r) return fail(h, LSM_ERR_HIP, err ? err : "lsm_reinitialize");
     if (ncandidate_cells) *ncandidate_cells = counts[0];

@@ -255,12 +255,21 @@ __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned cha
 // the numbers lsm_band_status hands to the host, gathered into one pinned-memory copy: {halo entries wanted, search misses,
 // active tiles, work tiles, face tiles, stage pieces}
 // `out` is the host's pinned page: the last word written, behind a system-scope fence, is the call's ticket — the host spins on it
-// instead of paying a stream synchronisation's wake-up (tens of microseconds of idle GPU per step)
-__global__ void band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, const int* fold_ovf,
-                                   double* out, double ticket) {
-    if (threadIdx.x < 4 && prefetched) out[6 + threadIdx.x] = prefetched[threadIdx.x];      // Δt of the next step (LsmHandle::BandCfl)
+// instead of paying a stream synchronisation's wake-up (tens of microseconds of idle GPU per step).
+// pf.n > 0: Δt of the next step, prefetched (LsmHandle::BandCfl) — this kernel is also the second stage of those reductions
+// (cfl_final_kernel's arithmetic on the partial maxima of cfl_band_list_kernel): one small launch less per step.
+__global__ void __launch_bounds__(64) band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, BandStatusCfl pf, double* out,
+                                                         double ticket) {
+    for (int s = 0; s < pf.n; ++s) {
+        double best = 0.0;
+        for (int i = threadIdx.x; i < pf.npartials; i += 64) { const double v = pf.partial[s * pf.npartials + i]; best = v > best ? v : best; }
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+        if (threadIdx.x == 0) {
+            const double cfl = pf.kind[s] == LSM_TERM_CURVATURE ? (pf.dxmin * pf.dxmin) / (2 * best) : 1 / best;
+            out[6 + s] = pf.nanflag[s] ? __builtin_nan("") : cfl;
+        }
+    }
     if (threadIdx.x == 0) {
-        out[10] = fold_ovf ? (double)fold_ovf[0] : 0.0;                                    // a fold slab overflowed (LsmHandle::BandFold)
         out[0] = (double)halo_count[0];
         out[1] = (double)miss[0];
         out[2] = lcounts ? (double)lcounts[0] : 0.0;
@@ -901,19 +910,13 @@ __device__ __forceinline__ unsigned nearest_key(const u64* B, const unsigned* xk
 
 __global__ void __launch_bounds__(256) band_bits_kernel(BandArgs a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE,
                                                         unsigned* GE, unsigned ntile_blocks, const unsigned char* flags_src,
-                                                        unsigned char* flags_dst, unsigned nflags, unsigned* zero0, unsigned* zero_arr, unsigned nzero,
-                                                        int* zero1) {
+                                                        unsigned char* flags_dst, unsigned nflags, unsigned* zero0) {
     if (blockIdx.x >= ntile_blocks) {
         // the workgroups behind the tiles' copy the old band's tile flags aside (the update writes the new ones in place) and clear the
-        // halo list's counter and the fold's per-part counters (nzero <= 2 per flag): small launches less per step
+        // halo list's counter: two small launches less per step
         const unsigned c = (blockIdx.x - ntile_blocks) * 4096u + threadIdx.x * 16u;
         for (unsigned k = c; k < c + 16u && k < nflags; ++k) flags_dst[k] = flags_src[k];
-        if (zero_arr)
-            for (unsigned k = 2u * c; k < 2u * c + 32u && k < nzero; ++k) zero_arr[k] = 0u;
-        if (blockIdx.x == ntile_blocks && threadIdx.x == 0) {
-            if (zero0) *zero0 = 0u;
-            if (zero1) *zero1 = 0;
-        }
+        if (blockIdx.x == ntile_blocks && threadIdx.x == 0 && zero0) *zero0 = 0u;
         return;
     }
     const unsigned tile = LSM_TILE_ID(a);
@@ -1107,18 +1110,8 @@ __global__ void __launch_bounds__(256) band_grow_bits_kernel(BandArgs a, void* v
 
 // halo mask and (node, nearest band node) list of the new band from its row words; interior bands only (no boundary-condition
 // sources pre-marked in halo[]): the halo bytes of every visited tile are written whole, no clearing pass
-// fold (may be NULL): every entry once more, DEALT TO THE BRICKS THAT READ IT (stage_brick.h, "fold").  The brick stage gives 8 planes of
-// an active tile to a workgroup, whose stencils reach G <= 3 nodes beyond those 32 x 8 x 8 nodes along one axis and (curvature's edge
-// diagonals) one node along two: an entry is wanted by the brick part that holds it and by up to three face and three edge neighbours.
-// Each such (tile, part) owns a slab of `cap` 32-bit words — position in the part's box (x + 4 | y + 3 << 6 | plane + 3 << 10), offset to
-// the nearest band node + 3 per axis (3 bits each from bit 14), slope choices (6 bits from bit 23) — filled through a per-part counter
-// (one global atomic per destination and workgroup; the counters are zeroed by band_bits_kernel).  A part then extrapolates exactly
-// its own entries, straight into its LDS brick, instead of a gather launch writing all of them to the stage input.  A slab that
-// overflows raises *ovf: the host keeps the gather launch for this band.
-struct FoldOut { unsigned* cnt; unsigned* codes; unsigned cap; int* ovf; };
-constexpr int FOLD_BZ = 8;       // planes per brick part: stage_brick.h's BZ
 __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo,
-                                                             int* miss, BandEntry* list, unsigned* list_count, unsigned list_cap, FoldOut fold) {
+                                                             int* miss, BandEntry* list, unsigned* list_count, unsigned list_cap) {
     const unsigned tile = LSM_TILE_ID(a);
     if (a.work && !a.work[tile]) return;
     const int x0 = (tile % a.nbx) * a.tx, y0 = ((tile / a.nbx) % a.nby) * a.ty, m0 = (tile / (a.nbx * a.nby)) * a.tm;
@@ -1206,9 +1199,7 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
     if (threadIdx.x == 0) s_base = list ? atomicAdd(list_count, tot) : 0u;
     __syncthreads();
     const unsigned base = s_base;
-    unsigned* cl = reinterpret_cast<unsigned*>(wl + 32 * wpt);          // fold: the entries' codes, tile-local (0xffffffff: none)
     for (unsigned k = threadIdx.x; k < tot; k += blockDim.x) {
-        if (fold.cnt) cl[k] = 0xffffffffu;
         const unsigned code16 = wl[k];
         const int row = (int)(code16 >> 5), tx_ = (int)(code16 & 31u), ry = row % a.ty, i = row / a.ty;
         const int lx = tx_ + ap, r = (ry + ap) + by * (i + ap);
@@ -1221,8 +1212,6 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
         if (ox) sc |= ((B[rP] >> (lxP + 1)) & 1ull) ? 1u : (((B[rP] >> (lxP - 1)) & 1ull) ? 2u : 0u);
         if (oy) sc |= (((B[rP + 1] >> lxP) & 1ull) ? 1u : (((B[rP - 1] >> lxP) & 1ull) ? 2u : 0u)) << 2;
         if (oz) sc |= (((B[rP + by] >> lxP) & 1ull) ? 1u : (((B[rP - by] >> lxP) & 1ull) ? 2u : 0u)) << 4;
-        if (fold.cnt) cl[k] = (unsigned)tx_ | ((unsigned)ry << 5) | ((unsigned)i << 8) | ((unsigned)(ox + 3) << 12) | ((unsigned)(oy + 3) << 15) |
-                              ((unsigned)(oz + 3) << 18) | (sc << 21);
         if (!list || base + k >= list_cap) continue;
         BandEntry e;
         e.q = a.origin + (x0 + tx_) + (long long)(y0 + ry) * a.s1 + (long long)(m0 + i) * a.s2;
@@ -1230,61 +1219,6 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
         e.d[0] = (signed char)(-ox); e.d[1] = (signed char)(-oy); e.d[2] = (signed char)(-oz);      // I - P
         e.d[3] = (signed char)(0x40u | sc);                                // 0x40: the slope neighbours are resolved (2 bits per axis)
         list[base + k] = e;
-    }
-    if (!fold.cnt) return;
-    // ---- deal the entries to the brick parts that read them
-    __shared__ unsigned d_cnt[54], d_base[54];
-    const int sub_per = a.tm / FOLD_BZ;                       // parts per tile (the launcher checks tm = 8 or 16)
-    for (int t = threadIdx.x; t < 54; t += blockDim.x) d_cnt[t] = 0u;
-    __syncthreads();
-    // the destinations of entry (x, y, i): calls f(counter index, tile offset, part, box position) for each
-    auto dests = [&](unsigned code, auto f) {
-        const int x = (int)(code & 31u), y = (int)((code >> 5) & 7u), i = (int)((code >> 8) & 15u);
-        const int s0 = i / FOLD_BZ, zs = i - s0 * FOLD_BZ;
-        // per axis: the entry lies inside (0) and, near a face, `e` nodes outside the neighbour on that side
-        const int ax[3] = {x < LSM_GHOST ? -1 : (x >= a.tx - LSM_GHOST ? 1 : 0), y < LSM_GHOST ? -1 : (y >= a.ty - LSM_GHOST ? 1 : 0),
-                           zs < LSM_GHOST ? -1 : (zs >= FOLD_BZ - LSM_GHOST ? 1 : 0)};
-        const int ex[3] = {ax[0] < 0 ? x + 1 : a.tx - x, ax[1] < 0 ? y + 1 : a.ty - y, ax[2] < 0 ? zs + 1 : FOLD_BZ - zs};
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {                          // which axes leave the part: none, one (within G), two (within 1 each)
-            const int o0 = (m & 1) ? ax[0] : 0, o1 = (m & 2) ? ax[1] : 0, o2 = (m & 4) ? ax[2] : 0;
-            if (((m & 1) && !ax[0]) || ((m & 2) && !ax[1]) || ((m & 4) && !ax[2])) continue;
-            const int nout = (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1);
-            if (nout == 3) continue;
-            if (nout == 2 && (((m & 1) && ex[0] > 1) || ((m & 2) && ex[1] > 1) || ((m & 4) && ex[2] > 1))) continue;
-            const int sg = s0 + o2, dm = sg < 0 ? -1 : (sg >= sub_per ? 1 : 0), sub = sg - dm * sub_per;
-            const int di = (o0 + 1) + 3 * (o1 + 1) + 9 * (dm + 1);
-            if (!nbflag[di]) continue;                          // no band node in that tile (or no such tile): no brick there
-            const unsigned pos = (unsigned)(x - a.tx * o0 + 4) | ((unsigned)(y - a.ty * o1 + 3) << 6) | ((unsigned)(i - (a.tm * dm + FOLD_BZ * sub) + 3) << 10);
-            f(2 * di + sub, o0 + (int)a.nbx * (o1 + (int)a.nby * dm), sub, pos);
-        }
-    };
-    for (unsigned k = threadIdx.x; k < tot; k += blockDim.x) {
-        const unsigned code = cl[k];
-        if (code == 0xffffffffu) continue;
-        dests(code, [&](int idx, int, int, unsigned) { atomicAdd(&d_cnt[idx], 1u); });
-    }
-    __syncthreads();
-    if (threadIdx.x < 54) {
-        const int idx = (int)threadIdx.x, di = idx >> 1, sub = idx & 1;
-        const unsigned c = d_cnt[idx];
-        unsigned b = 0;
-        if (c) {
-            const long long dt = (long long)tile + ((di % 3) - 1) + (long long)a.nbx * (((di / 3) % 3 - 1) + (long long)a.nby * (di / 9 - 1));
-            b = atomicAdd(&fold.cnt[(size_t)dt * sub_per + sub], c);
-            if (b + c > fold.cap) atomicOr(fold.ovf, 1);
-        }
-        d_base[idx] = b;
-        d_cnt[idx] = 0u;                                      // now the running position inside the reserved range
-    }
-    __syncthreads();
-    for (unsigned k = threadIdx.x; k < tot; k += blockDim.x) {
-        const unsigned code = cl[k];
-        if (code == 0xffffffffu) continue;
-        dests(code, [&](int idx, int toff, int sub, unsigned pos) {
-            const unsigned at = d_base[idx] + atomicAdd(&d_cnt[idx], 1u);
-            if (at < fold.cap) fold.codes[((size_t)((long long)tile + toff) * sub_per + sub) * fold.cap + at] = pos | ((code >> 12) << 14);
-        });
     }
 }
 
@@ -1578,9 +1512,9 @@ void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s) {
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_zero_kernel, tile_grid(a), dim3(256), 0, s, a, out);
 }
-void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, const int* fold_ovf, double* out,
-                        double ticket, hipStream_t s) {
-    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, prefetched, fold_ovf, out, ticket);
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const BandStatusCfl& pf, double* out, double ticket,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, pf, out, ticket);
 }
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
@@ -1601,12 +1535,10 @@ bool band_bits_fit(const BandArgs& a, int nl) {
     return fast3(a, BAP, 5) && nl >= 0 && nl + 1 <= BAP && a.tm >= BAP && a.ty * a.tm <= 128;
 }
 void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE,
-                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, unsigned* zero_arr, unsigned nzero, int* zero1,
-                      hipStream_t s) {
+                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, hipStream_t s) {
     const unsigned nflags = a.nbx * a.nby * a.nbm, ntile_blocks = a.list ? a.nlist : nflags;
-    if (nzero > 2u * nflags) nzero = 2u * nflags;
     hipLaunchKernelGGL(band_bits_kernel, dim3(ntile_blocks + (nflags + 4095u) / 4096u), dim3(256), 0, s, a, v, mask, OB, LE, GE, ntile_blocks,
-                       flags_src, flags_dst, nflags, zero0, zero_arr, nzero, zero1);
+                       flags_src, flags_dst, nflags, zero0);
 }
 void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
                            const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s) {
@@ -1614,17 +1546,12 @@ void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int 
     const size_t lds = (size_t)5 * 8 * (a.ty + 2 * BAP) * (a.tm + 2 * BAP);
     hipLaunchKernelGGL(band_grow_bits_kernel, tile_grid(a), dim3(256), lds, s, a, v, mask, nl, old_tiles, tiles, OB, LE, GE, NB, miss);
 }
-bool band_fold_fits(const BandArgs& a) { return a.ndim == 3 && a.tx == 32 && a.ty == 8 && (a.tm == FOLD_BZ || a.tm == 2 * FOLD_BZ); }
 void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
-                           unsigned* list_count, unsigned list_cap, unsigned* fold_cnt, unsigned* fold_codes, unsigned fold_cap, int* fold_ovf,
-                           hipStream_t s) {
+                           unsigned* list_count, unsigned list_cap, hipStream_t s) {
     if (no_tiles(a)) return;
     const size_t wpt = (size_t)a.ty * a.tm;
-    const bool f = fold_cnt && fold_codes && fold_cap && fold_ovf && band_fold_fits(a);
-    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + wpt) + 128 * sizeof(unsigned) + (2 * wpt + 4) * sizeof(unsigned) + 64 * wpt +
-                       (f ? 128 * wpt : 0);
-    const FoldOut fo{f ? fold_cnt : nullptr, fold_codes, fold_cap, fold_ovf};
-    hipLaunchKernelGGL(band_halo_bits_kernel, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap, fo);
+    const size_t lds = (size_t)8 * ((a.ty + 2 * BAP) * (a.tm + 2 * BAP) + wpt) + 128 * sizeof(unsigned) + (2 * wpt + 4) * sizeof(unsigned) + 64 * wpt;
+    hipLaunchKernelGGL(band_halo_bits_kernel, tile_grid(a), dim3(256), lds, s, a, tiles, NB, halo, miss, list, list_count, list_cap);
 }
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s) {

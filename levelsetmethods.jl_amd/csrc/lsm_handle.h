@@ -37,9 +37,6 @@ struct LsmHandle {
     // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
     int* d_act_list;
     int* d_work_list;
-    int* d_work_list_alt;              // lsm_band_update writes the new work list here while its halo kernel still walks the old one, then the two swap
-    hipStream_t band_stream;           // lsm_band_update: tile flags -> lists -> Δt prefetch run here, beside the halo search on the main stream
-    hipEvent_t band_ev[2];             // fork / join of that side chain
     int* d_stage_list;                 // stage pieces: tile | (bricks - 1) << 24 (lsm_band.hip, band_work_kernel)
     unsigned char* d_head;             // per tile: bricks of the stage piece starting there
     unsigned* d_lcounts;
@@ -49,21 +46,6 @@ struct LsmHandle {
     const void* halo_n_key;            // the device counter whose value lsm_band_status last read (NULL: unknown on the host)
     long long halo_n;
     unsigned nact, nwork, nface, nstage;   // list lengths; work tiles on a face of the grid; stage pieces
-    // Brick stage with the extrapolation folded in (stage_brick.h): band_halo_bits_kernel deals every halo-list entry to the brick
-    // parts (tile, 8 planes) that read it — a slab of `cap` codes and a counter per part.  Valid for exactly the band buffers named
-    // by the keys (lsm_band_update's arguments); void after anything else touched the list or the band (lsm_band_halo,
-    // lsm_band_retile, lsm_band_invalidate), and when a slab overflowed (lsm_band_status reads the flag).
-    struct BandFold {
-        unsigned* d_cnt; size_t cnt_cap;       // parts
-        unsigned* d_codes; size_t codes_cap;   // parts · cap words
-        int* d_ovf;
-        unsigned cap;
-        const void *key_count, *key_list, *key_mask, *key_tiles;
-        int key_mc;
-        long long key_cap;             // halo_cap of the list the slabs mirror
-        bool valid, pending;           // pending: dealt by the last update, overflow flag not yet read
-    } fold;
-    bool band_fold;                    // set around a stage of lsm_advance_band_*: the stage extrapolates the off-band nodes itself
     bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
     bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
     double* d_partial;   // 2 * MAXB doubles
@@ -105,6 +87,7 @@ struct LsmHandle {
     unsigned long long prof_seen;   // stage launches since lsm_profile_enable / lsm_profile_read
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used;
+    lsm::ReinitWorkspace* reinit_ws;   // reinitialize!'s device buffers, kept between calls (grow-only)
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
     int ghost_depth;               // ghost layers the fills write and the slab exchange sends: LSM_GHOST, or what the step in progress reads (XRedirect)

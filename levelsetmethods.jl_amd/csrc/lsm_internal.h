@@ -95,13 +95,6 @@ struct StageArgs {
     unsigned ntile_list;
     const int* brick_list;             // narrow band: the active tiles, one brick of `mc` planes each (stage_brick.h; NULL = none)
     unsigned nbrick_list;
-    // narrow band, brick stage: ϕ[I] of the off-band nodes a brick part's stencils read is extrapolated inside the brick kernel, into
-    // its LDS brick (stage_brick.h, "fold"), instead of by a gather launch into the stage input.  fold_cnt[tile · parts + part] entries
-    // at fold_codes[(tile · parts + part) · fold_cap ...], dealt by band_halo_bits_kernel; NULL = the stage input's off-band nodes hold
-    // their values already.
-    const unsigned* fold_cnt;
-    const unsigned* fold_codes;
-    unsigned fold_cap;
     int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
     unsigned long long* stamp;         // diagnostic build (-DLSM_STAMP, `make stamp`): per-workgroup {Δs_memtime, Δs_memrealtime} of the plane loop
 };
@@ -190,20 +183,24 @@ void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s);
 // bit-row path of update_band! (lsm_band.hip)
 bool band_bits_fit(const BandArgs& a, int nl);
 void launch_band_bits(const BandArgs& a, const void* v, const unsigned char* mask, unsigned* OB, unsigned* LE, unsigned* GE,
-                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, unsigned* zero_arr, unsigned nzero, int* zero1,
-                      hipStream_t s);
+                      const unsigned char* flags_src, unsigned char* flags_dst, unsigned* zero0, hipStream_t s);
 void launch_band_grow_bits(const BandArgs& a, void* v, unsigned char* mask, int nl, const unsigned char* old_tiles, unsigned char* tiles,
                            const unsigned* OB, const unsigned* LE, const unsigned* GE, unsigned* NB, int* miss, hipStream_t s);
 void launch_band_copy_values(const BandArgs& a, const unsigned char* mask, const void* src, void* dst, hipStream_t s);
-void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const double* prefetched, const int* fold_ovf, double* out,
-                        double ticket, hipStream_t s);
+struct BandStatusCfl {         // the prefetched Δt reductions lsm_band_status finishes: n slots of npartials partial maxima each
+    int n, npartials;
+    int kind[4];               // LSM_TERM_* of the slot's term
+    const double* partial;
+    const int* nanflag;
+    double dxmin;
+};
+void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const BandStatusCfl& pf, double* out, double ticket,
+                        hipStream_t s);
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,
                              BandEntry* list, unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_halo_bits(const BandArgs& a, const unsigned char* tiles, const unsigned* NB, unsigned char* halo, int* miss, BandEntry* list,
-                           unsigned* list_count, unsigned list_cap, unsigned* fold_cnt, unsigned* fold_codes, unsigned fold_cap, int* fold_ovf,
-                           hipStream_t s);
-bool band_fold_fits(const BandArgs& a);
+                           unsigned* list_count, unsigned list_cap, hipStream_t s);
 void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned* list_count, long long n_host, unsigned list_cap,
                        const unsigned char* src_mask, const void* src, void* dst, hipStream_t s);
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
@@ -217,9 +214,11 @@ void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned lo
 void stage_tile_shape(int ndim, int* tx, int* ty);
 
 // reinitialize! (lsm_reinit.hip)
+struct ReinitWorkspace;      // device buffers of reinitialize! kept between calls (lsm_reinit.hip); NULL workspace pointer = allocate and free per call
+void reinit_workspace_free(ReinitWorkspace* w);
 int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
                const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
-               void* out_field, hipStream_t stream, long long out_counts[3], const char** err);
+               void* out_field, hipStream_t stream, long long out_counts[3], const char** err, ReinitWorkspace** workspace);
 
 int interp_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3], const double h[3], int order,
                const void* phi, int f32, long long npts, const double* pts, double* val, double* grad, double* hess, hipStream_t stream, const char** err);
@@ -241,7 +240,6 @@ struct Combo {
 };
 // stage_brick.hip: the band stage with one lane per band node; -1 = not its case (the tiled kernels take the launch)
 int launch_stage_brick(const Combo& c, const StageArgs& a, hipStream_t s);
-bool stage_brick_applicable(const Combo& c, const StageArgs& a);      // would launch_stage_brick take this launch?
 
 // launchers implemented in stage_{fast,strict}.hip; return 0 if the combo is instantiated
 int launch_stage_fast(int ndim, const Combo& c, const StageArgs& a, hipStream_t s);

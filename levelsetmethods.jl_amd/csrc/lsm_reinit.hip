@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) reinit_nodes_kernel(ReinitArgs a, long lo
 // The same list for a band, built from a linear scan of the mask bytes, 16 per load: the band is ~1 % of a 3-D grid and
 // the node-indexed scan above spends its time on the other 99 % (one byte load and a 64-bit division per node).  One
 // global atomic per workgroup (a global atomic per wave serialises: ~10 ns each).  Mask bytes outside the grid are 0.
-__global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, long long total, long long* list, unsigned* count) {
+__global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, long long total, long long* list, long long cap, unsigned* count) {
     __shared__ unsigned blk_n, blk_base;
     const uint4* m4 = reinterpret_cast<const uint4*>(a.mask);        // hipMalloc'ed: 256-byte aligned
     const long long nvec = (total + 15) / 16;
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, lo
         __syncthreads();
         if (threadIdx.x == 0) blk_base = atomicAdd(count, blk_n);
         __syncthreads();
-        if (n && list) {                                   // list == NULL: count only
+        if (n && list) {                                   // list == NULL: count only; entries beyond `cap` are counted, not written
             unsigned at = blk_base + mine;
             for (int k = 0; k < 16; ++k) {
                 if (!((w[k >> 2] >> (8 * (k & 3))) & 0xffu)) continue;
@@ -530,7 +530,8 @@ __global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, lo
                 i0 = i0 < 0 ? 0 : (i0 > a.n[0] - 1 ? a.n[0] - 1 : i0);
                 i1 = i1 < 0 ? 0 : (i1 > a.n[1] - 1 ? a.n[1] - 1 : i1);
                 i2 = i2 < 0 ? 0 : (i2 > a.n[2] - 1 ? a.n[2] - 1 : i2);
-                list[at++] = i0 + (long long)a.n[0] * (i1 + (long long)a.n[1] * i2);
+                if ((long long)at < cap) list[at] = i0 + (long long)a.n[0] * (i1 + (long long)a.n[1] * i2);
+                ++at;
             }
         }
     }
@@ -1037,12 +1038,58 @@ struct SampleSet {
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
     unsigned long long* bits = nullptr;
+    // bytes allocated behind each pointer (grow(): a buffer is re-allocated only when a call needs more — the set of a NewtonSDF
+    // object is built once; the workspace of reinitialize! lives on the handle and stops allocating after the first calls)
+    size_t cap_cand_id = 0, cap_cand_cell = 0, cap_maybe = 0, cap_node_list = 0, cap_counters = 0, cap_pts = 0, cap_valid = 0, cap_cnt = 0, cap_blk = 0,
+           cap_bits = 0;
+    // workspace only: cand_id == -1, bits == 0 and blk == 0 everywhere for a grid of `clean_cells` cells — the state every band call
+    // starts from, and restores by un-marking its own candidate cells (reinit_unmark_kernel) instead of clearing arrays of the size of the grid
+    long long clean_cells = -1;
     void release() {
         (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(node_list); (void)hipFree(counters);
         (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(bits);
         cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; bits = nullptr;
+        cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = 0;
+        clean_cells = -1;
     }
 };
+template <class T>
+static hipError_t grow(T*& p, size_t& cap, size_t bytes, bool* fresh = nullptr) {
+    if (fresh) *fresh = false;
+    if (p && cap >= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;          // headroom: the band's size drifts from call to call
+    const hipError_t e = hipMalloc((void**)&p, want);
+    if (e == hipSuccess) { cap = want; if (fresh) *fresh = true; }
+    return e;
+}
+// the device buffers of reinitialize! kept between calls on one handle (LsmHandle::reinit_ws): eleven hipMalloc / hipFree pairs per
+// call were more than a third of a band call's 3.8 ms at 256³
+struct ReinitWorkspace {
+    SampleSet ss;
+    long long* seeds = nullptr;
+    size_t cap_seeds = 0;
+};
+void reinit_workspace_free(ReinitWorkspace* w) {
+    if (!w) return;
+    w->ss.release();
+    (void)hipFree(w->seeds);
+    delete w;
+}
+// band calls on a workspace: back to cand_id == -1, bits == 0, blk == 0 by visiting the candidate cells of the call that ends
+__global__ void __launch_bounds__(256) reinit_unmark_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int* cand_id, unsigned char* blk,
+                                                            unsigned long long* bits) {
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
+        const long long c = cand_cell[id];
+        cand_id[c] = -1;
+        int I[3];
+        cell_unlin(a, c, I);
+        const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
+        blk[blk_lin(a, B)] = 0;
+        bits[bits_row(a, I[1], I[2]) + I[0] / 64] = 0ull;        // every set bit of the word belongs to a candidate cell of this call
+    }
+}
 
 static int setup_args(ReinitArgs& a, int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, const double lc[3],
                       const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, const void* phi, int f32,
@@ -1059,8 +1106,9 @@ static int setup_args(ReinitArgs& a, int ndim, const int n[3], const int goff[3]
 }
 
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; ss.release(); return 2; } } while (0)
-// candidate cells -> interface samples -> per-cell counts, occupancy bits and blocks (steps 1 and 2 above); ss.a is set
-static int build_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err) {
+// candidate cells -> interface samples -> per-cell counts, occupancy bits and blocks (steps 1 and 2 above); ss.a is set.
+// `keep_clean`: ss is a workspace whose cand_id / bits / blk are restored by the caller after the call (band fields only)
+static int build_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err, bool keep_clean = false) {
     const ReinitArgs& a = ss.a;
     const int ndim = a.ndim;
     const int* n = a.n;
@@ -1069,10 +1117,19 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     ss.S = 1;
     for (int d = 0; d < ndim; ++d) ss.S *= a.upsample + 1;
     const int S = ss.S;
-    RE_HIP(hipMalloc((void**)&ss.cand_id, sizeof(int) * (size_t)nc));
-    RE_HIP(hipMalloc((void**)&ss.counters, 4 * sizeof(unsigned)));
+    bool fresh_id = false, fresh_blk = false, fresh_bits = false;
+    RE_HIP(grow(ss.cand_id, ss.cap_cand_id, sizeof(int) * (size_t)nc, &fresh_id));
+    RE_HIP(grow(ss.counters, ss.cap_counters, 4 * sizeof(unsigned)));
     unsigned nmaybe = 0, ncand = 0;
     RE_HIP(hipMemsetAsync(ss.counters, 0, 4 * sizeof(unsigned), stream));
+    size_t nblk = 1;
+    for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
+    size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
+    for (int d = 1; d < ndim; ++d) nwords *= (size_t)(n[d] - 1);
+    RE_HIP(grow(ss.blk, ss.cap_blk, nblk, &fresh_blk));
+    RE_HIP(grow(ss.bits, ss.cap_bits, sizeof(unsigned long long) * nwords, &fresh_bits));
+    const bool clean = keep_clean && a.mask && ss.clean_cells == nc && !fresh_id && !fresh_blk && !fresh_bits;
+    ss.clean_cells = -1;                       // until the caller has restored the state at the end of a successful call
     // band fields: the compact list of the active nodes first — candidate cells, the distance computation and the
     // commit all run over it (the band is ~1 % of a 3-D grid)
     const long long nodes = (long long)n[0] * n[1] * n[2];
@@ -1081,22 +1138,28 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
         unsigned nact = 0;
         const long long nvec = (total + 15) / 16;
         const unsigned gl = (unsigned)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, (long long*)nullptr, ss.counters + 3);
+        // the list is filled in ONE pass when the workspace already holds one (the band's size drifts slowly: the count is checked
+        // against the capacity afterwards); the first call counts first
+        const size_t have = ss.node_list ? ss.cap_node_list / sizeof(long long) : 0;
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, (long long)have, ss.counters + 3);
         RE_HIP(hipMemcpyAsync(&nact, ss.counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
-        RE_HIP(hipMalloc((void**)&ss.node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
-        RE_HIP(hipMemsetAsync(ss.counters + 3, 0, sizeof(unsigned), stream));
-        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, ss.counters + 3);
+        if (nact > have) {
+            RE_HIP(grow(ss.node_list, ss.cap_node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
+            RE_HIP(hipMemsetAsync(ss.counters + 3, 0, sizeof(unsigned), stream));
+            hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, (long long)(ss.cap_node_list / sizeof(long long)),
+                               ss.counters + 3);
+        }
         ss.nwork = nact;
-        RE_HIP(hipMemsetAsync(ss.cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
+        if (!clean) RE_HIP(hipMemsetAsync(ss.cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
     }
     const long long ncell_work = a.mask ? ss.nwork : nc;
     const unsigned gb = (unsigned)((ncell_work + 255) / 256 > 65535 ? 65535 : (ncell_work + 255) / 256);
-    RE_HIP(hipMalloc((void**)&ss.maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
+    RE_HIP(grow(ss.maybe, ss.cap_maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
     if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, ss.cand_id, ss.maybe, ss.counters, ss.node_list, ss.nwork);
     RE_HIP(hipMemcpyAsync(&nmaybe, ss.counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     RE_HIP(hipStreamSynchronize(stream));
-    RE_HIP(hipMalloc((void**)&ss.cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
+    RE_HIP(grow(ss.cand_cell, ss.cap_cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
     if (nmaybe) {
         const dim3 g2((nmaybe + 255) / 256), b2(256);
 #define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, nmaybe, ss.cand_id, ss.cand_cell, ss.counters + 1)
@@ -1115,19 +1178,15 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     ss.ncand = ncand;
     RE_HIP(hipMemsetAsync(ss.counters, 0, 3 * sizeof(unsigned), stream));
     const size_t slots = (size_t)(ncand ? ncand : 1) * S;
-    RE_HIP(hipMalloc((void**)&ss.pts, sizeof(double) * 3 * slots));
-    RE_HIP(hipMalloc((void**)&ss.valid, slots));
+    RE_HIP(grow(ss.pts, ss.cap_pts, sizeof(double) * 3 * slots));
+    RE_HIP(grow(ss.valid, ss.cap_valid, slots));
     RE_HIP(hipMemsetAsync(ss.valid, 0, slots, stream));
-    size_t nblk = 1;
-    for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
-    RE_HIP(hipMalloc((void**)&ss.cnt, (size_t)(ncand ? ncand : 1)));
-    RE_HIP(hipMalloc((void**)&ss.blk, nblk));
+    RE_HIP(grow(ss.cnt, ss.cap_cnt, (size_t)(ncand ? ncand : 1)));
     RE_HIP(hipMemsetAsync(ss.cnt, 0, (size_t)(ncand ? ncand : 1), stream));
-    RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
-    size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
-    for (int d = 1; d < ndim; ++d) nwords *= (size_t)(n[d] - 1);
-    RE_HIP(hipMalloc((void**)&ss.bits, sizeof(unsigned long long) * nwords));
-    RE_HIP(hipMemsetAsync(ss.bits, 0, sizeof(unsigned long long) * nwords, stream));
+    if (!clean) {
+        RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
+        RE_HIP(hipMemsetAsync(ss.bits, 0, sizeof(unsigned long long) * nwords, stream));
+    }
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
@@ -1143,16 +1202,24 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
 // returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
 int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
                const double h[3], int order, int upsample, int maxiters, double xtol, double ftol, void* phi, int f32, const unsigned char* mask,
-               void* out_field, hipStream_t stream, long long out_counts[3], const char** err) {
-    SampleSet ss;
-    if (int r = setup_args(ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, phi, f32, mask, err)) return r;
-    if (int r = build_samples(ss, total, stream, err)) return r;
+               void* out_field, hipStream_t stream, long long out_counts[3], const char** err, ReinitWorkspace** wsp) {
+    // the buffers live in the caller's workspace (the handle's) when there is one: no allocation after the first calls
+    ReinitWorkspace local;
+    if (wsp && !*wsp) *wsp = new ReinitWorkspace();
+    ReinitWorkspace& W = wsp ? **wsp : local;
+    SampleSet& ss = W.ss;
+    auto done = [&](int rc) {
+        if (!wsp) { ss.release(); (void)hipFree(W.seeds); W.seeds = nullptr; }
+        return rc;
+    };
+    if (int r = setup_args(ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, phi, f32, mask, err)) return done(r);
+    if (int r = build_samples(ss, total, stream, err, wsp != nullptr)) return r;     // (build_samples released ss)
     const ReinitArgs& a = ss.a;
     const int S = ss.S;
     const long long nwork = ss.nwork;
-    long long* seeds = nullptr;
     if (nwork) {
-        if (hipMalloc((void**)&seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return 2; }
+        if (grow(W.seeds, W.cap_seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return done(2); }
+        long long* seeds = W.seeds;
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
         const long long grp_blocks = (nwork * GRP + 255) / 256;
         const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
@@ -1174,14 +1241,21 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     }
     unsigned cn[4] = {0, 0, 0, 0};
     hipError_t e = hipMemcpyAsync(cn, ss.counters, sizeof(cn), hipMemcpyDeviceToHost, stream);
+    // a workspace serving a band goes back to its clean state by un-marking this call's candidate cells (behind everything that read them)
+    const bool restore = wsp && a.mask && e == hipSuccess;
+    if (restore && ss.ncand)
+        hipLaunchKernelGGL(reinit_unmark_kernel, dim3((ss.ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ss.ncand, ss.cand_id, ss.blk, ss.bits);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(seeds);
     const unsigned ncand = ss.ncand;
-    ss.release();
-    if (e != hipSuccess) { *err = "reinitialize: device error"; return 2; }
+    if (e != hipSuccess) { *err = "reinitialize: device error"; if (wsp) ss.release(); return done(2); }
+    if (restore) {
+        long long nc = 1;
+        for (int d = 0; d < ndim; ++d) nc *= n[d] - 1;
+        ss.clean_cells = nc;
+    }
     out_counts[0] = ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
-    return 0;
+    return done(0);
 }
 #undef RE_HIP
 

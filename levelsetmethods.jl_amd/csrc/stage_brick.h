@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     __shared__ int wsum[NT / 64];
     // gfx950 has 160 KB of LDS per CU (64 KB per workgroup on its predecessors: the fp64 instance would not launch there);
     // two workgroups of the largest instance must fit a CU
-    static_assert(2 * (sizeof(lsm_v4u) * NV4 + sizeof(unsigned short) * TX * TY * BZ + 512) <= 160 * 1024, "brick kernel: LDS budget of a gfx950 CU");
+    static_assert(2 * (sizeof(lsm_v4u) * NV4 + sizeof(unsigned short) * TX * TY * BZ + 64) <= 160 * 1024, "brick kernel: LDS budget of a gfx950 CU");
     const ST* brick = reinterpret_cast<const ST*>(vbrick);
 
     // the launch's workgroups in list order, dealt to the XCDs in contiguous ranges (TileOrder): the BZ-plane parts of a brick
@@ -92,16 +92,6 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     if (zb >= m1) return;
     const int nz = m1 - zb < BZ ? m1 - zb : BZ;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // ---- 0. (fold) this part's entries: how many, and the first NT of them — the first loads issued (vector loads return in order)
-    const bool fold = a.fold_cnt != nullptr;
-    unsigned fcnt = 0, fcode0 = 0;
-    const unsigned* fslab = nullptr;
-    if (fold) {
-        const size_t part = (size_t)tile_id * sub_per + sub;
-        fslab = a.fold_codes + part * a.fold_cap;
-        fcnt = a.fold_cnt[part];
-        fcode0 = fslab[tid];            // independent of the count (a slab holds at least NT words; words beyond the count are stale, not used)
-    }
     // ---- 1. loads: the mask bytes first (vector loads return in order: the node list is built while the brick is in flight),
     //         then the brick with its halo, row by row: RPI rows of NSEG 16-byte segments per round of the workgroup
     unsigned long long mbytes;
@@ -116,9 +106,8 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     constexpr int RPI = NT / NSEG, NIT = (NROW + RPI - 1) / RPI, QZ = RPI / H, RY = RPI % H;
     lsm_v4u v[NIT];
     const int crow = tid / NSEG, cseg = tid - crow * NSEG;
-    const ST* cb;
     {
-        cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
+        const ST* cb = uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (a.origin + (long long)(zb - G) * sm + (long long)(by0 - G) * sy + (bx0 - XL)));
         const bool cv = crow < RPI && bx0 - XL + cseg * SEG <= nx + G - 1;     // beyond: nothing a band node reads (zeros, no access)
         int zr = crow / H, yr = crow - zr * H;
 #pragma unroll
@@ -169,68 +158,6 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     for (int k = 0; k < NIT; ++k)
         if (crow < RPI && crow + k * RPI < NROW) vbrick[(crow + k * RPI) * PSEG + cseg] = v[k];
     __syncthreads();
-    // ---- 2b. (fold) ϕ[I] of the off-band nodes this part's stencils read (src/meshfield.jl:481-511), straight into the LDS brick: what
-    //          lsm_band_prepare's gather (band_apply_kernel) would have stored in the stage input — the same list entries (nearest band
-    //          node and the slope neighbours _axis_slope picks, found once per band by band_halo_bits_kernel and dealt to the parts
-    //          that read them), the same arithmetic in the same order, rounded to the storage type as the store would.  The nearest
-    //          node and its slope neighbours are band nodes: their values are read from the brick when they lie inside it (almost
-    //          always), from the stage input otherwise.  The stage input's off-band entries in HBM stay stale: nothing else reads them
-    //          (lsm_api.hip, advance_band).
-    if (fold) {
-        ST* bw = reinterpret_cast<ST*>(vbrick);
-        // a nearest node lies within 3 nodes of its entry and the slope neighbour one further: a base 4 planes, rows and elements
-        // below the brick's corner keeps every offset of the fall-back loads non-negative
-        const ST* gb = uniform_ptr(cb - (4 * sm + 4 * sy + 4));
-        fcnt = fcnt < a.fold_cap ? fcnt : a.fold_cap;
-        for (unsigned k = (unsigned)tid; k < fcnt; k += NT) {
-            const unsigned code = k < (unsigned)NT ? fcode0 : fslab[k];
-            const int X = (int)(code & 63u) - 4, Y = (int)((code >> 6) & 15u) - 3, Z = (int)((code >> 10) & 15u) - 3;
-            // (the dealer assumes the widest stencil: this kernel's box may be smaller)
-            if (X < -G || X >= TX + G || Y < -G || Y >= TY + G || Z < -G || Z >= BZ + G) continue;
-            const int o[3] = {(int)((code >> 14) & 7u) - 3, (int)((code >> 17) & 7u) - 3, (int)((code >> 20) & 7u) - 3};
-            const unsigned sc = (code >> 23) & 63u;
-            const int PX = X + o[0], PY = Y + o[1], PZ = Z + o[2];
-            const bool inbox = PX >= 1 - XL && PX <= TX + XL - 2 && PY >= 1 - G && PY <= TY + G - 2 && PZ >= 1 - G && PZ <= BZ + G - 2;
-            double phiP, nbv[3];
-            if (inbox) {
-                const int lp = ((PZ + G) * H + (PY + G)) * WP + PX + XL;
-                const int ld[3] = {1, WP, HW};
-                phiP = (double)bw[lp];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const unsigned c = (sc >> (2 * d)) & 3u;
-                    nbv[d] = phiP;
-                    if (c != 0u && o[d] != 0) nbv[d] = (double)bw[c == 1u ? lp + ld[d] : lp - ld[d]];
-                }
-            } else {
-                const unsigned eo = (unsigned)(PZ + G + 4) * (unsigned)sm + (unsigned)(PY + G + 4) * (unsigned)sy + (unsigned)(PX + XL + 4);
-                const unsigned sdv[3] = {1u, (unsigned)sy, (unsigned)sm};
-                phiP = ldg<ST>(gb, (unsigned)sizeof(ST) * eo);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const unsigned c = (sc >> (2 * d)) & 3u;
-                    nbv[d] = phiP;
-                    if (c != 0u && o[d] != 0) nbv[d] = ldg<ST>(gb, (unsigned)sizeof(ST) * (c == 1u ? eo + sdv[d] : eo - sdv[d]));
-                }
-            }
-            double val = phiP;
-            {
-#pragma clang fp contract(off)          // band_apply_kernel's translation unit is built without contraction: the same roundings here
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const unsigned c = (sc >> (2 * d)) & 3u;
-                    const int delta = -o[d];                      // I - P
-                    if (delta == 0) continue;
-                    const double slope = c == 1u ? nbv[d] - phiP : (c == 2u ? phiP - nbv[d] : 0.0);
-                    const double t = (double)delta * slope;
-                    val = val + t;
-                }
-            }
-            const double sv = val > 0 ? 1.0 : (val < 0 ? -1.0 : val), sp = phiP > 0 ? 1.0 : (phiP < 0 ? -1.0 : phiP);
-            bw[((Z + G) * H + (Y + G)) * WP + X + XL] = (ST)((phiP == 0.0 || sv == sp) ? val : phiP);
-        }
-        __syncthreads();
-    }
     // ---- 3. one lane per band node
     const long long po = a.origin + (long long)zb * sm + (long long)by0 * sy + bx0;     // the brick's first node
     PlaneTab pt;
@@ -258,8 +185,7 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
     }
 }
 
-// is this launch a case for the brick kernel?  (adv / nm / curv: the pass's combination; asked by lsm_api.hip before it decides
-// whether the stage input's off-band nodes are extrapolated inside the brick kernel or by a launch of their own)
+// is this launch a case for the brick kernel?  (adv / nm / curv: the pass's combination)
 inline bool bricks_applicable(int ADV, int NM, int CURV, const StageArgs& a) {
     const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
     if (env && env[0] == '0') return false;
@@ -272,8 +198,7 @@ inline bool bricks_applicable(int ADV, int NM, int CURV, const StageArgs& a) {
     const long long seg = a.f32 ? 4 : 2, lead = a.origin - LSM_GHOST * a.s2 - LSM_GHOST * a.s1;
     if (lead < BrickCfg::XL || lead % seg || a.s1 % 8 || a.s2 % 8 || a.origin % 8) return false;
     if (((unsigned long long)a.psi | (unsigned long long)a.mask) % 16ull) return false;
-    if ((long long)(16 + 2 * LSM_GHOST + 1 + 8) * a.s2 * 8 >= (1ll << 31)) return false;      // + 8: the fold's gathers reach 4 planes beyond the brick's box
-    if (a.fold_cnt && a.mc != 8 && a.mc != 16) return false;          // the fold deals the entries to parts of 8 planes of 8- or 16-plane tiles
+    if ((long long)(16 + 2 * LSM_GHOST + 1) * a.s2 * 8 >= (1ll << 31)) return false;
     return true;
 }
 

@@ -11,5 +11,4 @@ int launch_stage_brick(const Combo& c, const StageArgs& a, hipStream_t s) {
 #undef LSM_X
     return -1;
 }
-bool stage_brick_applicable(const Combo& c, const StageArgs& a) { return combo_available(c) && LSM_NS::bricks_applicable(c.adv, c.nm, c.curv, a); }
 }  // namespace lsm
