@@ -450,6 +450,34 @@ int lsm_advance_band_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, const L
 int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int order, int upsample, int maxiters,
                      double xtol, double ftol, int64_t* ncandidate_cells, int64_t* nfail, int64_t* nfar);
 
+/* ---- tuning switches ----
+ * Every switch has the name of an environment variable.  The environment is read ONCE per process, when the first handle is
+ * created; every handle starts from those values and lsm_set_tuning changes one handle's (tests and A/B measurements flip
+ * them between launches).  None of them changes a result beyond what its description says; the whole GPU test suite passes
+ * under each.  Unknown names are refused.  (Experiments that were measured and lost have no switch: their record is DESIGN.md.)
+ *
+ *   name                    default  meaning
+ *   LSM_STAGE_TAIL              16   planes per chunk of the graded tail of a dense 3-D stage launch (0: no tail)
+ *   LSM_STAGE_TAIL_DYN          25   % spare workgroups of the dynamic tail (0: the static tail)
+ *   LSM_STAGE_MC                 0   planes per march chunk in 3-D (0: 64, shorter on small grids)
+ *   LSM_STAGE_MC2                0   rows per march chunk in 2-D (0: 8)
+ *   LSM_PAIRS                    1   two nodes per thread for dense single-term stages (0: one node per thread)
+ *   LSM_STAGE_GENERIC            0   general stage kernels instead of the plain variants (diagnostic: same results)
+ *   LSM_XREDIRECT                1   FAST steps: x / y ghosts of copy-type faces (periodic, symmetry, NeumannBC) are read from the
+ *                                    node the boundary condition copies instead of being materialised (a copied -0.0 stays -0.0)
+ *   LSM_GHOST_FULL_DEPTH         0   ghost fills write all LSM_GHOST layers (default: the layers the step's stencils read)
+ *   LSM_BAND_BRICKS              1   narrow band: the stage with one lane per band node (0: the tiled stage; bitwise equal)
+ *   LSM_BAND_BITS                1   narrow band: update_band! on bit rows (0: the byte-mask kernels; bitwise equal)
+ *   LSM_BAND_CFL_PREFETCH        1   narrow band: dt of the next step reduced right behind lsm_band_update
+ *   LSM_BAND_BYTES               0   narrow band: byte-mask kernels in 3-D too (the path of wide bands and bands at a face)
+ *   LSM_BAND_NO_LISTS            0   narrow band: launches over all tiles instead of the compact tile lists
+ *   LSM_STATUS_SPIN              1   lsm_band_status spins on the status kernel's ticket in pinned memory (0: stream synchronise)
+ *   LSM_SLAB_OVERLAP             1   slab steps update the interface planes first (read when a communicator is attached)
+ *   LSM_COMM_TIMEOUT_MS      60000   how long a rank waits for its peers before LSM_ERR_COMM
+ *   LSM_LAYOUT_ALIGN             1   rows of the padded layout start on 64-byte lines (environment only: fixed by lsm_create) */
+int lsm_set_tuning(LsmHandle* h, const char* name, int value);
+int lsm_get_tuning(const LsmHandle* h, const char* name, int* value);
+
 /* ---- measurement: HIP-event timing of the stage kernels on the handle's stream ----
  * on = 0: off; on = 1: an event pair around every stage launch; on = N > 1: around every N-th launch (an event costs the
  * stream ≈3.7 µs on MI355X: six per RK3 step are 22 µs — 20 % of a 2048² step, 0.6 % of a 512³ one).  lsm_profile_read

@@ -134,6 +134,8 @@ _SIGS = [
     ("lsm_band_halo", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_band_retile", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
     ("lsm_band_invalidate", C.c_int, [_H]),
+    ("lsm_set_tuning", C.c_int, [_H, C.c_char_p, C.c_int]),
+    ("lsm_get_tuning", C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int)]),
     ("lsm_band_fill_list", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("lsm_reinitialize", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -1036,7 +1036,7 @@ class LevelSetEquation:
     `comm` (a torch.distributed process group, or a rank of an in-process LocalGroup: the grid is then split into
     slabs of the last dimension, one per rank, with the ghost-plane exchange inside the library — RCCL or peer copies)."""
 
-    def __init__(self, *, terms, ic, integrator=None, bc=None, t=0, mode="fast", device=0, comm=None, backend_factory=None):
+    def __init__(self, *, terms, ic, integrator=None, bc=None, t=0, mode="fast", device=0, comm=None, backend_factory=None, tuning=None):
         if isinstance(terms, LevelSetTerm):
             terms = (terms,)
         if not (isinstance(terms, tuple) and all(isinstance(x, LevelSetTerm) for x in terms)):
@@ -1108,7 +1108,7 @@ class LevelSetEquation:
         factory = backend_factory
         if factory is None:
             from .backend import HipBackend
-            factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device, dtype=self.dtype)
+            factory = lambda g, b, s: HipBackend(g, b, slab=s, mode=mode, device=device, dtype=self.dtype, tuning=tuning)   # tuning: {"LSM_...": value} (include/lsm.h)
         elif self.dtype != np.float64:
             raise ValueError("float32 fields need the HIP backend")
         self.backend = factory(grid._c(), _bc_c(bcs, N, slab_faces), self.slab)

@@ -18,7 +18,7 @@ from . import _lib as L
 class HipBackend:
     name = "hip"
 
-    def __init__(self, grid_c, bc_c, slab=None, mode="fast", device=0, dtype=np.float64):
+    def __init__(self, grid_c, bc_c, slab=None, mode="fast", device=0, dtype=np.float64, tuning=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -48,6 +48,8 @@ class HipBackend:
                 "lsm_set_stream")
         self.lay = L.LsmLayout()
         L.check(self.h, self.lib.lsm_layout(self.h, C.byref(self.lay)), "lsm_layout")
+        for name, value in (tuning or {}).items():     # include/lsm.h, "tuning switches": before anything is built on the handle
+            self.set_tuning(name, value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -295,6 +297,15 @@ class HipBackend:
     def band_halo(self, vals, mask, halo, tiles, mc, hlist, hcount):
         L.check(self.h, self.lib.lsm_band_halo(self.h, self.ptr(vals), self.ptr(mask), self.ptr(halo), self.ptr(tiles), int(mc),
                                                self.ptr(hlist), hlist.numel() // 2, self.ptr(hcount)), "lsm_band_halo")
+
+    def set_tuning(self, name, value):
+        """lsm_set_tuning: one of the switches of include/lsm.h ("LSM_BAND_BRICKS", ...) on this handle."""
+        L.check(self.h, self.lib.lsm_set_tuning(self.h, name.encode(), int(value)), "lsm_set_tuning")
+
+    def get_tuning(self, name):
+        v = C.c_int()
+        L.check(self.h, self.lib.lsm_get_tuning(self.h, name.encode(), C.byref(v)), "lsm_get_tuning")
+        return int(v.value)
 
     def band_retile(self, mask, tiles, mc):
         L.check(self.h, self.lib.lsm_band_retile(self.h, self.ptr(mask), self.ptr(tiles), int(mc)), "lsm_band_retile")

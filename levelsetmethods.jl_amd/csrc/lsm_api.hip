@@ -68,7 +68,76 @@ static double lagrange_w(int j, int k, int P) {
     return w;
 }
 
+namespace lsm {
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+// The environment, read once per process (the only getenv calls of the library).  A switch that is merely SET counts as 1 for the
+// flags that used to be tested for presence (LSM_STAGE_GENERIC, LSM_BAND_BYTES, LSM_BAND_NO_LISTS, LSM_GHOST_FULL_DEPTH).
+const LsmTuning& lsm_tuning_env() {
+    static const LsmTuning t = [] {
+        LsmTuning u;
+        auto flag = [](const char* n) { const char* v = getenv(n); return v ? (*v && atoi(v) == 0 && v[0] == '0' ? 0 : 1) : 0; };
+        u.stage_tail = env_int("LSM_STAGE_TAIL", 16);
+        u.stage_tail_dyn = env_int("LSM_STAGE_TAIL_DYN", 25);
+        u.stage_mc = env_int("LSM_STAGE_MC", 0);
+        u.stage_mc2 = env_int("LSM_STAGE_MC2", 0);
+        u.pairs = env_int("LSM_PAIRS", 1);
+        u.stage_generic = flag("LSM_STAGE_GENERIC");
+        u.xredirect = env_int("LSM_XREDIRECT", 1);
+        u.ghost_full_depth = flag("LSM_GHOST_FULL_DEPTH");
+        u.band_bricks = env_int("LSM_BAND_BRICKS", 1);
+        u.band_bits = env_int("LSM_BAND_BITS", 1);
+        u.band_cfl_prefetch = env_int("LSM_BAND_CFL_PREFETCH", 1);
+        u.band_bytes = flag("LSM_BAND_BYTES");
+        u.band_no_lists = flag("LSM_BAND_NO_LISTS");
+        u.status_spin = env_int("LSM_STATUS_SPIN", 1);
+        u.slab_overlap = env_int("LSM_SLAB_OVERLAP", 1);
+        u.comm_timeout_ms = env_int("LSM_COMM_TIMEOUT_MS", 60000);
+        if (u.comm_timeout_ms <= 0) u.comm_timeout_ms = 60000;
+        u.layout_align = env_int("LSM_LAYOUT_ALIGN", 1);
+        return u;
+    }();
+    return t;
+}
+int* lsm_tuning_field(LsmTuning& t, const char* name) {
+    if (!name) return nullptr;
+    const struct { const char* n; int* p; } tab[] = {
+        {"LSM_STAGE_TAIL", &t.stage_tail}, {"LSM_STAGE_TAIL_DYN", &t.stage_tail_dyn}, {"LSM_STAGE_MC", &t.stage_mc}, {"LSM_STAGE_MC2", &t.stage_mc2},
+        {"LSM_PAIRS", &t.pairs}, {"LSM_STAGE_GENERIC", &t.stage_generic}, {"LSM_XREDIRECT", &t.xredirect},
+        {"LSM_GHOST_FULL_DEPTH", &t.ghost_full_depth}, {"LSM_BAND_BRICKS", &t.band_bricks}, {"LSM_BAND_BITS", &t.band_bits},
+        {"LSM_BAND_CFL_PREFETCH", &t.band_cfl_prefetch}, {"LSM_BAND_BYTES", &t.band_bytes}, {"LSM_BAND_NO_LISTS", &t.band_no_lists},
+        {"LSM_STATUS_SPIN", &t.status_spin}, {"LSM_SLAB_OVERLAP", &t.slab_overlap}, {"LSM_COMM_TIMEOUT_MS", &t.comm_timeout_ms},
+        {"LSM_LAYOUT_ALIGN", &t.layout_align},
+    };
+    for (const auto& e : tab)
+        if (strcmp(e.n, name) == 0) return e.p;
+    return nullptr;
+}
+}  // namespace lsm
+
 extern "C" {
+
+int lsm_set_tuning(LsmHandle* h, const char* name, int value) {
+    if (!h) return LSM_ERR_INVALID;
+    int* p = lsm_tuning_field(h->tune, name);
+    if (!p) return fail(h, LSM_ERR_INVALID, std::string("lsm_set_tuning: no such switch: ") + (name ? name : "(null)"));
+    if (p == &h->tune.layout_align) return fail(h, LSM_ERR_INVALID, "lsm_set_tuning: LSM_LAYOUT_ALIGN is fixed when the handle is created (environment only)");
+    *p = value;
+    h->no_lists = h->tune.band_no_lists != 0;
+    h->band_bytes = h->tune.band_bytes != 0;
+    if (h->tune.band_no_lists) { h->lists_tiles = nullptr; h->lists_host_valid = false; }
+    return LSM_OK;
+}
+int lsm_get_tuning(const LsmHandle* h, const char* name, int* value) {
+    if (!h || !value) return LSM_ERR_INVALID;
+    LsmTuning t = h->tune;
+    const int* p = lsm_tuning_field(t, name);
+    if (!p) return LSM_ERR_INVALID;
+    *value = *p;
+    return LSM_OK;
+}
 
 const char* lsm_version(void) { return "hiplsm 0.1 (gfx950)"; }
 
@@ -131,10 +200,11 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->d_cand_count = nullptr;
     h->d_ring = nullptr; h->nring = 0; h->d_miss = nullptr; h->d_count = nullptr; h->d_work = nullptr; h->d_tiles_old = nullptr; h->work_cap = 0; h->halo_n_key = nullptr; h->halo_n = 0;
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
-    h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_stage_list = nullptr; h->d_head = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
+    h->d_act_list = nullptr; h->d_work_list = nullptr; h->d_lcounts = nullptr; h->lists_tiles = nullptr; h->lists_mc = 0;
     h->lists_host_valid = false; h->nact = h->nwork = h->nface = 0;
-    h->no_lists = getenv("LSM_BAND_NO_LISTS") != nullptr;
-    h->band_bytes = getenv("LSM_BAND_BYTES") != nullptr;
+    h->tune = lsm_tuning_env();
+    h->no_lists = h->tune.band_no_lists != 0;
+    h->band_bytes = h->tune.band_bytes != 0;
     h->slab.lo = 0; h->slab.n = grid->n[N - 1];
     if (slab) h->slab = *slab;
     if (h->slab.lo < 0 || h->slab.n < LSM_GHOST || h->slab.lo + h->slab.n > grid->n[N - 1]) {
@@ -143,7 +213,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     }
     long long s = 1;
     h->lay.origin = 0;
-    static const bool align_rows = !(getenv("LSM_LAYOUT_ALIGN") && getenv("LSM_LAYOUT_ALIGN")[0] == '0');   // A/B switch
+    const bool align_rows = lsm_tuning_env().layout_align != 0;      // LSM_LAYOUT_ALIGN=0: the compact layout (A/B)
     for (int d = 0; d < 3; ++d) {
         h->nloc[d] = (int)grid->n[d];
         h->goff[d] = 0;
@@ -238,7 +308,7 @@ void lsm_destroy(LsmHandle* h) {
     if (h->ch_result) (void)hipHostFree(h->ch_result);
     (void)hipFree(h->d_w);
     if (h->d_ring) { (void)hipFree(h->d_ring); (void)hipFree(h->d_miss); (void)hipFree(h->d_count); }
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
     (void)hipFree(h->d_result);
     if (h->d_pf_flag) (void)hipFree(h->d_pf_flag);
     reinit_workspace_free(h->reinit_ws);
@@ -313,7 +383,7 @@ static int fill_ghosts_fused(LsmHandle* h, void* field, int mb, int me, int fill
     a.mb = mb; a.me = me; a.fill_last = fill_last;
     a.skip_x = skip_x ? 1 : 0;
     a.skip_y = skip_y && N == 3 ? 1 : 0;
-    static const bool full_depth = getenv("LSM_GHOST_FULL_DEPTH") != nullptr;     // A/B switch
+    const bool full_depth = h->tune.ghost_full_depth != 0;
     if (depth == 0) depth = h->ghost_depth;
     a.depth = (depth < 1 || depth > LSM_GHOST || full_depth) ? LSM_GHOST : depth;
     launch_ghost_fill_all(N, a, s);
@@ -325,8 +395,7 @@ int lsm_fill_ghosts(LsmHandle* h, void* field, int dim_mask, void* stream) {
     if (!h || !field) return LSM_ERR_INVALID;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const int N = h->grid.ndim;
-    static const bool per_dim_env = getenv("LSM_GHOST_PER_DIM") != nullptr;   // A/B switch
-    if ((dim_mask & ((1 << N) - 1)) == ((1 << N) - 1) && !per_dim_env)
+    if ((dim_mask & ((1 << N) - 1)) == ((1 << N) - 1))
         return fill_ghosts_fused(h, field, 0, h->nloc[N - 1], 1, s);   // one launch, bit-identical to the passes below
     for (int d = 0; d < N; ++d) {
         if (!((dim_mask >> d) & 1)) continue;
@@ -381,6 +450,7 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.yredirect = h->yredirect ? 1 : 0;
     a.ykind[0] = h->bc[1][0].kind; a.ykind[1] = h->bc[1][1].kind;
     a.stamp = h->d_stamp;
+    a.tune = &h->tune;
     a.nbig = 0; a.mc_tail = 0;
 }
 
@@ -562,12 +632,11 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             CflArgs a;
             cfl_args(h, tm, t, a);
             // ϕ-independent coefficient, dense field: the reduction runs on the handle's CFL stream with its own scratch and
-            // does not queue behind the stages on the main stream (LSM_CFL_MAIN_STREAM=1 is the A/B switch).  A table is
-            // waited for once, the first time it is seen (its upload was ordered on the main stream).
-            static const bool main_env = getenv("LSM_CFL_MAIN_STREAM") != nullptr;
+            // does not queue behind the stages on the main stream.  A table is waited for once, the first time it is seen (its
+            // upload was ordered on the main stream).
             // Only while the coefficient cache is on: lsm_cfl_cache(h, 0) is how a caller says "tables may be rewritten in
             // place between calls" (hooks), and such writes are ordered on the main stream only.
-            const bool side = !main_env && h->cfl_cache_on && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD;
+            const bool side = h->cfl_cache_on && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD;
             if (side && tm.coeff.kind == LSM_COEFF_SEPARABLE)
                 for (int c = 0; c < 3; ++c) {
                     const void* tp = tm.coeff.sep[c];
@@ -596,12 +665,10 @@ int lsm_compute_cfl(LsmHandle* h, const LsmTerm* terms, int nterms, const void* 
             int nb = cfl_blocks(N, h->nloc);
             if (nb > MAXB) nb = MAXB;
             LSM_HIP(h, hipMemsetAsync(dflag, 0, sizeof(int), cs));
-            static const bool single_env = getenv("LSM_CFL_SINGLE_PASS") != nullptr;   // A/B switch
             // (on a band the exact divisions run on the few band nodes only: one pass)
-            const bool two_pass = !single_env && !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
+            const bool two_pass = !h->band_mask && tm.coeff.kind != LSM_COEFF_FIELD && tm.kind != LSM_TERM_CURVATURE;
             // u(x)·g(t): the nodes that can attain the maximum are the same for every t (recorded once, with g = 1)
-            static const bool nocand_env = getenv("LSM_CFL_NO_CANDIDATES") != nullptr;   // A/B switch
-            const bool sep_time = two_pass && !nocand_env && h->cfl_cache_on && !h->band_mask && tm.coeff.kind == LSM_COEFF_SEPARABLE &&
+            const bool sep_time = two_pass && h->cfl_cache_on && !h->band_mask && tm.coeff.kind == LSM_COEFF_SEPARABLE &&
                                   tm.coeff.time_kind != LSM_TIME_ONE && fabs(a.coeff.tfac) > 1e-200;
             const LsmHandle::CflCand* cand = nullptr;
             if (sep_time) {
@@ -705,7 +772,7 @@ struct XRedirect {
             depth = g > depth ? g : depth;
         }
         h->ghost_depth = (hook || depth < 1) ? LSM_GHOST : depth;
-        static const bool off = getenv("LSM_XREDIRECT") && getenv("LSM_XREDIRECT")[0] == '0';
+        const bool off = !h->tune.xredirect;                                   // LsmTuning: the fills materialise these ghosts
         auto copies = [&](int d, int sd) {
             const int k = h->bc[d][sd].kind;
             return k == LSM_BC_PERIODIC || k == LSM_BC_SYMMETRY || (k == LSM_BC_EXTRAPOLATION && h->bc[d][sd].degree == 0);
@@ -1058,11 +1125,6 @@ static BandArgs band_args(const LsmHandle* h, int mc, const unsigned char* work)
     a.list = nullptr; a.nlist = 0;
     a.f32 = is_f32(h);
     a.force_bytes = h->band_bytes ? 1 : 0;
-    static const int band_exp = getenv("LSM_BAND_EXP") ? atoi(getenv("LSM_BAND_EXP")) : 0;
-    a.exp = band_exp;
-    static const bool no_pieces = getenv("LSM_BAND_PIECES") && getenv("LSM_BAND_PIECES")[0] == '0';   // A/B switch
-    static const bool want_pieces = getenv("LSM_BAND_PIECES") && getenv("LSM_BAND_PIECES")[0] == '1';
-    a.pieces = (want_pieces && !no_pieces && a.ndim == 3 && (long long)a.nbx * a.nby * a.nbm < (1ll << 24)) ? 1 : 0;
     return a;
 }
 
@@ -1093,14 +1155,12 @@ static int ensure_ring(LsmHandle* h) {
 // handle-owned scratch for the per-tile work flags
 static int ensure_work(LsmHandle* h, int64_t ntiles) {
     if (h->work_cap >= ntiles) return LSM_OK;
-    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); (void)hipFree(h->d_stage_list); (void)hipFree(h->d_head); }
+    if (h->d_work) { (void)hipFree(h->d_work); (void)hipFree(h->d_act_list); (void)hipFree(h->d_work_list); (void)hipFree(h->d_lcounts); (void)hipFree(h->d_tiles_old); }
     LSM_HIP(h, hipMalloc((void**)&h->d_work, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_tiles_old, (size_t)ntiles));
     LSM_HIP(h, hipMalloc((void**)&h->d_act_list, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_work_list, (size_t)ntiles * sizeof(int)));
     LSM_HIP(h, hipMalloc((void**)&h->d_lcounts, 4 * sizeof(unsigned)));
-    LSM_HIP(h, hipMalloc((void**)&h->d_stage_list, (size_t)ntiles * sizeof(int)));
-    LSM_HIP(h, hipMalloc((void**)&h->d_head, (size_t)ntiles));
     h->work_cap = ntiles;
     h->lists_tiles = nullptr; h->lists_host_valid = false;
     return LSM_OK;
@@ -1136,14 +1196,13 @@ static int band_halo_impl(LsmHandle* h, const void* vals, const void* mask, void
     } else if (have_lists(h, tiles, mc)) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     const int N = h->grid.ndim;
     // nothing reads the halo mask outside the tiles visited here: clear those (0.5 % of a 768³ grid) instead of every byte
-    static const bool full_clear = getenv("LSM_BAND_FULL_CLEAR") != nullptr;   // A/B switch
     if (halo_cleared && visit) {}                                   // lsm_band_update's copy pass cleared the visited tiles
-    else if ((a.list || a.work) && !full_clear) launch_band_zero(a, (unsigned char*)halo_mask, h->stream);
+    else if (a.list || a.work) launch_band_zero(a, (unsigned char*)halo_mask, h->stream);
     else LSM_HIP(h, hipMemsetAsync(halo_mask, 0, (size_t)h->lay.total, h->stream));
     BandBcArgs bc;
     for (int d = 0; d < 3; ++d)
@@ -1172,7 +1231,7 @@ static int band_cfl_prefetch(LsmHandle* h, const void* mask, const void* tiles, 
     hipStream_t s = h->stream;
     LsmHandle::BandCfl& pf = h->band_cfl;
     pf.pending = false; pf.valid = false;
-    static const bool off = getenv("LSM_BAND_CFL_PREFETCH") && getenv("LSM_BAND_CFL_PREFETCH")[0] == '0';   // A/B switch
+    const bool off = !h->tune.band_cfl_prefetch;
     if (off || !pf.armed || pf.mask != mask || pf.tiles != tiles || pf.mc != mc || h->grid.ndim != 3 || h->no_lists) return LSM_OK;
     const BandArgs ba = band_args(h, mc, nullptr);
     for (int k = 0; k < pf.nterms; ++k) {
@@ -1224,12 +1283,12 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (listed) {
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (local) {
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     const size_t bytes = (size_t)h->lay.total;
     // Bit-row path (lsm_band.hip): every node read once, the mask updated in place, new nodes extrapolated by the grow kernel itself
-    const bool bits_env = !(getenv("LSM_BAND_BITS") && getenv("LSM_BAND_BITS")[0] == '0');   // A/B switch (read per call: tests flip it)
+    const bool bits_env = h->tune.band_bits != 0;
     const size_t words = (size_t)ntiles * (size_t)(a.ty * a.tm);                 // u32 words per bit array
     if (bits_env && local && nlayers <= 3 && band_bits_fit(a, nlayers) && 2 * words * sizeof(unsigned) <= bytes &&
         ((uintptr_t)scratch_a & 7) == 0 && ((uintptr_t)scratch_b & 7) == 0) {
@@ -1256,8 +1315,8 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
             LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior_b ? 1 : 0));
         }
         BandArgs full = band_args(h, mc, nullptr);
-        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
-        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
+        launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_lcounts + 2, h->d_pf_flag, h->stream);
+        launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
         h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
         LSM_HIP(h, hipGetLastError());
         return band_cfl_prefetch(h, mask, tiles, mc, NB);
@@ -1280,8 +1339,7 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     if (!from_dense)
         launch_band_extrapolate(a, A, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds, vals,
                                 vals, h->d_miss, nullptr, nullptr, 0, h->stream);
-    static const bool full_clear_env = getenv("LSM_BAND_FULL_CLEAR") != nullptr;
-    const bool clear_with_copy = listed && !full_clear_env;    // the halo pass below visits the same listed tiles
+    const bool clear_with_copy = listed;                       // the halo pass below visits the same listed tiles
     launch_band_copy(a, A, (unsigned char*)mask, clear_with_copy ? (unsigned char*)halo_mask : nullptr, h->stream);   // the old band lies inside the visited tiles
     if (!fused) launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
     LSM_HIP(h, hipGetLastError());
@@ -1291,8 +1349,8 @@ int lsm_band_update(LsmHandle* h, void* vals, void* mask, int from_dense, int nl
     LSM_TRY(band_halo_impl(h, vals, mask, halo_mask, tiles, mc, halo_list, halo_cap, halo_count, listed ? &a : nullptr, interior, clear_with_copy));
     // compact lists of the new band's tiles for the launches that follow lsm_band_status
     BandArgs full = band_args(h, mc, nullptr);
-    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
-    launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
+    launch_band_work(full, (const unsigned char*)tiles, h->d_work, h->d_lcounts + 2, h->d_pf_flag, h->stream);
+    launch_band_lists(full, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
     return band_cfl_prefetch(h, mask, tiles, mc);
@@ -1317,8 +1375,8 @@ int lsm_band_retile(LsmHandle* h, const void* mask, void* tiles, int mc) {
     BandArgs a = band_args(h, mc, nullptr);
     LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
     launch_band_tiles(a, (const unsigned char*)mask, (unsigned char*)tiles, h->stream);
-    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_lcounts + 2, h->d_pf_flag, h->stream);
-    launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_head, h->d_act_list, h->d_work_list, h->d_stage_list, h->d_lcounts, h->stream);
+    launch_band_work(a, (const unsigned char*)tiles, h->d_work, h->d_lcounts + 2, h->d_pf_flag, h->stream);
+    launch_band_lists(a, (const unsigned char*)tiles, h->d_work, h->d_act_list, h->d_work_list, h->d_lcounts, h->stream);
     h->lists_tiles = tiles; h->lists_mc = mc; h->lists_host_valid = false;
     LSM_HIP(h, hipGetLastError());
     return LSM_OK;
@@ -1346,7 +1404,7 @@ int lsm_band_fill(LsmHandle* h, void* vals, const void* mask, const void* target
         a.list = h->d_work_list; a.nlist = h->nwork;
     } else if (tiles) {
         LSM_TRY(ensure_work(h, (int64_t)a.nbx * a.nby * a.nbm));
-        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, nullptr, h->stream);
+        launch_band_work(a, (const unsigned char*)tiles, h->d_work, nullptr, nullptr, h->stream);
         a.work = h->d_work;
     }
     launch_band_extrapolate(a, (const unsigned char*)targets, nullptr, (const unsigned char*)mask, h->d_ring, h->nring, h->nring_lds,
@@ -1422,7 +1480,7 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
         const volatile double* tk = h->h_result + 13;
         const double want = (double)h->status_ticket;
         const auto t0 = std::chrono::steady_clock::now();
-        static const bool no_spin = getenv("LSM_STATUS_SPIN") && getenv("LSM_STATUS_SPIN")[0] == '0';      // A/B switch
+        const bool no_spin = !h->tune.status_spin;
         bool seen = false;
         while (!no_spin && !(seen = (*tk == want))) {
             __builtin_ia32_pause();
@@ -1438,7 +1496,7 @@ int lsm_band_status(LsmHandle* h, const void* halo_count, int64_t* count, int* m
         h->band_cfl.valid = true;
     }
     *missed = (int)h->h_result[3];
-    if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->nstage = (unsigned)h->h_result[7]; h->lists_host_valid = true; }
+    if (h->lists_tiles) { h->nact = (unsigned)h->h_result[4]; h->nwork = (unsigned)h->h_result[5]; h->nface = (unsigned)h->h_result[6]; h->lists_host_valid = true; }
     if (*missed) LSM_HIP(h, hipMemsetAsync(h->d_miss, 0, sizeof(int), h->stream));
     *count = (int64_t)h->h_result[2];
     h->halo_n_key = halo_count; h->halo_n = *count;
@@ -1453,7 +1511,7 @@ int lsm_stage_band(LsmHandle* h, const LsmTerm* terms, int nterms, const void* p
     h->band_mask = (const unsigned char*)mask;
     h->band_tiles = (const unsigned char*)tiles;
     h->band_mc = tiles ? mc : 0;
-    if (tiles && have_lists(h, tiles, mc)) { h->band_list = h->d_stage_list; h->band_nlist = h->nstage; }   // tile | (bricks - 1) << 24
+    if (tiles && have_lists(h, tiles, mc)) { h->band_list = h->d_act_list; h->band_nlist = h->nact; }
     const int r = stage_impl(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t_stage, 0, h->nloc[h->grid.ndim - 1], stream);
     h->band_mask = nullptr; h->band_tiles = nullptr; h->band_mc = 0; h->band_list = nullptr; h->band_nlist = 0;
     return r;

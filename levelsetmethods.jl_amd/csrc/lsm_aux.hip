@@ -218,8 +218,6 @@ __global__ void __launch_bounds__(256) ghost_rows_kernel(const GhostAllArgs a) {
 
 static bool ghost_rows_launch(int ndim, const GhostAllArgs& a, hipStream_t s) {
     if (ndim < 2) return false;
-    static const bool off = getenv("LSM_GHOST_FLAT") != nullptr;          // A/B switch: the flat enumeration
-    if (off) return false;
     const int G = a.depth;
     const long long P0 = a.n[0] + 2 * G, P1 = ndim == 3 ? a.n[1] + 2 * G : 1;
     const int nlastg = a.fill_last ? (a.kind[ndim - 1][0] != LSM_BC_NONE ? G : 0) + (a.kind[ndim - 1][1] != LSM_BC_NONE ? G : 0) : 0;

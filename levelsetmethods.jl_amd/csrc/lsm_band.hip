@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned cha
 }
 
 // the numbers lsm_band_status hands to the host, gathered into one pinned-memory copy: {halo entries wanted, search misses,
-// active tiles, work tiles, face tiles, stage pieces}
+// active tiles, work tiles, face tiles}
 // `out` is the host's pinned page: the last word written, behind a system-scope fence, is the call's ticket — the host spins on it
 // instead of paying a stream synchronisation's wake-up (tens of microseconds of idle GPU per step).
 // pf.n > 0: Δt of the next step, prefetched (LsmHandle::BandCfl) — this kernel is also the second stage of those reductions
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(64) band_status_kernel(const unsigned* halo_co
         out[2] = lcounts ? (double)lcounts[0] : 0.0;
         out[3] = lcounts ? (double)lcounts[1] : 0.0;
         out[4] = lcounts ? (double)lcounts[2] : 0.0;
-        out[5] = lcounts ? (double)lcounts[3] : 0.0;
+        out[5] = 0.0;
     }
     __threadfence_system();
     if (threadIdx.x == 0) *reinterpret_cast<volatile double*>(out + 11) = ticket;
@@ -565,12 +565,9 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
             return;
         }
     }
-    // timing experiments (LSM_BAND_EXP; wrong results): 1 = no value pass, 2 = stop after the mask pass, 4 = no mask output
-    if (a.exp & 2) return;
     // pass 2: values of the band nodes -> (<= 0) and (>= 0) row words
     u64* const out2[2] = {LE, GE};
-    if (a.exp & 1) { for (int t = threadIdx.x; t < nrows; t += blockDim.x) { LE[t] = B[t] & 0x5555555555555555ull; GE[t] = B[t] & 0xaaaaaaaaaaaaaaaaull; } }
-    else stage_rows<GK, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, B, [&](long long q, bool, u64 rowB) -> unsigned {
+    stage_rows<GK, 2>(a, ap, bx, by, bm, x0, y0, m0, out2, B, [&](long long q, bool, u64 rowB) -> unsigned {
         const bool on = (rowB >> (threadIdx.x & 63)) & 1ull;
         const double xv = ld_val(v, on ? q : a.origin, a.f32);
         return on ? ((xv <= 0.0 ? 1u : 0u) | (xv >= 0.0 ? 2u : 0u)) : 0u;
@@ -625,7 +622,6 @@ __global__ void __launch_bounds__(256) band_grow3_kernel(BandArgs a, const void*
         u64* tmp = cur; cur = nxt; nxt = tmp;
     }
     int any = 0;
-    if (a.exp & 4) { if (threadIdx.x == 0) tiles[tile] = 1; return; }
     if (x0 + a.tx <= a.n[0]) {
         // whole x-rows inside the grid: a thread expands 8 bits of a row word to 8 mask bytes and stores them at once
         typedef u64 w8 __attribute__((aligned(1)));
@@ -688,7 +684,6 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
     }
     stage_mask_rows8(a, RL, bx, by, bm, x0, y0, m0, B, src_mask);
     __syncthreads();
-    if (a.exp & 8) return;
     if (halo) {
         // what stencils centred on band nodes read: LSM_GHOST nodes along each axis and the 3^3 box
         for (int t = threadIdx.x; t < a.ty * a.tm; t += blockDim.x) {
@@ -729,7 +724,6 @@ __global__ void __launch_bounds__(256) band_search3_kernel(BandArgs a, const uns
                     want = false;
                 }
             }
-            if (a.exp & 16) want = false;
             if (want) {
                 const int I[3] = {x, y, m};
                 int P[3] = {0, 0, 0};
@@ -1150,7 +1144,6 @@ __global__ void __launch_bounds__(256) band_halo_bits_kernel(BandArgs a, const u
     const int nxv = a.n[0] - x0;
     const unsigned xvalid = nxv >= 32 ? 0xffffffffu : ((1u << nxv) - 1u);
     for (int e = threadIdx.x; e < 4 * wpt; e += blockDim.x) {
-        if (a.exp & 32) break;                                   // timing experiment: no halo bytes
         const int p = e & 3, row = e >> 2, ry = row % a.ty, i = row / a.ty;
         if (y0 + ry >= a.n[1] || m0 + i >= a.n[2]) continue;
         const unsigned hw = anyh ? ((unsigned)(T[row] >> ap) & xvalid) : 0u, h8 = (hw >> (8 * p)) & 0xffu;
@@ -1345,11 +1338,10 @@ __global__ void __launch_bounds__(256) band_tiles_kernel(BandArgs a, const unsig
     if (threadIdx.x == 0) tiles[tile] = any ? 1 : 0;
 }
 
-// work[t] = OR of active over the 3^N tile neighbourhood of t;  head[t] (may be NULL) = number of bricks of the stage piece that
-// starts at tile t, 0 if none does.  Stage pieces: two active bricks that follow each other along the march axis (an aligned
-// pair: the lower one has an even brick index) are marched by ONE workgroup — a brick pays 2G planes of prologue for its mc = 8.
-__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work, unsigned char* head,
-                                                        unsigned* zero_face, int* zero_flags) {
+// work[t] = OR of active over the 3^N tile neighbourhood of t.  (Stage pieces of two bricks marched by one workgroup were tried in
+// round 3 — the launch 6 % slower, the step 1 % faster at best — and are gone: a stage launch takes the active-tile list.)
+__global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsigned char* active, unsigned char* work, unsigned* zero_face,
+                                                        int* zero_flags) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {                       // counters the list / Δt kernels behind this one accumulate into
@@ -1367,15 +1359,6 @@ __global__ void __launch_bounds__(256) band_work_kernel(BandArgs a, const unsign
                 r |= active[X + a.nbx * (Y + a.nby * M)];
             }
     work[t] = r ? 1 : 0;
-    if (head) {
-        const unsigned P = a.nbx * a.nby;
-        unsigned char hd = 0;
-        if (active[t]) {
-            if ((bm & 1) == 0) hd = (unsigned char)(1 + ((bm + 1 < (int)a.nbm && active[t + P]) ? 1 : 0));
-            else if (!active[t - P]) hd = 1;
-        }
-        head[t] = a.pieces ? hd : (active[t] ? 1 : 0);
-    }
 }
 
 // compact, ordered lists of the active tiles and of the work tiles (active or next to one), so that the
@@ -1391,12 +1374,11 @@ __device__ __forceinline__ unsigned nz_bytes(unsigned long long w) {       // nu
     w |= w >> 4; w |= w >> 2; w |= w >> 1;
     return (unsigned)__builtin_popcountll(w & 0x0101010101010101ull);
 }
-__global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsigned char* active, const unsigned char* work,
-                                                          const unsigned char* head, int* act_list, int* work_list, int* stage_list,
-                                                          unsigned* counts) {
-    __shared__ unsigned red[3][16], wsum[3][16];
+__global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsigned char* active, const unsigned char* work, int* act_list,
+                                                          int* work_list, unsigned* counts) {
+    __shared__ unsigned red[2][16], wsum[2][16];
     const unsigned ntiles = a.nbx * a.nby * a.nbm;
-    const bool words = (((unsigned long long)active | (unsigned long long)work | (unsigned long long)head) & 7ull) == 0;
+    const bool words = (((unsigned long long)active | (unsigned long long)work) & 7ull) == 0;
     auto flags8 = [&](const unsigned char* p, unsigned t) -> unsigned long long {   // flags of tiles t .. t+7 (t % 8 == 0)
         if (t >= ntiles) return 0ull;
         if (words && t + 8 <= ntiles) return *(const unsigned long long*)(p + t);
@@ -1410,36 +1392,34 @@ __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsi
         return v;
     };
     // offset of this chunk = set flags in the chunks before it
-    unsigned pa = 0, pw = 0, ps = 0;
+    unsigned pa = 0, pw = 0;
     for (unsigned cb = 0; cb < blockIdx.x; ++cb) {
         const unsigned t = cb * LISTS_CHUNK + threadIdx.x * 8;
         pa += nz_bytes(flags8(active, t));
         pw += nz_bytes(flags8(work, t));
-        ps += nz_bytes(flags8(head, t));
     }
-    pa = wave_sum(pa); pw = wave_sum(pw); ps = wave_sum(ps);
-    if (lane == 0) { red[0][wave] = pa; red[1][wave] = pw; red[2][wave] = ps; }
+    pa = wave_sum(pa); pw = wave_sum(pw);
+    if (lane == 0) { red[0][wave] = pa; red[1][wave] = pw; }
     // own chunk: one word per thread, exclusive scan over the workgroup (wave scan + 16 wave totals)
     const unsigned t0 = blockIdx.x * LISTS_CHUNK + threadIdx.x * 8;
-    const unsigned long long fa = flags8(active, t0), fw = flags8(work, t0), fs = flags8(head, t0);
-    const unsigned na = nz_bytes(fa), nw = nz_bytes(fw), ns = nz_bytes(fs);
-    unsigned ia = na, iw = nw, is = ns;                           // inclusive wave scans
+    const unsigned long long fa = flags8(active, t0), fw = flags8(work, t0);
+    const unsigned na = nz_bytes(fa), nw = nz_bytes(fw);
+    unsigned ia = na, iw = nw;                                    // inclusive wave scans
     for (int off = 1; off < 64; off <<= 1) {
-        const unsigned va = __shfl_up(ia, off, 64), vw = __shfl_up(iw, off, 64), vs = __shfl_up(is, off, 64);
-        if ((int)lane >= off) { ia += va; iw += vw; is += vs; }
+        const unsigned va = __shfl_up(ia, off, 64), vw = __shfl_up(iw, off, 64);
+        if ((int)lane >= off) { ia += va; iw += vw; }
     }
-    if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = iw; wsum[2][wave] = is; }
+    if (lane == 63) { wsum[0][wave] = ia; wsum[1][wave] = iw; }
     __syncthreads();
-    unsigned offa = 0, offw = 0, offs = 0, tota = 0, totw = 0, tots = 0;
+    unsigned offa = 0, offw = 0, tota = 0, totw = 0;
     for (unsigned w = 0; w < 16; ++w) {
-        offa += red[0][w]; offw += red[1][w]; offs += red[2][w];
-        if (w < wave) { offa += wsum[0][w]; offw += wsum[1][w]; offs += wsum[2][w]; }
-        tota += wsum[0][w]; totw += wsum[1][w]; tots += wsum[2][w];
+        offa += red[0][w]; offw += red[1][w];
+        if (w < wave) { offa += wsum[0][w]; offw += wsum[1][w]; }
+        tota += wsum[0][w]; totw += wsum[1][w];
     }
-    ia = offa + ia - na; iw = offw + iw - nw; is = offs + is - ns;
+    ia = offa + ia - na; iw = offw + iw - nw;
     unsigned nbd = 0;
     for (unsigned k = 0; k < 8; ++k) {
-        if ((fs >> (8 * k)) & 0xff) stage_list[is++] = (int)((t0 + k) | ((unsigned)(((fs >> (8 * k)) & 0xff) - 1) << 24));   // tile | (bricks - 1) << 24
         if ((fa >> (8 * k)) & 0xff) act_list[ia++] = (int)(t0 + k);
         if ((fw >> (8 * k)) & 0xff) {
             work_list[iw++] = (int)(t0 + k);
@@ -1452,11 +1432,10 @@ __global__ void __launch_bounds__(1024) band_lists_kernel(BandArgs a, const unsi
     nbd = wave_sum(nbd);
     if (lane == 0 && nbd) atomicAdd(&counts[2], nbd);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        unsigned ba = 0, bw = 0, bs = 0;
-        for (unsigned w = 0; w < 16; ++w) { ba += red[0][w]; bw += red[1][w]; bs += red[2][w]; }
+        unsigned ba = 0, bw = 0;
+        for (unsigned w = 0; w < 16; ++w) { ba += red[0][w]; bw += red[1][w]; }
         counts[0] = ba + tota;
         counts[1] = bw + totw;
-        counts[3] = bs + tots;
     }
 }
 
@@ -1579,16 +1558,14 @@ void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned ch
     if (no_tiles(a)) return;
     hipLaunchKernelGGL(band_tiles_kernel, tile_grid(a), dim3(256), 0, s, a, mask, tiles);
 }
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, unsigned* zero_face,
-                      int* zero_flags, hipStream_t s) {
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned* zero_face, int* zero_flags, hipStream_t s) {
     const unsigned nt = a.nbx * a.nby * a.nbm;
-    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work, head, zero_face, zero_flags);
+    hipLaunchKernelGGL(band_work_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, a, active, work, zero_face, zero_flags);
 }
-void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, const unsigned char* head, int* act_list,
-                       int* work_list, int* stage_list, unsigned* counts, hipStream_t s) {
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list, unsigned* counts,
+                       hipStream_t s) {
     const unsigned ntiles = a.nbx * a.nby * a.nbm;      // counts[2] (face tiles) is accumulated: cleared by the band_work launch before this one
-    hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, head, act_list, work_list,
-                       stage_list, counts);
+    hipLaunchKernelGGL(band_lists_kernel, dim3((ntiles + LISTS_CHUNK - 1) / LISTS_CHUNK), dim3(1024), 0, s, a, active, work, act_list, work_list, counts);
 }
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s) {
     if (no_tiles(a)) return;

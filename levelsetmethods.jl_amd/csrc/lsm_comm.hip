@@ -117,9 +117,9 @@ struct LocalGroup {
     std::string why;
 };
 
-std::chrono::milliseconds comm_timeout() {
-    static const long long ms = getenv("LSM_COMM_TIMEOUT_MS") ? atoll(getenv("LSM_COMM_TIMEOUT_MS")) : 60000ll;
-    return std::chrono::milliseconds(ms > 0 ? ms : 60000ll);
+std::chrono::milliseconds comm_timeout(const LsmHandle* h) {
+    const int ms = h ? h->tune.comm_timeout_ms : lsm::lsm_tuning_env().comm_timeout_ms;
+    return std::chrono::milliseconds(ms > 0 ? ms : 60000);
 }
 
 }  // namespace
@@ -234,7 +234,7 @@ int make_comm(LsmHandle* h, int transport, int rank, int world, LsmComm** out) {
     c->up = face_up ? (rank < world - 1 ? rank + 1 : 0) : -1;
     c->wrap_dn = face_dn && rank == 0;
     c->wrap_up = face_up && rank == world - 1;
-    c->overlap = !(getenv("LSM_SLAB_OVERLAP") && getenv("LSM_SLAB_OVERLAP")[0] == '0');
+    c->overlap = h->tune.slab_overlap != 0;
     c->seq = 0; c->pending = false; c->failed.store(false); c->nccl = nullptr; c->nccl_aborted.store(false); c->d_dt = nullptr; c->h_dt = nullptr; c->grp = nullptr;
     c->stream = nullptr;
     for (auto& e : c->ev_ready) e = nullptr;
@@ -338,7 +338,7 @@ int local_enqueue(LsmHandle* h, LocalGroup* g, unsigned long long seq) {
 template <class P>
 int group_wait(LsmHandle* h, LsmComm* c, std::unique_lock<std::mutex>& lk, P done, const char* what) {
     LocalGroup* g = c->grp;
-    const auto deadline = std::chrono::steady_clock::now() + comm_timeout();
+    const auto deadline = std::chrono::steady_clock::now() + comm_timeout(h);
     while (!done()) {
         if (g->failed) { c->failed.store(true); return lsm_fail(h, LSM_ERR_COMM, std::string(what) + ": " + g->why); }
         if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout && !done() && !g->failed) {
@@ -429,7 +429,7 @@ int exchange_wait(LsmHandle* h, const char* what) {
 // host wait for the handle's stream that gives up when the communicator fails or the timeout passes
 int stream_wait(LsmHandle* h, LsmComm* c, const char* what) {
     const auto t0 = std::chrono::steady_clock::now();
-    const auto deadline = t0 + comm_timeout();
+    const auto deadline = t0 + comm_timeout(h);
     for (;;) {
         const hipError_t e = hipStreamQuery(h->stream);
         if (e == hipSuccess) return LSM_OK;

@@ -37,17 +37,16 @@ struct LsmHandle {
     // lsm_band_status): with them the band kernels launch one block per listed tile instead of one per tile
     int* d_act_list;
     int* d_work_list;
-    int* d_stage_list;                 // stage pieces: tile | (bricks - 1) << 24 (lsm_band.hip, band_work_kernel)
-    unsigned char* d_head;             // per tile: bricks of the stage piece starting there
     unsigned* d_lcounts;
     const void* lists_tiles;           // the tile-flag buffer the lists describe
     int lists_mc;
     bool lists_host_valid;
     const void* halo_n_key;            // the device counter whose value lsm_band_status last read (NULL: unknown on the host)
     long long halo_n;
-    unsigned nact, nwork, nface, nstage;   // list lengths; work tiles on a face of the grid; stage pieces
-    bool no_lists;                     // LSM_BAND_NO_LISTS=1: always launch over all tiles (A/B switch)
-    bool band_bytes;                   // LSM_BAND_BYTES=1: byte-mask band kernels in 3-D too (A/B switch)
+    unsigned nact, nwork, nface;       // list lengths; work tiles on a face of the grid
+    lsm::LsmTuning tune;               // tuning switches: the environment's (read once per process) unless lsm_set_tuning changed them
+    bool no_lists;                     // = tune.band_no_lists: always launch over all tiles
+    bool band_bytes;                   // = tune.band_bytes: byte-mask band kernels in 3-D too
     double* d_partial;   // 2 * MAXB doubles
     int* d_flag;
     double* d_result;    // 16 doubles: [0..1] reductions, [2..6] lsm_band_status, [8..11] Δt of the next step prefetched by lsm_band_update

@@ -16,6 +16,30 @@ __device__ __forceinline__ void st_val(void* p, long long i, int f32, double v) 
     else static_cast<double*>(p)[i] = v;
 }
 
+// Tuning switches (include/lsm.h, lsm_set_tuning).  The environment is read ONCE per process (lsm_tuning_env), every handle starts
+// from that copy, lsm_set_tuning changes one handle's; the launchers see the handle's through StageArgs::tune.
+struct LsmTuning {
+    int stage_tail;         // LSM_STAGE_TAIL        planes per chunk of a dense 3-D launch's graded tail (0 = no tail)          16
+    int stage_tail_dyn;     // LSM_STAGE_TAIL_DYN    % spare workgroups of the dynamic tail (0 = static tail)                    25
+    int stage_mc;           // LSM_STAGE_MC          planes per march chunk in 3-D (0 = 64, shorter on small grids)               0
+    int stage_mc2;          // LSM_STAGE_MC2         rows per march chunk in 2-D (0 = 8)                                         0
+    int pairs;              // LSM_PAIRS             two nodes per thread for the dense single-term kernels                      1
+    int stage_generic;      // LSM_STAGE_GENERIC     general stage variants instead of the plain ones (diagnostic)               0
+    int xredirect;          // LSM_XREDIRECT         x / y ghosts of copy-type faces served by the stage kernel's loads          1
+    int ghost_full_depth;   // LSM_GHOST_FULL_DEPTH  fills write all three ghost layers whatever the step reads                  0
+    int band_bricks;        // LSM_BAND_BRICKS       band stage with one lane per band node (stage_brick.h)                      1
+    int band_bits;          // LSM_BAND_BITS         update_band! on bit rows                                                     1
+    int band_cfl_prefetch;  // LSM_BAND_CFL_PREFETCH Δt of the next step reduced right behind the update                         1
+    int band_bytes;         // LSM_BAND_BYTES        byte-mask band kernels in 3-D too (the general path, forced)                0
+    int band_no_lists;      // LSM_BAND_NO_LISTS     band kernels over all tiles instead of the compact lists (forced)           0
+    int status_spin;        // LSM_STATUS_SPIN       lsm_band_status spins on the status kernel's ticket                         1
+    int slab_overlap;       // LSM_SLAB_OVERLAP      slab stages update the interface planes first (read at attach time)         1
+    int comm_timeout_ms;    // LSM_COMM_TIMEOUT_MS   a rank's wait for its peers                                              60000
+    int layout_align;       // LSM_LAYOUT_ALIGN      rows of the padded layout on 64-byte lines (read by lsm_create)             1
+};
+const LsmTuning& lsm_tuning_env();
+int* lsm_tuning_field(LsmTuning& t, const char* name);      // NULL: no such switch
+
 // term-kind slots inside a fused stage kernel
 enum { SLOT_ADV = 0, SLOT_NM = 1, SLOT_CURV = 2, SLOT_EIK = 3, NSLOTS = 4 };
 
@@ -68,7 +92,6 @@ struct StageArgs {
     // over the duration of a short workgroup instead of a long one
     unsigned nbig;
     int mc_tail;
-    int yfast;         // dense 3-D launches: the tiles of a chunk layer are numbered y-fastest (set by the launcher)
     // x ghosts resolved by the loads themselves (set by the whole-grid lsm_advance_* in FAST mode when both x faces copy ONE
     // node: periodic / symmetry / degree-0 extrapolation): a load of a node with x outside [0, n0) goes to the node the boundary
     // condition copies instead, and the ghost fill before the stage skips the x faces.  xkind[side] = LSM_BC_* of the x faces.
@@ -97,6 +120,7 @@ struct StageArgs {
     unsigned nbrick_list;
     int f32;                           // psi / phin / out / out2 hold float (LSM_DTYPE_F32); side arrays stay fp64
     unsigned long long* stamp;         // diagnostic build (-DLSM_STAMP, `make stamp`): per-workgroup {Δs_memtime, Δs_memrealtime} of the plane loop
+    const LsmTuning* tune;             // host side: the handle's tuning switches (the launchers read them; never NULL)
 };
 
 #define LSM_TAIL_SLOTS 16
@@ -162,13 +186,10 @@ struct BandArgs {
     const int* list;             // compact list of the tiles to visit (NULL = every tile gets a block)
     unsigned nlist;
     int f32;                     // the value arrays hold float
-    int force_bytes;             // A/B switch (LSM_BAND_BYTES at lsm_create): byte-mask kernels in 3-D too
-    int pieces;                  // stage pieces may span two bricks (LSM_BAND_PIECES=0: one brick per workgroup)
-    int exp;                     // timing experiments (LSM_BAND_EXP bit mask, results are WRONG): see lsm_band.hip
+    int force_bytes;             // LsmTuning::band_bytes: byte-mask kernels in 3-D too
 };
 void launch_band_copy(const BandArgs& a, const unsigned char* in, unsigned char* out, unsigned char* zero, hipStream_t s);
-void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned char* head, unsigned* zero_face,
-                      int* zero_flags, hipStream_t s);
+void launch_band_work(const BandArgs& a, const unsigned char* active, unsigned char* work, unsigned* zero_face, int* zero_flags, hipStream_t s);
 void launch_band_cut(const BandArgs& a, const void* v, const unsigned char* old_mask, unsigned char* seed, hipStream_t s);
 void launch_band_dilate(const BandArgs& a, const unsigned char* in, unsigned char* out, hipStream_t s);
 void launch_band_grow(const BandArgs& a, const void* v, const unsigned char* old_mask, int nl, unsigned char* new_mask,
@@ -206,8 +227,8 @@ void launch_band_apply(const BandArgs& a, const BandEntry* list, const unsigned*
 struct BandBcArgs { int kind[3][2]; int degree[3][2]; };
 void launch_band_halo_bc(const BandArgs& a, const BandBcArgs& bc, int d, int r, const unsigned char* band, unsigned char* halo,
                          hipStream_t s);
-void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, const unsigned char* head, int* act_list,
-                       int* work_list, int* stage_list, unsigned* counts, hipStream_t s);
+void launch_band_lists(const BandArgs& a, const unsigned char* active, const unsigned char* work, int* act_list, int* work_list, unsigned* counts,
+                       hipStream_t s);
 void launch_band_tiles(const BandArgs& a, const unsigned char* mask, unsigned char* tiles, hipStream_t s);
 void launch_band_count(const BandArgs& a, const unsigned char* mask, unsigned long long* count, hipStream_t s);
 // tile geometry of the stage kernel for a given dimension and march chunk (stage_tu.hip)

@@ -16,7 +16,7 @@
 //      stride — so the arithmetic, and every bit of the result, is stage_tile's.
 // Lanes are idle only in the last batch of a wave.  Plain variants of the FAST build (constant or ROTATION advection
 // coefficient, constant speed / curvature coefficient, one output, terms in slot order) on the aligned layout; everything
-// else stays with stage_tile.  LSM_BAND_BRICKS=0 is the A/B switch.
+// else stays with stage_tile.  LsmTuning::band_bricks = 0 (LSM_BAND_BRICKS) keeps the tiled stage for everything.
 #pragma once
 #include "stage_kernel.h"
 
@@ -187,13 +187,12 @@ __global__ void __launch_bounds__(NT) brick_kernel(const StageArgs a, const unsi
 
 // is this launch a case for the brick kernel?  (adv / nm / curv: the pass's combination)
 inline bool bricks_applicable(int ADV, int NM, int CURV, const StageArgs& a) {
-    const char* env = getenv("LSM_BAND_BRICKS");                     // A/B switch (read per launch: tests flip it)
-    if (env && env[0] == '0') return false;
+    if (!a.tune->band_bricks) return false;                          // LsmTuning: the tiled band stage
     if (!a.mask || !a.brick_list || a.mc <= 0 || a.nbrick_list == 0 || a.out2 || !a.natural || a.xredirect || a.yredirect) return false;
     if ((NM && a.nm.kind != LSM_COEFF_CONST) || (CURV && a.curv.kind != LSM_COEFF_CONST)) return false;
     const int ak = ADV ? a.adv.kind : (int)LSM_COEFF_CONST;
     if (ak != LSM_COEFF_CONST && ak != LSM_COEFF_ROTATION) return false;
-    if (a.me <= a.mb || getenv("LSM_STAGE_GENERIC")) return false;
+    if (a.me <= a.mb || a.tune->stage_generic) return false;
     // 16-byte rows: the aligned layout (lsm_create), 16-byte aligned arrays; 32-bit byte offsets inside a pass
     const long long seg = a.f32 ? 4 : 2, lead = a.origin - LSM_GHOST * a.s2 - LSM_GHOST * a.s1;
     if (lead < BrickCfg::XL || lead % seg || a.s1 % 8 || a.s2 % 8 || a.origin % 8) return false;
@@ -211,16 +210,16 @@ int launch_bricks(const StageArgs& a, hipStream_t s) {
     b.nb[0] = (a.n[0] + BrickCfg::TX - 1) / BrickCfg::TX;
     b.nb[1] = (a.n[1] + BrickCfg::TY - 1) / BrickCfg::TY;
     b.nb[2] = (a.me - a.mb + a.mc - 1) / a.mc;
-    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0; b.yfast = 0;
-    // planes per workgroup and workgroup size (A/B: LSM_BRICK_SHAPE=0 takes 512 threads x 16 planes for float fields)
-    const char* shp = getenv("LSM_BRICK_SHAPE");
-    const bool small = !(shp && shp[0] == '0');
-    const int bz = (b.f32 && !small) ? 16 : 8;
+    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0;
+    // 8 planes per workgroup: 256 threads for float fields (35 KB of LDS, four workgroups per CU in different phases), 512 for fp64
+    // (67 KB, two per CU).  Measured against it: 512 threads x 16 planes for float (0.559 against 0.537-0.544 ms per 768³ step),
+    // 256 x 4 for fp64 (0.665 against 0.642).
+    constexpr int bz = 8;
     const unsigned sub_per = (unsigned)((a.mc + bz - 1) / bz);
     const unsigned nwg = a.nbrick_list * sub_per;
     const dim3 grid(((nwg + 7u) / 8u) * 8u);
 #define LSM_BRICK(STT, AKK, NTT, BZZ) hipLaunchKernelGGL((brick_kernel<ADV, NM, CURV, EIK, STT, AKK, NTT, BZZ>), grid, dim3(NTT), 0, s, b, sub_per)
-#define LSM_BRICK_ST(AKK) do { if (!b.f32) LSM_BRICK(double, AKK, 512, 8); else if (small) LSM_BRICK(float, AKK, 256, 8); else LSM_BRICK(float, AKK, 512, 16); } while (0)
+#define LSM_BRICK_ST(AKK) do { if (!b.f32) LSM_BRICK(double, AKK, 512, 8); else LSM_BRICK(float, AKK, 256, 8); } while (0)
     if constexpr (ADV != 0) {
         if (ak == LSM_COEFF_ROTATION) { LSM_BRICK_ST(LSM_COEFF_ROTATION); return hipGetLastError() == hipSuccess ? 0 : -1; }
     }

@@ -72,11 +72,8 @@ LSM_DEV __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, int range = (int)0x8
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, range, 0x00020000);
 }
 constexpr unsigned LSM_OOB_OFFSET = 0xC0000000u;
-// AUX = cache policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1); LSM_NT_STREAM (A/B switch) marks the
-// once-touched streams — ϕⁿ of the convex combination and the output — non-temporal
-#ifndef LSM_NT_STREAM
-#define LSM_NT_STREAM 0
-#endif
+// AUX = cache policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Everything is loaded and stored with the
+// default policy: non-temporal ϕⁿ loads and result stores were measured in round 2 and were slower everywhere (upwind +25 %).
 template <class ST, int AUX = 0>
 LSM_DEV double ldg(const ST* base, unsigned boff, int range = (int)0x80000000u) {   // range 0: returns 0, no access
     if constexpr (sizeof(ST) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(plane_rsrc(base, range), boff, 0, AUX));
@@ -249,7 +246,7 @@ LSM_DEV void node_operands(const StageArgs& a, const NodeIO& io, const double pr
     if constexpr (EIK == 1) op.s0 = ldg(uniform_ptr(a.s0 + io.plane_off), io.ocold);
     // always issued (a load inside a branch costs the loop its exact wait counts); when the base is ψ the
     // descriptor's range is 0: the load returns 0 and touches no memory
-    op.phin = ldg<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol,
+    op.phin = ldg<ST, 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + io.plane_off), io.ocol,
                   __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u));
     if (AK < 0 && a.out2 && a.out2_accum) op.out2 = ldg(uniform_ptr(reinterpret_cast<const ST*>(a.out2) + io.plane_off), io.ocol);
 }
@@ -641,7 +638,7 @@ LSM_DEV void node_update(const StageArgs& a, const NV& nv, const NodeOps& op, do
 template <class ST, bool PLAIN>
 LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_out, double r_out2) {
     if (!on) return;
-    stg<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + io.plane_off), io.ocol, r_out);
+    stg<ST, 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + io.plane_off), io.ocol, r_out);
     if (!PLAIN && a.out2) stg(uniform_ptr(reinterpret_cast<ST*>(a.out2) + io.plane_off), io.ocol, r_out2);
 }
 
@@ -654,30 +651,7 @@ LSM_DEV void node_store(const StageArgs& a, const NodeIO& io, bool on, double r_
 #ifndef LSM_ZROT
 #define LSM_ZROT 1
 #endif
-// A/B switches: the ring (and the unrolled plane loop) for every 3-D FAST kernel, not only the WENO5 ones; and PFX extra
-// planes of ψ in flight (ring of 2G+1+PFX entries: the newest PFX+1 are loads that have not been waited for yet)
-#ifndef LSM_STAGE_YFAST_DEFAULT
-#define LSM_STAGE_YFAST_DEFAULT 0     // dense 3-D launches: tiles of a layer numbered y-fastest (LSM_STAGE_YFAST overrides at run time)
-#endif
-#ifndef LSM_STAGE_TAIL_DYN_DEFAULT
-#define LSM_STAGE_TAIL_DYN_DEFAULT 25 // dynamic tail: % of spare tail workgroups (0 = off; LSM_STAGE_TAIL_DYN overrides at run time)
-#endif
-#ifndef LSM_STAGE_TAIL_DEFAULT
-#define LSM_STAGE_TAIL_DEFAULT 16  // planes per chunk of the graded tail (0 = off; LSM_STAGE_TAIL overrides at run time)
-#endif
-#ifndef LSM_ZROT_ALL
-#define LSM_ZROT_ALL 0
-#endif
-#ifndef LSM_PFX
-#define LSM_PFX 0
-#endif
-// build switches of the A/B experiments recorded in DESIGN.md §3.1 (tools/variants.sh): occupancy hint, and a
-// timing-only build without the per-plane barrier (its results are wrong)
-#ifdef LSM_EXP_NOBARRIER
-#define LSM_BARRIER() do {} while (0)
-#else
 #define LSM_BARRIER() __syncthreads()
-#endif
 // One tile (a 32×8 or 64×8 column of `mc` planes; a row segment in 2-D; 256 nodes in 1-D) of one stage: the body of the
 // stage kernels below.  `slot` only names the tile in the diagnostic build's stamp buffer.
 template <int NDIM, int ADV, int NM, int CURV, int EIK, int TX, int TY, int MC, class ST, int AK, bool MASKED>
@@ -690,8 +664,8 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     constexpr int LEAD = (CURV && MARCH) ? 1 : 0;
     constexpr int NSLOT = MARCH ? 2 * LEAD + 2 : 1;
     // the march line as a register ring with the plane loop unrolled 2G+1-fold: the WENO5 kernels in 3-D (7 moves a plane)
-    constexpr bool ZROT = LSM_ZROT && !LSM_STRICT && NDIM == 3 && (ADV == 2 || LSM_ZROT_ALL);
-    constexpr int PFX = (ZROT && ADV != 2) ? LSM_PFX : 0;
+    // (the ring for the lighter 3-D kernels too, with 0 / 1 / 2 more planes of ψ in flight: ±3 %, no pattern — round 2, not kept)
+    constexpr bool ZROT = LSM_ZROT && !LSM_STRICT && NDIM == 3 && ADV == 2;
     constexpr int W = TX + 2 * G;
     constexpr int H = HAS_Y ? TY + 2 * G : 1;
     constexpr int HW = H * W;
@@ -703,27 +677,20 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     constexpr int HPT = (NH + NT - 1) / NT;
     static_assert(!HAS_Y || TY > 1 || true, "");
     __shared__ double tile[NSLOT * HW];
+    // (Round 4, measured and not kept: faces with ExtrapolationBC{P}, P >= 1, resolved here — the face tiles summing their weighted
+    // ghosts from the nodes they hold in LDS behind a second barrier per plane, so that a step's fill writes the march axis' ghost
+    // planes only (54 -> 14 µs at 512³).  Correct (FAST tolerance, tests/test_gpu_parity.py keeps the cases), and slower: the
+    // NormalMotion + curvature stage 0.741 -> 0.808 ms, BASELINE config 3 2.38 -> 2.49 ms per step — the second barrier takes the
+    // slack between a tile's waves and the sums cost every variant registers.  profiles/r4/exp_weighted_faces_in_kernel_ab.log.)
 
 #ifdef LSM_STAMP
     const unsigned long long st_rb = __builtin_amdgcn_s_memrealtime();
 #endif
-    int nbricks = 1;                                               // narrow band: a listed piece may span two bricks of the march axis
-    if (a.tile_list) { const unsigned e = (unsigned)a.tile_list[tile_id]; tile_id = e & 0x00ffffffu; nbricks = (int)(e >> 24) + 1; }
+    if (a.tile_list) tile_id = (unsigned)a.tile_list[tile_id];     // narrow band: the compact list of active tiles
     else if (a.tile_active && !a.tile_active[tile_id]) return;   // narrow band: no band node in this tile
-    // dense 3-D launches number the tiles of a layer y-fastest (StageArgs::yfast): workgroups dispatched one after the other are
-    // then y-neighbours — they start together, march in phase and find each other's rows (6 of the 14 a tile loads per plane)
-    // in the XCD's L2.  Band tile flags and lists keep the x-fastest numbering.
-    const int yf = NDIM == 3 ? a.yfast : 0;
-    unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1];
+    // tiles are numbered x fastest (y-fastest and 2 x 2 ... 8 x 8 blocks of tiles were measured in rounds 2 and 3: +2 % and ±0.1 %)
+    const unsigned tbx = tile_id % a.nb[0], tby = (tile_id / a.nb[0]) % a.nb[1];
     const unsigned tbm = tile_id / (a.nb[0] * a.nb[1]);
-    if (yf == 1) {
-        tbx = (tile_id / a.nb[1]) % a.nb[0];
-        tby = tile_id % a.nb[1];
-    } else if (yf >= 2) {            // blocks of yf x yf tiles (extents divisible by yf: checked by the launcher)
-        const unsigned B = (unsigned)yf, inl = tile_id % (a.nb[0] * a.nb[1]), blk = inl / (B * B), w = inl % (B * B), bpr = a.nb[0] / B;
-        tbx = (blk % bpr) * B + w % B;
-        tby = (blk / bpr) * B + w / B;
-    }
 
     const int tid = threadIdx.x;
     int tx = tid % TX, ty = tid / TX;
@@ -769,7 +736,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     const int mcl = a.mc > 0 ? a.mc : MC;
     const int mc = tail_tile ? a.mc_tail : mcl;
     const int m0 = MARCH ? (tail_tile ? a.mb + (int)a.nbig * mcl + (int)(tbm - a.nbig) * mc : a.mb + (int)tbm * mc) : 0;
-    const int m1 = MARCH ? (m0 + mc * nbricks < a.me ? m0 + mc * nbricks : a.me) : 1;
+    const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
     auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
     auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
@@ -839,9 +806,9 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         // the halo elements of the first LDS planes — and only then wait and fill the LDS planes
         PlaneTab pt;
         plane_tab<NDIM, ADV, NM, CURV, AK>(a, m0 + a.goff[NDIM - 1], pt);
-        double zl[2 * G + 1 + PFX];
+        double zl[2 * G + 1];
 #pragma unroll
-        for (int j = 0; j <= 2 * G + PFX; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
+        for (int j = 0; j <= 2 * G; ++j) zl[j] = ldg(plane(m0 - G + j), ocol);
         double hp[2 * LEAD + 1][HPT > 0 ? HPT : 1];
 #pragma unroll
         for (int pl = -LEAD; pl <= LEAD; ++pl) {
@@ -865,7 +832,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         long long po = corner + (long long)m0 * sm;     // plane m of the pointwise operands (ϕⁿ, outputs, mask, side arrays)
         unsigned mk_next = 0;
         if constexpr (!NOMASK) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
-        const ST* Pnx = plane(m0 + G + PFX);            // plane m+G+PFX of ψ, advanced (and clamped) before each use
+        const ST* Pnx = plane(m0 + G);            // plane m+G of ψ, advanced (and clamped) before each use
         const ST* Pn = plane(m0 + LEAD);
         const int plast = nm + G - 1;
         const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
@@ -885,11 +852,11 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
 #endif
         // One plane of the march.  ROT > 0: the register line is a ring (see NodeView) and the loop below is unrolled
         // ROT-fold with the rotation Rc a compile-time constant of each copy.
-        constexpr int ROT = ZROT ? 2 * G + 1 + PFX : 0, RM = ROT > 0 ? ROT : 1;
+        constexpr int ROT = ZROT ? 2 * G + 1 : 0, RM = ROT > 0 ? ROT : 1;
         auto plane_iter = [&](auto Rc, int m) {
             constexpr int R = decltype(Rc)::value;
             // issue the next plane's loads early; they land in LDS after this plane's arithmetic
-            Pnx = uniform_ptr(m + 1 + G + PFX <= plast ? Pnx + sm : Pnx);
+            Pnx = uniform_ptr(m + 1 + G <= plast ? Pnx + sm : Pnx);
             Pn = uniform_ptr(m + 1 + LEAD <= plast ? Pn + sm : Pn);
             const double nxt = ldg(Pnx, ocol);
             double hn[HPT > 0 ? HPT : 1];
@@ -1160,7 +1127,7 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
         opB = opA;
         if constexpr (EIK == 1) ldg2(uniform_ptr(a.s0 + po), ocold0, opA.s0, opB.s0);
         // always issued; when the base is ψ the descriptor's range is 0: the load returns 0 and touches no memory
-        ldg2<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + po), ocol0, opA.phin, opB.phin, prange);
+        ldg2<ST, 0>(uniform_ptr(reinterpret_cast<const ST*>(a.phin) + po), ocol0, opA.phin, opB.phin, prange);
         LSM_BARRIER();
         double rA = 0.0, rB = 0.0, r2 = 0.0;
         if (any_active) {
@@ -1180,7 +1147,7 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
 #pragma unroll
         for (int h = 0; h < HPT; ++h)
             if (hv[h]) tile[wslot * HW + hl[h]] = hn[h];
-        if (active) stg2<ST, LSM_NT_STREAM ? 2 : 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + po), ocol0, rA, rB);
+        if (active) stg2<ST, 0>(uniform_ptr(reinterpret_cast<ST*>(a.out) + po), ocol0, rA, rB);
         po += sm;
     }
 }
@@ -1243,10 +1210,10 @@ constexpr bool pair_combo() {
 }
 template <int ADV, int NM, int CURV, int EIK>
 bool launch_pairs(const StageArgs& a, hipStream_t s) {
-    const int env = getenv("LSM_PAIRS") ? atoi(getenv("LSM_PAIRS")) : 1;     // A/B switch (read per launch: tests flip it): 0 = one node per thread everywhere
+    const int env = a.tune->pairs;                                            // 0 = one node per thread everywhere
     const bool consts = (!ADV || a.adv.kind == LSM_COEFF_CONST) && (!NM || a.nm.kind == LSM_COEFF_CONST) && (!CURV || a.curv.kind == LSM_COEFF_CONST);
     if (!env || a.mask || a.tile_active || a.tile_list || a.mc > 0 || a.out2 || !a.natural || !consts || (a.n[0] & 1) || a.n[0] < 128 || a.me <= a.mb ||
-        getenv("LSM_STAGE_GENERIC"))
+        a.tune->stage_generic)
         return false;
     static_assert(!CURV, "the pair kernels serve the axis-aligned single terms");
     constexpr int TX = 64, TY = 8, MC = LSM_MC3;
@@ -1257,7 +1224,7 @@ bool launch_pairs(const StageArgs& a, hipStream_t s) {
     while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
     b.mc = mc;
     b.nb[2] = (a.me - a.mb + mc - 1) / mc;
-    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0; b.yfast = 0;
+    b.nbig = 0; b.mc_tail = 0; b.tail_wgs = 0;
     const unsigned ntiles = b.nb[0] * b.nb[1] * b.nb[2];
     const dim3 grid(((ntiles + 7u) / 8u) * 8u), block(TX * TY);
     if (b.f32) hipLaunchKernelGGL((stage_kernel2<ADV, NM, CURV, EIK, TX, TY, MC, float>), grid, block, 0, s, b);
@@ -1287,18 +1254,12 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     b.nb[1] = NDIM == 3 ? (a.n[1] + T::TY - 1) / T::TY : 1;
     if (NDIM >= 2 && a.me <= a.mb) return;
     int mc = a.mc > 0 ? a.mc : T::MC;
-    if (a.mc <= 0 && NDIM == 3) {   // A/B switch: planes per march chunk
-        static const int mc_env = getenv("LSM_STAGE_MC") ? atoi(getenv("LSM_STAGE_MC")) : 0;
-        if (mc_env > 0) mc = mc_env;
-    }
-    if (a.mc <= 0 && NDIM == 2) {   // A/B switch: rows per march chunk in 2-D
-        static const int mc_env = getenv("LSM_STAGE_MC2") ? atoi(getenv("LSM_STAGE_MC2")) : 0;
-        if (mc_env > 0) mc = mc_env;
-    }
+    if (a.mc <= 0 && NDIM == 3 && a.tune->stage_mc > 0) mc = a.tune->stage_mc;       // planes per march chunk
+    if (a.mc <= 0 && NDIM == 2 && a.tune->stage_mc2 > 0) mc = a.tune->stage_mc2;     // rows per march chunk in 2-D
     // small grids: a workgroup marching 64 planes leaves most of the 256 CUs idle (48^3 = 12 workgroups, a serial walk
     // of 48 planes each).  Shorter chunks — down to 8 planes — until there are ~8 workgroups per CU; each chunk pays its
     // 2G+1 planes of prologue, which is why large grids keep the long march.
-    if (a.mc <= 0 && NDIM == 3 && !a.mask && !(getenv("LSM_STAGE_MC") && atoi(getenv("LSM_STAGE_MC")) > 0))
+    if (a.mc <= 0 && NDIM == 3 && !a.mask && !(a.tune->stage_mc > 0))
         while (mc > 8 && (long long)b.nb[0] * b.nb[1] * ((a.me - a.mb + mc - 1) / mc) < 2048) mc /= 2;
     b.mc = mc;
     b.nb[2] = NDIM >= 2 ? (a.me - a.mb + mc - 1) / mc : 1;
@@ -1307,7 +1268,7 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     // graded tail: a launch ends with every workgroup slot finishing its last chunk at a different moment — on average half a
     // chunk's duration of the whole chip is lost.  Cut the last layer into short chunks and run them last.
     if (NDIM == 3 && a.mc <= 0 && !a.mask && !a.tile_list && !a.tile_active && b.nb[2] >= 4) {
-        static const int tail_env = getenv("LSM_STAGE_TAIL") ? atoi(getenv("LSM_STAGE_TAIL")) : LSM_STAGE_TAIL_DEFAULT;
+        const int tail_env = a.tune->stage_tail;
         if (tail_env > 0 && tail_env < mc) {
             b.nbig = b.nb[2] - 1;
             b.mc_tail = tail_env;
@@ -1318,16 +1279,11 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
     const unsigned ntiles = b.tile_list ? b.ntile_list : b.nb[0] * b.nb[1] * b.nb[2];
     if (ntiles == 0) return;
     dim3 grid(((ntiles + 7u) / 8u) * 8u, 1, 1);
-    {
-        static const int yfast_env = getenv("LSM_STAGE_YFAST") ? atoi(getenv("LSM_STAGE_YFAST")) : LSM_STAGE_YFAST_DEFAULT;
-        b.yfast = (NDIM == 3 && yfast_env && !a.mask && !a.tile_list && !a.tile_active) ? yfast_env : 0;
-        if (b.yfast >= 2 && (b.nb[0] % (unsigned)b.yfast || b.nb[1] % (unsigned)b.yfast)) b.yfast = 0;
-    }
     b.tail_wgs = 0;
     if (b.mc_tail > 0) {
         const unsigned nbigt = b.nb[0] * b.nb[1] * b.nbig;
         grid.x = 8u * ((nbigt + 7u) / 8u + (ntiles - nbigt + 7u) / 8u);
-        static const int dyn_env = getenv("LSM_STAGE_TAIL_DYN") ? atoi(getenv("LSM_STAGE_TAIL_DYN")) : LSM_STAGE_TAIL_DYN_DEFAULT;
+        const int dyn_env = a.tune->stage_tail_dyn;
         if (dyn_env > 0 && a.tail_ring && a.tail_slot_host && nbigt % 8u == 0) {
             const unsigned ntail = ntiles - nbigt;
             b.tail_wgs = ((ntail + ntail * (unsigned)dyn_env / 100u) + 7u) / 8u * 8u;      // dyn_env % spare workgroups
@@ -1340,7 +1296,7 @@ void launch_tiled(const StageArgs& a, hipStream_t s) {
 #if !LSM_STRICT
     int ak = -1;
     const bool plain = !b.out2 && b.natural && (!NM || b.nm.kind == LSM_COEFF_CONST) && (!CURV || b.curv.kind == LSM_COEFF_CONST) &&
-                       !getenv("LSM_STAGE_GENERIC");
+                       !b.tune->stage_generic;
     const bool masked = b.mask != nullptr;          // narrow band: the plain variants exist with and without the band mask
     if (plain) ak = ADV ? b.adv.kind : (int)LSM_COEFF_CONST;
     if (ak == LSM_COEFF_FIELD) ak = -1;

@@ -289,13 +289,12 @@ def test_fallback_band_paths_give_the_same_band_and_values(lsm, monkeypatch, env
     compact lists).  Both must step a 3-D band to bitwise the same state as the default path."""
     grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (40, 36, 44))
     phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.1) ** 2 + x[1] ** 2 + (x[2] + 0.05) ** 2) - 0.55, grid)
-    mk = lambda: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02)),
-                                      ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2), integrator=lsm.RK3())
+    mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02)),
+                                           ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2), integrator=lsm.RK3(), **kw)
     ref = mk()
     lsm.integrate_(ref, 0.03)
-    monkeypatch.setenv(env, "1")
-    alt = mk()                      # the switches are read when the handle is created
-    monkeypatch.delenv(env)
+    alt = mk(tuning={env: 1})       # lsm_set_tuning right after lsm_create: the band is built on that path too
+    assert alt.backend.get_tuning(env) == 1 and ref.backend.get_tuning(env) == 0
     lsm.integrate_(alt, 0.03)
     a, b = ref.current_state(), alt.current_state()
     m = a.active_mask()
@@ -320,16 +319,14 @@ def test_brick_stage_equals_the_tiled_band_stage_bitwise(lsm, monkeypatch, case,
         "weno_eik": (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.EikonalReinitializationTerm()),
         "nm_curv": (lsm.NormalMotionTerm(0.4), lsm.CurvatureTerm(-0.03)),
     }[case]
-    mk = lambda: lsm.LevelSetEquation(terms=terms, ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2),
-                                      integrator=lsm.RK3())
+    mk = lambda **kw: lsm.LevelSetEquation(terms=terms, ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.ExtrapolationBC(2),
+                                           integrator=lsm.RK3(), **kw)
     out = []
-    for bricks in ("1", "0"):
-        monkeypatch.setenv("LSM_BAND_BRICKS", bricks)
-        eq = mk()
+    for bricks in (1, 0):
+        eq = mk(tuning={"LSM_BAND_BRICKS": bricks})
         lsm.integrate_(eq, 0.02)
         st = eq.current_state()
         out.append((st.active_mask(), st.values()))
-    monkeypatch.delenv("LSM_BAND_BRICKS")
     (ma, va), (mb, vb) = out
     assert ma.sum() > 5000 and np.array_equal(ma, mb)
     assert ma[0].any() or ma[:, 0].any() or ma[:, :, -1].any()          # the band reaches a face
@@ -583,9 +580,9 @@ def test_bit_row_update_equals_the_byte_mask_update_bitwise(lsm, monkeypatch, dt
     phi = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.03) ** 2 + (x[1] + 0.02) ** 2 + x[2] ** 2) - 0.3, grid, dtype=dt)
 
     def run(bits):
-        monkeypatch.setenv("LSM_BAND_BITS", "1" if bits else "0")
         eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(2.0, (0.4, 0.0)), lsm.WENO5()), lsm.CurvatureTerm(-0.01)),
-                                  ic=lsm.NarrowBandMeshField(phi, nlayers=nlayers), bc=lsm.NeumannBC(), integrator=lsm.RK3())
+                                  ic=lsm.NarrowBandMeshField(phi, nlayers=nlayers), bc=lsm.NeumannBC(), integrator=lsm.RK3(),
+                                  tuning={"LSM_BAND_BITS": 1 if bits else 0})
         masks = []
         tc = 0.0
         for _ in range(8):

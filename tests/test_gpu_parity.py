@@ -197,11 +197,11 @@ def test_plain_and_general_kernel_variants_agree(hip, orc, shape, monkeypatch):
         cases.append([("adv", ("rot", 1.3, 0.45, 0.55), "weno5"), ("eik", phi)])
     for specs in cases:
         for base_mode in (0, 1, 2, 3):
-            monkeypatch.delenv("LSM_STAGE_GENERIC", raising=False)
+            c.be.set_tuning("LSM_STAGE_GENERIC", 0)
             plain, want, _, _ = _run_stage(c, orc, specs, phi, base_mode, t=0.4)
-            monkeypatch.setenv("LSM_STAGE_GENERIC", "1")
+            c.be.set_tuning("LSM_STAGE_GENERIC", 1)
             general, _, _, _ = _run_stage(c, orc, specs, phi, base_mode, t=0.4)
-            monkeypatch.delenv("LSM_STAGE_GENERIC", raising=False)
+            c.be.set_tuning("LSM_STAGE_GENERIC", 0)
             scale = np.abs(want).max()
             assert np.abs(plain - want).max() <= TOL_STAGE * scale, (specs[0][:1], base_mode, np.abs(plain - want).max())
             assert np.abs(general - want).max() <= TOL_STAGE * scale, (specs[0][:1], base_mode, np.abs(general - want).max())
@@ -412,12 +412,51 @@ def test_pair_kernels_match_the_oracle_and_the_one_node_kernels(hip, orc, monkey
         phi = np.asfortranarray(phi.astype(np.float32).astype(np.float64))
     specs = _fix_specs(PAIRS[name], 3, phi)
     for base_mode in (0, 1, 2, 3):
-        monkeypatch.setenv("LSM_PAIRS", "1")
+        c.be.set_tuning("LSM_PAIRS", 1)
         got, want, _, _ = _run_stage(c, orc, specs, phi, base_mode)
-        monkeypatch.setenv("LSM_PAIRS", "0")
+        c.be.set_tuning("LSM_PAIRS", 0)
         one, _, _, _ = _run_stage(c, orc, specs, phi, base_mode)
         assert np.array_equal(got, one), (name, base_mode, np.abs(got - one).max())
         if dt == np.float64:
             assert np.abs(got - want).max() <= TOL_STAGE * np.abs(want).max(), (name, base_mode)
         else:
             assert np.abs(got - want.astype(np.float32).astype(np.float64)).max() <= 2.4e-7 * np.abs(want).max(), (name, base_mode)
+
+
+WEIGHTED_TERMS = {
+    "nm+curv": [("nm", ("const", (0.1,))), ("curv", ("const", (-0.1,)))],          # BASELINE config 3's pair
+    "upwind": [("adv", ("const", (0.5, 0.25, -1.0)), "upwind")],
+    "eik": [("eik", None)],
+    "nm": [("nm", ("const", (-0.4,)))],
+    "curv": [("curv", ("const", (-0.05,)))],
+    "nm+eik_multipass": [("nm", ("const", (0.3,))), ("eik", None), ("curv", ("const", (-0.02,)))],
+}
+
+
+@pytest.mark.parametrize("terms", list(WEIGHTED_TERMS))
+@pytest.mark.parametrize("bcspec", [
+    ("extrapolation", 2),                                                            # config 3's boundary condition, every face
+    [(("extrapolation", 1), ("extrapolation", 3)), (("extrapolation", 2), "neumann"), "neumann"],      # a degree per side, a copy-type side beside a weighted one
+    [("symmetry", ("extrapolation", 2)), ("extrapolation", 3), ("extrapolation", 1)],
+], ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("integ", ["rk3", "fe"])
+def test_weighted_and_copy_type_faces_side_by_side(hip, orc, terms, bcspec, integ):
+    """ExtrapolationBC{P}, P = 1..3, on x / y faces of a 3-D grid whose extents are multiples of every tile shape (128 | n1, 8 | n2), with
+    every face weighted, a degree per side, and copy-type sides (served by the stage kernel's loads in FAST steps) beside weighted
+    ones (materialised by the fill) — the two mechanisms meet in the tile corners.  The step must equal the oracle's literal
+    loop (dense arrays, recursive ghost resolution: src/boundaryconditions.jl:134-144, src/meshfield.jl:248-260) to FAST's tolerance.
+    (Round 4 resolved the weighted faces inside the kernel as well; these cases caught its bugs and stay, the code did not:
+    DESIGN.md §3.1.)"""
+    shape = (128, 16, 11)
+    c = hip.Case(shape, bcspec, mode="fast")
+    phi = _rand_field(shape, 21)
+    specs = _fix_specs(WEIGHTED_TERMS[terms], 3, phi)
+    ref = phi.copy(order="F")
+    tc, dt = 0.2, 1.5e-3
+    orc.advance(INTEG[integ], c.grid, c.bc, ref, c.dense_terms(specs), tc, dt)
+    _, arr = c.terms(specs)
+    d_phi = c.to_dev(np.nan_to_num(c.pad(phi, fill=False), nan=0.0))       # ghost layers hold zeros: a kernel that read them would show
+    b1, b2 = c.be.alloc(), c.be.alloc()
+    c.be.advance_single(integ, arr, len(specs), d_phi, b1, b2, tc, dt, None)
+    got = c.interior(c.to_host(d_phi))
+    assert np.abs(got - ref).max() <= 3 * TOL_STAGE * np.abs(ref).max(), float(np.abs(got - ref).max())

@@ -1,5 +1,5 @@
 """Random 3-D band runs, brick stage (csrc/stage_brick.h) against the tiled band stage (LSM_BAND_BRICKS=0), bit for bit:
-python tools/brick_stress.py [seed] [cases]   (LSM_BAND_MC / LSM_BRICK_SHAPE from the environment)"""
+python tools/brick_stress.py [seed] [cases]   (LSM_BAND_MC from the environment)"""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np
@@ -35,12 +35,12 @@ for it in range(ncase):
     phi = lsm.MeshField(lambda x: np.sqrt(sum((x[d] - ctr[d]) ** 2 for d in range(3))) - r, grid, dtype=dt)
     out = []
     try:
-        for bricks in ("1", "0"):
-            os.environ["LSM_BAND_BRICKS"] = bricks
+        for bricks in (1, 0):
             rng.bit_generator.state = state          # the same random coefficients for both runs
             _ = tuple(rng.integers(0, 3) for _ in range(3))
             terms = tuple(menu[n]() for n in names)
-            eq = lsm.LevelSetEquation(terms=terms, ic=lsm.NarrowBandMeshField(phi, nlayers=nl), bc=bcs, integrator=integ())
+            eq = lsm.LevelSetEquation(terms=terms, ic=lsm.NarrowBandMeshField(phi, nlayers=nl), bc=bcs, integrator=integ(),
+                                      tuning={"LSM_BAND_BRICKS": bricks})
             lsm.integrate_(eq, 4 * 0.5 * min(grid.meshsize()))
             st = eq.current_state()
             out.append((st.active_mask(), st.values()))

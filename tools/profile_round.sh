@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: tools/profile_round.sh <outdir> [round, default r3]  (GPU box) — everything profiles/<round>/ is made from, for the build in the tree:
+# usage: tools/profile_round.sh <outdir> [round, default r4]  (GPU box) — everything profiles/<round>/ is made from, for the build in the tree:
 #   rocprofv3 kernel trace + PMC passes of the default bench (separate passes per counter group, as the guide prescribes),
 #   the in-kernel clock of the diagnostic build, the bench line itself, configs 2/3/5, the single-term stages with their
 #   HBM traffic, the slab-overhead run and the reinit run.  tools/make_profile_summary.py turns the CSVs into
 #   pmc_per_dispatch.json (keyed by the sha256 of the kernel sources).
 set -u
 OUT=$1
-RND=${2:-r3}
+RND=${2:-r4}
 mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
@@ -29,7 +29,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5 -- python3
 python3 tools/configs.py terms > $OUT/terms.json 2> $OUT/terms.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/terms_pmc_f -- python3 tools/configs.py terms > /dev/null 2> $OUT/terms_pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/terms_pmc_w -- python3 tools/configs.py terms > /dev/null 2> $OUT/terms_pmc_w.err
+# issue / wait / LDS counters of every member of the stage-kernel family (DESIGN.md §3.1's "issue-bound" / "latency-bound" sentences cite these)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/terms_pmc_1 -- python3 tools/configs.py terms > /dev/null 2> $OUT/terms_pmc_1.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $OUT/terms_pmc_2 -- python3 tools/configs.py terms > /dev/null 2> $OUT/terms_pmc_2.err
+python3 tools/pmc_terms_summary.py $OUT $OUT/pmc_terms.json > $OUT/pmc_terms.log 2>&1
 python3 tools/slab_overhead.py > $OUT/slab_overhead.json 2> $OUT/slab_overhead.err
+python3 bench.py --transport local --gpus 8 --steps 6 --warmup 2 --prewarm 4 --no-cpu-baseline > $OUT/bench_local8.json 2> $OUT/bench_local8.err
 python3 tools/reinit_bench.py > $OUT/reinit_bench.json 2> $OUT/reinit_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reinit -- python3 tools/reinit_bench.py > /dev/null 2> $OUT/trace_reinit.err
 ls $OUT
