@@ -76,10 +76,10 @@ def cpu_baseline(n_sample, threads, steps=1):
 
 def committed_profile(n, world, mode):
     """The rocprofv3 PMC summary committed for THIS build of the kernels and THIS workload, or None.
-    profiles/r3/pmc_per_dispatch.json (r2's for a build that still has r2's kernel sources) records the sha256 of the kernel sources it was measured on (the GPU box has no
+    profiles/r4/pmc_per_dispatch.json (an earlier round's for a build that still has that round's kernel sources) records the sha256 of the kernel sources it was measured on (the GPU box has no
     .git, so the key is the source text, not a commit) and the workload; anything else gets no traffic figure."""
     import lsm_amd
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4", "r3", "r2"):
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_per_dispatch.json")))
         except Exception:
@@ -336,7 +336,7 @@ def run(args, lsm, torch, ctx):
                      "stage_time_fraction_of_step": round(stage_ms / (el * 1e3), 4)},
     }
     # Counter-derived figures cannot be collected from inside this process: they come from the rocprofv3 passes of this
-    # same command committed under profiles/r3/ (tools/profile_round.sh) — and only when that summary was measured on the
+    # same command committed under profiles/r4/ (tools/profile_round.sh) — and only when that summary was measured on the
     # kernel sources this library was built from, on this grid, GPU count and mode.  Otherwise traffic stays null.
     #   traffic = 2·FETCH_SIZE + WRITE_SIZE (KiB -> B) per launch: FETCH_SIZE counts half of the bytes of the 8-byte-per-lane
     #   reads of this kernel, WRITE_SIZE is exact (calibrated on known-traffic kernels of the same access width).

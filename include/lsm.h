@@ -465,6 +465,8 @@ int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int 
  *   LSM_STAGE_GENERIC            0   general stage kernels instead of the plain variants (diagnostic: same results)
  *   LSM_XREDIRECT                1   FAST steps: x / y ghosts of copy-type faces (periodic, symmetry, NeumannBC) are read from the
  *                                    node the boundary condition copies instead of being materialised (a copied -0.0 stays -0.0)
+ *   LSM_MREDIRECT                1   ... and NeumannBC faces of the march (last) axis by clamping the march at the boundary plane: a FAST
+ *                                    step whose other faces are served by the loads launches no ghost fill at all
  *   LSM_GHOST_FULL_DEPTH         0   ghost fills write all LSM_GHOST layers (default: the layers the step's stencils read)
  *   LSM_BAND_BRICKS              1   narrow band: the stage with one lane per band node (0: the tiled stage; bitwise equal)
  *   LSM_BAND_BITS                1   narrow band: update_band! on bit rows (0: the byte-mask kernels; bitwise equal)

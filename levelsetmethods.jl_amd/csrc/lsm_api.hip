@@ -86,6 +86,7 @@ const LsmTuning& lsm_tuning_env() {
         u.pairs = env_int("LSM_PAIRS", 1);
         u.stage_generic = flag("LSM_STAGE_GENERIC");
         u.xredirect = env_int("LSM_XREDIRECT", 1);
+        u.mredirect = env_int("LSM_MREDIRECT", 1);
         u.ghost_full_depth = flag("LSM_GHOST_FULL_DEPTH");
         u.band_bricks = env_int("LSM_BAND_BRICKS", 1);
         u.band_bits = env_int("LSM_BAND_BITS", 1);
@@ -105,7 +106,7 @@ int* lsm_tuning_field(LsmTuning& t, const char* name) {
     if (!name) return nullptr;
     const struct { const char* n; int* p; } tab[] = {
         {"LSM_STAGE_TAIL", &t.stage_tail}, {"LSM_STAGE_TAIL_DYN", &t.stage_tail_dyn}, {"LSM_STAGE_MC", &t.stage_mc}, {"LSM_STAGE_MC2", &t.stage_mc2},
-        {"LSM_PAIRS", &t.pairs}, {"LSM_STAGE_GENERIC", &t.stage_generic}, {"LSM_XREDIRECT", &t.xredirect},
+        {"LSM_PAIRS", &t.pairs}, {"LSM_STAGE_GENERIC", &t.stage_generic}, {"LSM_XREDIRECT", &t.xredirect}, {"LSM_MREDIRECT", &t.mredirect},
         {"LSM_GHOST_FULL_DEPTH", &t.ghost_full_depth}, {"LSM_BAND_BRICKS", &t.band_bricks}, {"LSM_BAND_BITS", &t.band_bits},
         {"LSM_BAND_CFL_PREFETCH", &t.band_cfl_prefetch}, {"LSM_BAND_BYTES", &t.band_bytes}, {"LSM_BAND_NO_LISTS", &t.band_no_lists},
         {"LSM_STATUS_SPIN", &t.status_spin}, {"LSM_SLAB_OVERLAP", &t.slab_overlap}, {"LSM_COMM_TIMEOUT_MS", &t.comm_timeout_ms},
@@ -188,6 +189,7 @@ int lsm_create(const LsmGrid* grid, const LsmBc bc[LSM_MAX_DIM][2], const LsmSla
     h->ghost_depth = LSM_GHOST;
     h->slab_depth_valid = LSM_GHOST;     // a slab's ghosts are the host's to make valid before its first step (include/lsm.h)
     h->status_ticket = 0;
+    h->mredirect = false;
     h->reinit_ws = nullptr;
     h->d_pf_flag = nullptr;
     memset(&h->band_cfl, 0, sizeof(h->band_cfl));
@@ -449,6 +451,10 @@ static void base_args(const LsmHandle* h, StageArgs& a) {
     a.xkind[0] = h->bc[0][0].kind; a.xkind[1] = h->bc[0][1].kind;
     a.yredirect = h->yredirect ? 1 : 0;
     a.ykind[0] = h->bc[1][0].kind; a.ykind[1] = h->bc[1][1].kind;
+    for (int sd = 0; sd < 2; ++sd) {
+        const LsmBc& mb = h->bc[h->grid.ndim - 1][sd];
+        a.mredirect[sd] = h->mredirect && mb.kind == LSM_BC_EXTRAPOLATION && mb.degree == 0 ? 1 : 0;
+    }
     a.stamp = h->d_stamp;
     a.tune = &h->tune;
     a.nbig = 0; a.mc_tail = 0;
@@ -781,10 +787,19 @@ struct XRedirect {
         h->xredirect = on;
         // dimension 2 of a 3-D grid likewise (in 2-D it is the march axis: its ghost rows stay in memory)
         h->yredirect = on && h->grid.ndim == 3 && h->nloc[1] >= 2 * LSM_GHOST + 2 && copies(1, 0) && copies(1, 1);
+        // The march axis (round 4): a NeumannBC ghost plane is a copy of the boundary plane, so the march CLAMPS there (two scalars in
+        // the kernel, the plane pointers still advance by one plane — the general map of round 2, with its recomputed pointers, cost
+        // the kernel its scalar registers).  When every face of the march axis is NeumannBC (or a slab interface, whose planes are
+        // exchanged) and the other dimensions are served by the loads, a step of the headline equation or of BASELINE config 2
+        // launches no ghost fill at all.
+        const int L = h->grid.ndim - 1;
+        auto clamps = [&](int sd) { const LsmBc& b = h->bc[L][sd]; return b.kind == LSM_BC_NONE || (b.kind == LSM_BC_EXTRAPOLATION && b.degree == 0); };
+        h->mredirect = on && h->tune.mredirect && (h->grid.ndim == 2 || h->yredirect) && h->nloc[L] >= 2 * LSM_GHOST + 2 && clamps(0) && clamps(1);
     }
-    ~XRedirect() { h->xredirect = false; h->yredirect = false; h->ghost_depth = LSM_GHOST; }
+    ~XRedirect() { h->xredirect = false; h->yredirect = false; h->mredirect = false; h->ghost_depth = LSM_GHOST; }
     int fill(void* field) const {
         if (!on) return lsm_fill_ghosts(h, field, 7, nullptr);
+        if (h->mredirect) return LSM_OK;         // nothing of the padded array's ghost layers is read inside this step
         return fill_ghosts_fused(h, field, 0, h->nloc[h->grid.ndim - 1], 1, h->stream, true, h->yredirect);
     }
 };
@@ -802,7 +817,8 @@ static int stage_slab(LsmHandle* h, const LsmTerm* terms, int nterms, const void
     const int B = h->ghost_depth + 1;            // the planes the exchange sends (lsm_halo_start); +1: the periodic wrap sends planes shifted by one node
     if (!lsm_comm_overlap(h) || N < 2 || nloc < 2 * B + 1) {
         LSM_TRY(lsm_stage(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, nullptr));
-        if (h->xredirect) LSM_TRY(fill_ghosts_fused(h, out, 0, nloc, 1, h->stream, true, h->yredirect));
+        if (h->mredirect) {}                                  // every ghost the step reads is served by the loads or exchanged
+        else if (h->xredirect) LSM_TRY(fill_ghosts_fused(h, out, 0, nloc, 1, h->stream, true, h->yredirect));
         else LSM_TRY(lsm_fill_ghosts(h, out, 7, nullptr));
         return lsm_halo_exchange(h, out);
     }
@@ -815,6 +831,7 @@ static int stage_slab(LsmHandle* h, const LsmTerm* terms, int nterms, const void
     LSM_TRY(lsm_stage_planes(h, terms, nterms, psi, phin, out, out2, base_mode, cdt, cdt2, t, B, nloc - B, nullptr));
     LSM_TRY(lsm_fill_ghosts_planes(h, out, B, nloc - B, 0, nullptr));
     LSM_TRY(lsm_halo_wait(h));
+    if (h->mredirect) return LSM_OK;                         // NeumannBC end faces: the march clamps at the boundary plane
     return lsm_fill_ghosts(h, out, 1 << (N - 1), nullptr);   // physical ghost planes of the last dimension (interfaces are skipped)
 }
 

@@ -89,6 +89,7 @@ struct LsmHandle {
     lsm::ReinitWorkspace* reinit_ws;   // reinitialize!'s device buffers, kept between calls (grow-only)
     LsmComm* comm;       // multi-GPU: attached by lsm_comm_attach_* (slab handles)
     bool yredirect;                // ... and those of dimension 2 (3-D)
+    bool mredirect;                // ... and the march axis' NeumannBC faces are served by clamping the march at the boundary plane: no fill is left
     int ghost_depth;               // ghost layers the fills write and the slab exchange sends: LSM_GHOST, or what the step in progress reads (XRedirect)
     int slab_depth_valid;          // slab steps: ghost layers of ϕ (boundary conditions + neighbours' planes) the last step left valid
     unsigned* d_tail_ctr;          // ring of LSM_TAIL_SLOTS ticket counters of the dynamic tail (each launch resets its own)

@@ -26,6 +26,7 @@ struct LsmTuning {
     int pairs;              // LSM_PAIRS             two nodes per thread for the dense single-term kernels                      1
     int stage_generic;      // LSM_STAGE_GENERIC     general stage variants instead of the plain ones (diagnostic)               0
     int xredirect;          // LSM_XREDIRECT         x / y ghosts of copy-type faces served by the stage kernel's loads          1
+    int mredirect;          // LSM_MREDIRECT         ... and NeumannBC faces of the march axis by clamping the march: no fill left  1
     int ghost_full_depth;   // LSM_GHOST_FULL_DEPTH  fills write all three ghost layers whatever the step reads                  0
     int band_bricks;        // LSM_BAND_BRICKS       band stage with one lane per band node (stage_brick.h)                      1
     int band_bits;          // LSM_BAND_BITS         update_band! on bit rows                                                     1
@@ -112,6 +113,7 @@ struct StageArgs {
     int xkind[2];
     int yredirect;     // the same for dimension 2 of a 3-D grid (the tile's y): its ghost rows are skipped by the fills as well
     int ykind[2];
+    int mredirect[2];  // march axis, per face: NeumannBC — the ghost planes ARE the boundary plane, the march clamps there and they are never read
     const unsigned char* mask;         // narrow band: store only where mask != 0 (NULL = dense)
     const unsigned char* tile_active;  // narrow band: per-tile activity flags (NULL = all tiles)
     const int* tile_list;              // narrow band: compact list of the tiles to run (NULL = all tiles get a block)

@@ -737,7 +737,11 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
     const int mc = tail_tile ? a.mc_tail : mcl;
     const int m0 = MARCH ? (tail_tile ? a.mb + (int)a.nbig * mcl + (int)(tbm - a.nbig) * mc : a.mb + (int)tbm * mc) : 0;
     const int m1 = MARCH ? (m0 + mc < a.me ? m0 + mc : a.me) : 1;
-    auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
+    // StageArgs::mredirect (NeumannBC on a face of the march axis): a ghost plane IS the boundary plane (degree-0 extrapolation copies
+    // it, src/boundaryconditions.jl:134-144 with P = 0), so the march clamps at the boundary plane instead of at the last ghost
+    // plane and that face's ghost planes are never read — nor filled.  Two scalars; the plane pointers still advance by one plane.
+    const int mlo = (MARCH && a.mredirect[0]) ? 0 : -G, mhi = (MARCH && a.mredirect[1]) ? nm - 1 : nm + G - 1;
+    auto clampM = [&](int p) { return p < mlo ? mlo : (p > mhi ? mhi : p); };
     // wave-uniform plane base (SGPRs) + 32-bit per-thread offset: no vector address arithmetic in the loop
     auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
 
@@ -834,7 +838,7 @@ __device__ __forceinline__ void stage_tile(const StageArgs& a, unsigned tile_id,
         if constexpr (!NOMASK) mk_next = ldg_u8(uniform_ptr(a.mask + po), ocold >> 3, mrange);
         const ST* Pnx = plane(m0 + G);            // plane m+G of ψ, advanced (and clamped) before each use
         const ST* Pn = plane(m0 + LEAD);
-        const int plast = nm + G - 1;
+        const int plast = mhi;
         const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
         // sign bits of the march-invariant parts of u_d (plain variants; see NodeOps::negs)
         constexpr bool SIGNS_KNOWN = PLAIN && ADV == 2 && AK != LSM_COEFF_FIELD && !LSM_STRICT;
@@ -1051,7 +1055,8 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
     const int mc = a.mc > 0 ? a.mc : MC;
     const int m0 = a.mb + (int)tbm * mc;
     const int m1 = m0 + mc < a.me ? m0 + mc : a.me;
-    auto clampM = [&](int p) { return p < -G ? -G : (p > nm + G - 1 ? nm + G - 1 : p); };
+    const int mlo = a.mredirect[0] ? 0 : -G, mhi = a.mredirect[1] ? nm - 1 : nm + G - 1;      // (stage_tile: StageArgs::mredirect)
+    auto clampM = [&](int p) { return p < mlo ? mlo : (p > mhi ? mhi : p); };
     auto plane = [&](int p) { return uniform_ptr(reinterpret_cast<const ST*>(a.psi) + (corner + (long long)clampM(p) * sm)); };
     auto ldpair = [&](const ST* P, double& x, double& y) {
         if (whole) ldg2(P, ocol0, x, y);
@@ -1107,7 +1112,7 @@ __device__ __forceinline__ void stage_tile2(const StageArgs& a, unsigned tile_id
     long long po = corner + (long long)m0 * sm;
     const ST* Pnx = plane(m0 + G);
     const ST* Pn = plane(m0);
-    const int plast = nm + G - 1;
+    const int plast = mhi;
     const bool any_active = __builtin_amdgcn_ballot_w64(active) != 0;
     const int prange = __builtin_amdgcn_readfirstlane(a.base_mode == LSM_BASE_PSI ? 0 : (int)0x80000000u);
     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -1,4 +1,4 @@
-"""DESIGN.md's measurement tables are generated from the tracked files under profiles/r3/ (tools/design_tables.py): the document
+"""DESIGN.md's measurement tables are generated from the tracked files under profiles/r4/ (tools/design_tables.py): the document
 must contain exactly what the generator prints today, so a figure cannot drift from the file it cites."""
 import os
 import sys

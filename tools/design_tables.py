@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = "r3"
+RND = "r4"
 P = os.path.join(ROOT, "profiles", RND)
 
 
@@ -70,6 +70,16 @@ def configs_table():
         w, o, pl = s["whole_grid_ms"], s["two_local_slabs_overlap_ms"], s["two_local_slabs_plain_ms"]
         rows.append("| slab decomposition on one device (two in-process ranks sharing the GPU, %s) | whole grid %.2f ms, two slabs %.2f ms with the boundary-first split (+%.1f %%), %.2f ms without (+%.1f %%); device-to-device copies stand in for xGMI | `slab_overhead.json` |" % (
             "×".join(str(k) for k in s["grid"]), w, o, 100 * (o / w - 1), pl, 100 * (pl / w - 1)))
+    f = os.path.join(P, "bench_local8.json")
+    if os.path.exists(f):
+        b = json.load(open(f))
+        rows.append("| the scaling run's code on ONE device (`bench.py --gpus 8 --transport local`: 8 rank threads, in-process transport, %s) | %.2f ms per step for the 8 slabs = %.3f ms per slab-step; self-check of the two stage orders: %s | `bench_local8.json` |" % (
+            "×".join(str(k) for k in b["config"]["grid"]), b["ms_per_step"], b["ms_per_step"] / b["config"]["ranks"], b["config"]["halo_overlap"]))
+    f = os.path.join(P, "reinit_bench.json")
+    if os.path.exists(f):
+        r = json.load(open(f))
+        rows.append("| `reinitialize!` (`tools/reinit_bench.py`) | " + "; ".join("%d³ %s, %.2f M nodes: %.2f ms" % (
+            x["n"], "band" if x["band"] else "dense", x["active_nodes"] / 1e6, x["ms"]) for x in r) + " | `reinit_bench.json`, `kernel_stats_reinit.csv` |")
     return "\n".join(rows)
 
 

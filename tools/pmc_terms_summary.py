@@ -48,7 +48,7 @@ for k, c in sorted(avg.items()):
         cyc = c["GRBM_GUI_ACTIVE"] / 8.0
         d["valu_pipe_held_fraction"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / cyc, 3)
     if "SQ_WAVE_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"]:
-        d["waves_resident_per_cu"] = round(c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CU_CYCLES"], 2)
+        d["wave_cycles_per_busy_cu_cycle"] = round(c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CU_CYCLES"], 2)
     if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
         d["wave_cycles_waiting_for_an_instruction_fraction"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)
     if "SQ_WAIT_INST_LDS" in c and "SQ_WAVE_CYCLES_2" not in c and "SQ_WAIT_ANY" in c and c["SQ_WAIT_ANY"]:
