@@ -608,3 +608,71 @@ def test_bit_row_update_equals_the_byte_mask_update_bitwise(lsm, monkeypatch, dt
     assert np.array_equal(v0[m], v1[m])
     assert np.array_equal(h0, h1) and h0.sum() > m.sum() and c0 == c1 == int(h0.sum() - m.sum())
     assert np.array_equal(p0[h0], p1[h1])
+
+
+def test_band_buffers_rewritten_in_place_need_the_handles_state_rebuilt(lsm):
+    """include/lsm.h, lsm_band_invalidate: what the handle remembers about a band — compact tile lists, the halo list's length as the host
+    last read it, a prefetched Δt — is keyed by the ADDRESSES of the caller's buffers.  copy!(dst, src) (src/meshfield.jl:282-292) rewrites
+    dst's buffers in place with ANOTHER band: the host layer rebuilds that state (lsm_band_retile + lsm_band_status, as julia/ROCMeshField.jl's
+    copy! does), after which dst steps exactly as src does — bit for bit, Δt included.  And the bare lsm_band_invalidate is enough for
+    correctness: the kernels then run over all tiles and take the list's length from the device."""
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (72, 40, 48))
+    big = lsm.MeshField(lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.6, grid)
+    small = lsm.MeshField(lambda x: np.sqrt((x[0] - 0.2) ** 2 + (x[1] + 0.1) ** 2 + x[2] ** 2) - 0.3, grid)
+    terms = lambda: (lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.02))
+    mk = lambda phi: lsm.LevelSetEquation(terms=terms(), ic=lsm.NarrowBandMeshField(phi, nlayers=3), bc=lsm.NeumannBC(), integrator=lsm.RK3())
+
+    def steps(eq, n=3):
+        tc, dts = 0.0, []
+        for _ in range(n):
+            dt = 0.5 * eq.compute_cfl(tc)
+            eq._advance(tc, dt)
+            eq.update_band()
+            tc += dt
+            dts.append(dt)
+        st = eq.current_state()
+        return dts, st.active_mask(), st.values()
+
+    want_dts, want_m, want_v = steps(mk(small))
+    for how in ("copy!", "invalidate"):
+        eq, src = mk(big), mk(small)
+        steps(eq, 2)                                     # the handle holds lists, a halo count and a prefetched Δt of the BIG band
+        a, b = eq.state, src.state
+        if how == "copy!":
+            a.copy_(b)
+        else:                                            # the same rewrite by hand, and only the bare invalidation
+            eq.backend.copy_(a.buf, b.buf)
+            a.mask.copy_(b.mask); a.halo.copy_(b.halo); a.tiles.copy_(b.tiles)
+            nl = min(a._hlist.numel(), b._hlist.numel())     # (the big band's list is the longer one: the small band's entries fit)
+            assert 2 * int(b._hcount.item()) <= nl
+            a._hlist[:nl].copy_(b._hlist[:nl])
+            a._hcount.copy_(b._hcount)
+            from lsm_amd import _lib as L
+            L.check(eq.backend.h, eq.backend.lib.lsm_band_invalidate(eq.backend.h), "lsm_band_invalidate")
+            a.ghosts_dirty = True
+        dts, m, v = steps(eq)
+        assert dts == want_dts, (how, dts, want_dts)
+        assert np.array_equal(m, want_m) and np.array_equal(v[m], want_v[want_m]), how
+
+
+def test_tuning_switches_live_on_the_handle(lsm):
+    """include/lsm.h, "tuning switches": every handle starts from the environment's values (read once per process), lsm_set_tuning
+    changes one handle's, unknown names and the create-time switch are refused."""
+    from lsm_amd import _lib as L
+    grid = lsm.CartesianGrid((-1, -1), (1, 1), (40, 36))
+    ic = lsm.MeshField(lambda x: np.hypot(x[0], x[1]) - 0.5, grid)
+    mk = lambda **kw: lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.3),), ic=ic, bc=lsm.NeumannBC(), **kw)
+    a, b = mk(), mk(tuning={"LSM_STAGE_GENERIC": 1, "LSM_XREDIRECT": 0})
+    assert a.backend.get_tuning("LSM_STAGE_GENERIC") == 0 and b.backend.get_tuning("LSM_STAGE_GENERIC") == 1
+    assert a.backend.get_tuning("LSM_XREDIRECT") == 1 and b.backend.get_tuning("LSM_XREDIRECT") == 0
+    assert a.backend.get_tuning("LSM_STAGE_TAIL") == 16 and a.backend.get_tuning("LSM_COMM_TIMEOUT_MS") > 0
+    a.backend.set_tuning("LSM_STAGE_TAIL", 0)
+    assert a.backend.get_tuning("LSM_STAGE_TAIL") == 0 and b.backend.get_tuning("LSM_STAGE_TAIL") == 16
+    with pytest.raises(L.LsmError, match="no such switch"):
+        a.backend.set_tuning("LSM_STAGE_YFAST", 1)                  # an experiment that lost: its switch went with its code
+    with pytest.raises(L.LsmError, match="fixed when the handle is created"):
+        a.backend.set_tuning("LSM_LAYOUT_ALIGN", 0)
+    lsm.integrate_(a, 0.05)
+    lsm.integrate_(b, 0.05)                                        # general kernels, materialised ghosts: the same equation
+    va, vb = a.current_state().values(), b.current_state().values()
+    assert np.abs(va - vb).max() <= 1e-13 * np.abs(va).max()
