@@ -258,16 +258,21 @@ __global__ void __launch_bounds__(256) band_zero_kernel(BandArgs a, unsigned cha
 // instead of paying a stream synchronisation's wake-up (tens of microseconds of idle GPU per step).
 // pf.n > 0: Δt of the next step, prefetched (LsmHandle::BandCfl) — this kernel is also the second stage of those reductions
 // (cfl_final_kernel's arithmetic on the partial maxima of cfl_band_list_kernel): one small launch less per step.
-__global__ void __launch_bounds__(64) band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, BandStatusCfl pf, double* out,
-                                                         double ticket) {
+__global__ void __launch_bounds__(256) band_status_kernel(const unsigned* halo_count, const int* miss, const unsigned* lcounts, BandStatusCfl pf, double* out,
+                                                          double ticket) {
+    __shared__ double wmax[4];
     for (int s = 0; s < pf.n; ++s) {
         double best = 0.0;
-        for (int i = threadIdx.x; i < pf.npartials; i += 64) { const double v = pf.partial[s * pf.npartials + i]; best = v > best ? v : best; }
+        for (int i = threadIdx.x; i < pf.npartials; i += 256) { const double v = pf.partial[s * pf.npartials + i]; best = v > best ? v : best; }
         for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+        __syncthreads();
         if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) best = wmax[w] > best ? wmax[w] : best;
             const double cfl = pf.kind[s] == LSM_TERM_CURVATURE ? (pf.dxmin * pf.dxmin) / (2 * best) : 1 / best;
             out[6 + s] = pf.nanflag[s] ? __builtin_nan("") : cfl;
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         out[0] = (double)halo_count[0];
@@ -276,9 +281,9 @@ __global__ void __launch_bounds__(64) band_status_kernel(const unsigned* halo_co
         out[3] = lcounts ? (double)lcounts[1] : 0.0;
         out[4] = lcounts ? (double)lcounts[2] : 0.0;
         out[5] = 0.0;
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(out + 11) = ticket;
     }
-    __threadfence_system();
-    if (threadIdx.x == 0) *reinterpret_cast<volatile double*>(out + 11) = ticket;
 }
 
 // _nearest_band_node continued in global memory: ring entries [r0, nring) in order, bounds-checked
@@ -1493,7 +1498,7 @@ void launch_band_zero(const BandArgs& a, unsigned char* out, hipStream_t s) {
 }
 void launch_band_status(const unsigned* halo_count, const int* miss, const unsigned* lcounts, const BandStatusCfl& pf, double* out, double ticket,
                         hipStream_t s) {
-    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(64), 0, s, halo_count, miss, lcounts, pf, out, ticket);
+    hipLaunchKernelGGL(band_status_kernel, dim3(1), dim3(256), 0, s, halo_count, miss, lcounts, pf, out, ticket);
 }
 void launch_band_extrapolate(const BandArgs& a, const unsigned char* target, unsigned char* halo, const unsigned char* src_mask,
                              const signed char* ring, int nring, int nring_lds, const void* src, void* dst, int* miss,

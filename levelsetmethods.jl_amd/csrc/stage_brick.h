@@ -48,9 +48,9 @@ struct BrickCfg {
     // Row pitch of the LDS brick.  A lane reads ITS band node's stencil: the 32 lanes of a half-wave are consecutive entries of the
     // brick's node list (x fastest), i.e. runs of 8-12 nodes of three or four successive rows where the band's normal has an x
     // component — and a run of row r + 1 lands on the banks of row r's run shifted by the pitch mod 32 (32 banks of 4 bytes for
-    // ds_read_b32, 64 for ds_read_b64 with 8-byte elements: the same in elements).  Pitch 40 (= 8 mod 32) stacks runs of more
-    // than 8 nodes onto each other's banks (profiles/r3/band_step: SQ_LDS_BANK_CONFLICT 4.48 M > SQ_ACTIVE_INST_LDS 3.41 M cycles);
-    // 44 (= 12 mod 32) keeps runs of up to 12 nodes of four successive rows apart: 0, 12, 24, 4 (+ 8 = 12 again).
+    // ds_read_b32, 64 for ds_read_b64 with 8-byte elements: the same in elements).  44 (= 12 mod 32) keeps runs of up to 12 nodes of
+    // three successive rows apart where 40 (= 8) stacks them; measured −0.5 % per step, and SQ_LDS_BANK_CONFLICT unchanged at 1.3-1.4
+    // cycles per LDS-active cycle: 32 scattered addresses on 32 banks always find a pair, whatever the pitch.
     static constexpr int WP = LSM_BRICK_PITCH;
     static_assert(WP >= W && WP % 4 == 0, "rows hold the loaded elements and start on 16-byte boundaries");
 };
