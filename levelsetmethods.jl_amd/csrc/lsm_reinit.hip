@@ -15,12 +15,13 @@
 //    cheap conservative bound (|p - c| <= Λ·spread of the stencil values) runs over all cells and the
 //    reference's Bernstein test over the survivors.
 //  * closest point (src/sdf.jl:85-131,223-249): the nearest sample — exact, like the reference's KD-tree query:
-//    a cheap estimate of the closest point leads to the cells that hold it, and every cell meeting the ball of
-//    that radius around the node is then scanned (16 lanes per node; occupancy bits per cell); nodes without a
+//    a cheap estimate of the closest point (one lane per node) leads to the cells that hold it, and every cell meeting the
+//    ball of that radius around the node is then scanned (16 lanes per node; occupancy bits per cell); nodes without a
 //    usable estimate fall back to expanding shells of cells, then of 8^N-cell blocks — seeds a damped
-//    Newton–Lagrange solve on the seed cell's patch; up to 4 further near seeds are tried when it fails (the
-//    reference tries up to 10).
-// fp64 throughout, -ffp-contract=off.
+//    Newton–Lagrange solve on the seed cell's patch.  Where that solve fails, the NSEED nearest samples are collected by the
+//    shell search and tried in order in a second pass (the reference: nn first, then knn with up to 10).
+// fp64 throughout; -ffp-contract=off except inside the patch evaluation (cardinal functions and the tensor contraction), which
+// contracts to fma.
 #include <cmath>
 #include <vector>
 
@@ -59,6 +60,7 @@ __device__ __forceinline__ double bern(int m, int i, const double* tp, const dou
 // cardinal functions of one dimension at local coordinate t, derivatives w.r.t. x (1/h folded in)
 template <int NV>
 __device__ __forceinline__ void cardinal(const ReinitArgs& a, double t, double invh, bool second, Card<NV>& o) {
+#pragma clang fp contract(fast)
     const int n = a.order;       // NV - 1 (odd orders) or NV - 2 (even orders: least-squares fit of a larger stencil)
     double tp[NV], sp[NV];
     tp[0] = sp[0] = 1.0;
@@ -84,13 +86,53 @@ __device__ __forceinline__ void cardinal(const ReinitArgs& a, double t, double i
     }
 }
 
+// The stencil values of the patch of cell I.  NV <= 4: held in registers by the caller across the iterations of a solve on one
+// cell (64 doubles in 3-D) — re-loading them per evaluation was 64 gathers in front of every Newton step; NV = 6 (216 values) reads
+// them from memory at every evaluation.
+// ND > 0: the dimension as a compile-time constant (every loop over dimensions and stencil rows unrolls without selects); ND = 0: a.ndim
+template <int ND>
+__device__ __forceinline__ int ndim_of(const ReinitArgs& a) {
+    if constexpr (ND > 0) return ND;
+    else return a.ndim;
+}
+template <int NV, int ND = 0, bool REGS = (NV <= 4)>
+struct PatchValues {
+    static constexpr bool IN_REGS = REGS;
+    double v[IN_REGS ? NV * NV * NV : 1];
+    long long q0;
+    __device__ __forceinline__ void load(const ReinitArgs& a, const int I[3]) {
+        const int nd = ndim_of<ND>(a);
+        q0 = a.origin + (I[0] + a.off) + (nd > 1 ? (I[1] + a.off) * a.s1 : 0) + (nd > 2 ? (I[2] + a.off) * a.s2 : 0);
+        if constexpr (IN_REGS) {
+            const int nv1 = nd > 1 ? NV : 1, nv2 = nd > 2 ? NV : 1;
+#pragma unroll
+            for (int j2 = 0; j2 < NV; ++j2) {
+                if (j2 >= nv2) break;
+#pragma unroll
+                for (int j1 = 0; j1 < NV; ++j1) {
+                    if (j1 >= nv1) break;
+#pragma unroll
+                    for (int j0 = 0; j0 < NV; ++j0) v[j0 + NV * (j1 + NV * j2)] = ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ double at(const ReinitArgs& a, int j0, int j1, int j2) const {
+        if constexpr (IN_REGS) return v[j0 + NV * (j1 + NV * j2)];
+        else return ld_val(a.phi, q0 + j0 + j1 * a.s1 + j2 * a.s2, a.f32);
+    }
+};
+
 // value, gradient and (optionally) Hessian {00,11,22,01,02,12} of the patch of cell I at x
-template <int NV>
-__device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3], bool second, double& val, double g[3], double H[6]) {
+template <int NV, int ND, bool REGS>
+__device__ __forceinline__ void patch_eval(const ReinitArgs& a, const PatchValues<NV, ND, REGS>& pv, const int I[3], const double x[3], bool second, double& val,
+                                           double g[3], double H[6]) {
+#pragma clang fp contract(fast)
+    const int nd = ndim_of<ND>(a);
     Card<NV> c[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (d < a.ndim) {
+        if (d < nd) {
             const double t = (x[d] - (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d])) / a.h[d];
             cardinal<NV>(a, t, 1.0 / a.h[d], second, c[d]);
         } else {
@@ -98,8 +140,7 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
             for (int j = 0; j < NV; ++j) { c[d].L[j] = j == 0 ? 1.0 : 0.0; c[d].dL[j] = 0.0; c[d].d2L[j] = 0.0; }
         }
     }
-    const int nv1 = a.ndim > 1 ? NV : 1, nv2 = a.ndim > 2 ? NV : 1;
-    const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
+    const int nv1 = nd > 1 ? NV : 1, nv2 = nd > 2 ? NV : 1;
     val = 0.0; g[0] = g[1] = g[2] = 0.0;
     for (int k = 0; k < 6; ++k) H[k] = 0.0;
 #pragma unroll
@@ -109,10 +150,9 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
         for (int j1 = 0; j1 < NV; ++j1) {
             if (j1 >= nv1) break;
             double s = 0.0, ds = 0.0, d2s = 0.0;
-            const long long q = q0 + j1 * a.s1 + j2 * a.s2;
 #pragma unroll
             for (int j0 = 0; j0 < NV; ++j0) {
-                const double v = ld_val(a.phi, q + j0, a.f32);
+                const double v = pv.at(a, j0, j1, j2);
                 s += v * c[0].L[j0]; ds += v * c[0].dL[j0]; d2s += v * c[0].d2L[j0];
             }
             const double L1 = c[1].L[j1], D1 = c[1].dL[j1], E1 = c[1].d2L[j1];
@@ -126,11 +166,20 @@ __device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3
         }
     }
 }
+// one evaluation on the patch of cell I (values loaded for it)
+template <int NV>
+__device__ void patch_eval(const ReinitArgs& a, const int I[3], const double x[3], bool second, double& val, double g[3], double H[6]) {
+    PatchValues<NV, 0> pv;
+    pv.load(a, I);
+    patch_eval(a, pv, I, x, second, val, g, H);
+}
 
 // compute_index (src/meshes.jl:155-167): cell containing x, clamped to the grid
+template <int ND = 0>
 __device__ __forceinline__ void cell_of(const ReinitArgs& a, const double x[3], int I[3]) {
+#pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (d >= a.ndim) { I[d] = 0; continue; }
+        if (d >= ndim_of<ND>(a)) { I[d] = 0; continue; }
         int i = (int)floor((x[d] - a.lc[d]) / a.h[d]) - a.goff[d];
         I[d] = i < 0 ? 0 : (i > a.n[d] - 2 ? a.n[d] - 2 : i);
     }
@@ -321,12 +370,16 @@ __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const 
 }
 
 // ---- 2. interface samples: one thread per (candidate cell, start point)
-template <int NV>
-__global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
+#ifndef LSM_SAMPLE_MINBLOCKS
+#define LSM_SAMPLE_MINBLOCKS 2
+#endif
+template <int NV, int ND>
+__global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
                                                             unsigned char* valid) {
+    const int nd = ndim_of<ND>(a);
     const long long total = (long long)ncand * S;
     double hmax = a.h[0];
-    for (int d = 1; d < a.ndim; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
+    for (int d = 1; d < nd; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
     const int up1 = a.upsample + 1;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
         const long long id = w / S;
@@ -335,25 +388,35 @@ __global__ void __launch_bounds__(256) reinit_sample_kernel(ReinitArgs a, const 
         cell_unlin(a, cand_cell[id], I);
         const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
         double x0[3] = {0, 0, 0}, x[3];
-        for (int d = 0; d < a.ndim; ++d) x0[d] = (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < nd) x0[d] = (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
         x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2];
         bool conv = false;
+#ifndef LSM_SAMPLE_REGS
+#define LSM_SAMPLE_REGS 1
+#endif
+        PatchValues<NV, ND, (NV <= 4) && LSM_SAMPLE_REGS> pv;
+        int Jp[3] = {-1, -1, -1};
         for (int it = 0; it < a.maxiters; ++it) {      // _project_to_interface (src/sdf.jl:223-236)
             int J[3];
-            cell_of(a, x, J);
+            cell_of<ND>(a, x, J);
+            if (J[0] != Jp[0] || J[1] != Jp[1] || J[2] != Jp[2]) { pv.load(a, J); Jp[0] = J[0]; Jp[1] = J[1]; Jp[2] = J[2]; }
             double val, g[3], H[6];
-            patch_eval<NV>(a, J, x, false, val, g, H);
+            patch_eval(a, pv, J, x, false, val, g, H);
             if (fabs(val) < a.ftol) { conv = true; break; }
             const double g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
             if (g2 == 0.0 || !(g2 == g2)) break;
             double dist2 = 0.0;
-            for (int d = 0; d < a.ndim; ++d) { x[d] = x[d] - val * g[d] / g2; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (d < nd) { x[d] = x[d] - val * g[d] / g2; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
             if (sqrt(dist2) > hmax) break;
         }
         bool keep = false;
         if (conv) {
             int J[3];
-            cell_of(a, x, J);
+            cell_of<ND>(a, x, J);
             keep = J[0] == I[0] && J[1] == I[1] && J[2] == I[2];
         }
         const long long slot = id * S + s;
@@ -376,6 +439,40 @@ __device__ __forceinline__ long long bits_row(const ReinitArgs& a, int c1, int c
 __global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
                                                              const unsigned char* valid, unsigned char* cnt, unsigned char* blk,
                                                              unsigned long long* bits) {
+    auto mark = [&](unsigned id) {
+        int I[3];
+        cell_unlin(a, cand_cell[id], I);
+        const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
+        blk[blk_lin(a, B)] = 1;
+        atomicOr(bits + bits_row(a, I[1], I[2]) + I[0] / 64, 1ull << (I[0] & 63));     // one bit per cell with samples
+    };
+    if (S <= 32) {
+        // half a wave per cell, a lane per slot: the kept samples move to the front in slot order (one thread per cell walked its
+        // S slots through a chain of dependent loads — 53 µs for 38 k cells)
+        const int lane = threadIdx.x & 63, sub = lane & 31, half = lane >> 5;
+        const unsigned per_block = blockDim.x / 32;
+        for (unsigned base = blockIdx.x * per_block; base < ncand; base += gridDim.x * per_block) {      // uniform trip count per block
+            const unsigned id = base + (threadIdx.x >> 5);
+            const bool in = id < ncand && sub < S;
+            const long long slot = (long long)id * S + sub;
+            const bool keep = in && valid[slot];
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            if (keep) { x0 = pts[3 * slot]; x1 = pts[3 * slot + 1]; x2 = pts[3 * slot + 2]; }
+            const unsigned kept = (unsigned)((__ballot(keep) >> (32 * half)) & 0xffffffffull);
+            const int m = __popc(kept), rank = __popc(kept & ((1u << sub) - 1u));
+            // every lane of the half-wave has read its sample before any writes (the loads above are complete: the ballot depends on them)
+            __builtin_amdgcn_wave_barrier();
+            if (keep && rank != sub) {
+                const long long dst = (long long)id * S + rank;
+                pts[3 * dst] = x0; pts[3 * dst + 1] = x1; pts[3 * dst + 2] = x2;
+            }
+            if (id < ncand && sub == 0) {
+                cnt[id] = (unsigned char)m;
+                if (m) mark(id);
+            }
+        }
+        return;
+    }
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
         int m = 0;
         for (int k = 0; k < S; ++k) {
@@ -388,13 +485,7 @@ __global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const
             ++m;
         }
         cnt[id] = (unsigned char)(m > 255 ? 255 : m);
-        if (m) {
-            int I[3];
-            cell_unlin(a, cand_cell[id], I);
-            const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
-            blk[blk_lin(a, B)] = 1;
-            atomicOr(bits + bits_row(a, I[1], I[2]) + I[0] / 64, 1ull << (I[0] & 63));     // one bit per cell with samples
-        }
+        if (m) mark(id);
     }
 }
 
@@ -423,44 +514,104 @@ __device__ bool solve_small(int m, double A[4][4], double b[4]) {
     }
     return true;
 }
+// The same with the size fixed at compile time.  The pivot row is brought up by conditional swaps with every row below in turn
+// (first largest |entry| wins, as above) — the rows below end up in another order, which changes nothing: each is reduced with the
+// same pivot row by the same operations — so no register array is indexed by a per-lane row number (the version above becomes a
+// serialised loop over the distinct pivot rows of a wave at every access).
+template <int M>
+__device__ __forceinline__ bool solve_small_static(double A[4][4], double b[4]) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+#pragma unroll
+        for (int r = k + 1; r < M; ++r) {
+            const bool sw = fabs(A[r][k]) > fabs(A[k][k]);
+#pragma unroll
+            for (int cc = 0; cc < M; ++cc) { const double u = A[k][cc], v = A[r][cc]; A[k][cc] = sw ? v : u; A[r][cc] = sw ? u : v; }
+            const double u = b[k], v = b[r];
+            b[k] = sw ? v : u; b[r] = sw ? u : v;
+        }
+        const double piv = fabs(A[k][k]);
+        if (piv == 0.0 || !(piv == piv)) return false;
+#pragma unroll
+        for (int r = k + 1; r < M; ++r) {
+            const double f = A[r][k] / A[k][k];
+#pragma unroll
+            for (int cc = k; cc < M; ++cc) A[r][cc] -= f * A[k][cc];
+            b[r] -= f * b[k];
+        }
+    }
+#pragma unroll
+    for (int k = M - 1; k >= 0; --k) {
+        double sacc = b[k];
+#pragma unroll
+        for (int cc = k + 1; cc < M; ++cc) sacc -= A[k][cc] * b[cc];
+        b[k] = sacc / A[k][k];
+    }
+    return true;
+}
 
 // _closest_point (src/sdf.jl:239-272) on the patch of cell I, from x0; returns converged
-template <int NV>
+template <int NV, int ND>
 __device__ bool closest_on_patch(const ReinitArgs& a, const int I[3], const double xq[3], const double x0[3], double safeguard, double cp[3]) {
-    const int N = a.ndim;
+    const int N = ndim_of<ND>(a);
     double val, g[3], H[6];
-    patch_eval<NV>(a, I, x0, false, val, g, H);
+    PatchValues<NV, ND> pv;
+    pv.load(a, I);
+    patch_eval(a, pv, I, x0, false, val, g, H);
     double g2 = 0.0, num = 0.0;
-    for (int d = 0; d < N; ++d) { g2 += g[d] * g[d]; num += (xq[d] - x0[d]) * g[d]; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < N) { g2 += g[d] * g[d]; num += (xq[d] - x0[d]) * g[d]; }
     double lam = g2 == 0.0 ? 0.0 : num / g2;
     double x[3] = {x0[0], x0[1], x0[2]};
     double best_res = __builtin_inf();
     cp[0] = x0[0]; cp[1] = x0[1]; cp[2] = x0[2];
     const double reg = 1.4901161193847656e-08;   // sqrt(eps(Float64))
     for (int it = 0; it < a.maxiters; ++it) {
-        patch_eval<NV>(a, I, x, true, val, g, H);
-        double res[4], rn2 = 0.0;
-        for (int d = 0; d < N; ++d) { res[d] = x[d] - xq[d] + lam * g[d]; rn2 += res[d] * res[d]; }
-        res[N] = val; rn2 += val * val;
+        patch_eval(a, pv, I, x, true, val, g, H);
+        double res[4] = {0, 0, 0, 0}, rn2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < N) { res[d] = x[d] - xq[d] + lam * g[d]; rn2 += res[d] * res[d]; }
+        rn2 += val * val;
         const double rn = sqrt(rn2);
         if (rn < best_res) { best_res = rn; cp[0] = x[0]; cp[1] = x[1]; cp[2] = x[2]; }
         if (fabs(val) < a.ftol && rn < a.xtol) { cp[0] = x[0]; cp[1] = x[1]; cp[2] = x[2]; return true; }
-        double K[4][4];
         const double Hm[3][3] = {{H[0], H[3], H[4]}, {H[3], H[1], H[5]}, {H[4], H[5], H[2]}};
-        for (int r = 0; r < N; ++r) {
-            for (int cc = 0; cc < N; ++cc) K[r][cc] = (r == cc ? 1.0 : 0.0) + lam * Hm[r][cc] + (r == cc ? reg : 0.0);
-            K[r][N] = g[r]; K[N][r] = g[r];
+        double K[4][4], rhs[4];
+        bool ok;
+        if constexpr (ND > 0) {
+#pragma unroll
+            for (int r = 0; r < ND; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < ND; ++cc) K[r][cc] = (r == cc ? 1.0 : 0.0) + lam * Hm[r][cc] + (r == cc ? reg : 0.0);
+                K[r][ND] = g[r]; K[ND][r] = g[r];
+                rhs[r] = -res[r];
+            }
+            K[ND][ND] = reg;
+            rhs[ND] = -val;
+            ok = solve_small_static<ND + 1>(K, rhs);
+        } else {
+            res[N] = val;
+            for (int r = 0; r < N; ++r) {
+                for (int cc = 0; cc < N; ++cc) K[r][cc] = (r == cc ? 1.0 : 0.0) + lam * Hm[r][cc] + (r == cc ? reg : 0.0);
+                K[r][N] = g[r]; K[N][r] = g[r];
+            }
+            K[N][N] = reg;
+            for (int r = 0; r <= N; ++r) rhs[r] = -res[r];
+            ok = solve_small(N + 1, K, rhs);
         }
-        K[N][N] = reg;
-        double rhs[4];
-        for (int r = 0; r <= N; ++r) rhs[r] = -res[r];
-        if (!solve_small(N + 1, K, rhs)) return false;
-        double nd = 0.0;
-        for (int d = 0; d < N; ++d) nd += rhs[d] * rhs[d];
-        nd = sqrt(nd);
+        if (!ok) return false;
+        double nd2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < N) nd2 += rhs[d] * rhs[d];
+        const double nd = sqrt(nd2);
         const double alpha = nd > 0.0 ? (safeguard / nd < 1.0 ? safeguard / nd : 1.0) : 1.0;
         double dist2 = 0.0;
-        for (int d = 0; d < N; ++d) { x[d] += alpha * rhs[d]; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < N) { x[d] += alpha * rhs[d]; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
         lam += alpha * rhs[N];
         if (sqrt(dist2) > safeguard) return false;
     }
@@ -539,6 +690,59 @@ __global__ void __launch_bounds__(256) reinit_band_nodes_kernel(ReinitArgs a, lo
 
 constexpr int NSEED = 5;
 constexpr int FINE_SHELLS = 6;
+// The first-order closest-point estimate x - ϕ∇ϕ/|∇ϕ|² (centred differences), iterated on the node-wise linear model
+// ϕ_J + ∇ϕ_J·(x - x_J), J the node nearest to the iterate: cheap, and within a cell of the interface even when ϕ is far from a
+// distance function.  Returns false when there is no usable estimate.
+template <int ND>
+__device__ __forceinline__ bool first_order_foot(const ReinitArgs& a, const double xq[3], double hmin, double xe[3]) {
+    xe[0] = xq[0]; xe[1] = xq[1]; xe[2] = xq[2];
+    bool have = true;
+    for (int it = 0; it < 5 && have; ++it) {
+        int J[3] = {0, 0, 0};
+        long long qj = a.origin;
+        for (int d = 0; d < ND; ++d) {
+            int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
+            j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
+            J[d] = j;
+            qj += (long long)j * (d == 0 ? 1 : (d == 1 ? a.s1 : a.s2));
+        }
+        if (a.mask && !a.mask[qj]) break;              // left the band: keep the last iterate
+        const double vj = ld_val(a.phi, qj, a.f32);
+        double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
+        for (int d = 0; d < ND; ++d) {
+            const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
+            g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
+            g2 += g[d] * g[d];
+            val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
+        }
+        if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
+        for (int d = 0; d < ND; ++d) xe[d] -= val * g[d] / g2;
+        if (val * val < 0.0625 * hmin * hmin * g2) break;   // within a quarter cell of the model's zero
+    }
+    return have;
+}
+// the estimate's cell per node, one lane per node (21 bits per index; -1 = no usable estimate): the 16 lanes that share a node in the
+// search below would all compute the same five dependent steps — a third of that kernel's instructions
+template <int ND>
+__global__ void __launch_bounds__(256) reinit_foot_kernel(ReinitArgs a, const long long* node_list, long long nlist, long long* foot) {
+    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    double hmin = a.h[0];
+    for (int d = 1; d < ND; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long t = node_list ? node_list[w] : w;
+        const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
+        double xq[3] = {0, 0, 0}, xe[3];
+        for (int d = 0; d < ND; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
+        long long out = -1;
+        if (first_order_foot<ND>(a, xq, hmin, xe)) {
+            int E[3];
+            cell_of(a, xe, E);
+            out = (long long)E[0] | ((long long)E[1] << 21) | ((long long)E[2] << 42);
+        }
+        foot[w] = out;
+    }
+}
+
 // (a0) the guided search, GRP lanes per node.  One lane per node spends milliseconds on its chain of dependent loads
 // (row word -> cell id -> sample count -> samples); sixteen lanes share the rows of the ball, keep one best each and
 // merge with shuffles.  Nodes the guided search cannot settle (no usable estimate, ball wider than 10 cells) are
@@ -554,7 +758,8 @@ constexpr int QCAP = LSM_REINIT_QCAP;
 template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
                                                                   const unsigned char* cnt, const unsigned long long* bits,
-                                                                  const long long* node_list, long long nlist, long long* seeds) {
+                                                                  const long long* node_list, long long nlist, const long long* foot,
+                                                                  long long* seeds) {
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0];
     for (int d = 1; d < ND; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
@@ -608,34 +813,10 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             for (int off = GRP / 2; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, GRP); v = o < v ? o : v; }
             return v;
         };
-        // the estimate (every lane computes the same; the loads coalesce into broadcasts)
-        double xe[3] = {xq[0], xq[1], xq[2]};
-        bool have = true;
-        for (int it = 0; it < 5 && have; ++it) {
-            int J[3] = {0, 0, 0};
-            long long qj = a.origin;
-            for (int d = 0; d < ND; ++d) {
-                int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
-                j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
-                J[d] = j;
-                qj += (long long)j * (d == 0 ? 1 : (d == 1 ? a.s1 : a.s2));
-            }
-            if (a.mask && !a.mask[qj]) break;
-            const double vj = ld_val(a.phi, qj, a.f32);
-            double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
-            for (int d = 0; d < ND; ++d) {
-                const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-                g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
-                g2 += g[d] * g[d];
-                val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
-            }
-            if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
-            for (int d = 0; d < ND; ++d) xe[d] -= val * g[d] / g2;
-            if (val * val < 0.0625 * hmin * hmin * g2) break;
-        }
+        const long long fe = foot[w];                 // the estimate's cell (reinit_foot_kernel)
+        const bool have = fe >= 0;
+        const int E[3] = {(int)(fe & 0x1fffff), (int)((fe >> 21) & 0x1fffff), (int)((fe >> 42) & 0x1fffff)};
         if (have) {     // the rows around the estimate's cell, one per lane
-            int E[3];
-            cell_of(a, xe, E);
             const int r1 = ND > 1 ? 3 : 1, r2 = ND > 2 ? 3 : 1;
             if (gl < r1 * r2) scan_row(E[0] - 1, E[0] + 1, E[1] + (ND > 1 ? gl % 3 - 1 : 0), E[2] + (ND > 2 ? gl / 3 - 1 : 0));
         }
@@ -653,7 +834,8 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
             if (gl == 0) qn[g] = 0;
             __builtin_amdgcn_wave_barrier();
             auto gap = [&](int d, int c) { return c > I[d] ? c - I[d] : (c + 1 < I[d] ? I[d] - (c + 1) : 0); };
-            const int k2 = ND > 2 ? (int)(R0 / a.h[2]) + 1 : 0, k1 = ND > 1 ? (int)(R0 / a.h[1]) + 1 : 0;
+            // rows (c1, c2) whose gap to the node is at most floor(R0 / h) cells: a row one further lies more than R0 away
+            const int k2 = ND > 2 ? (int)(R0 / a.h[2]) : 0, k1 = ND > 1 ? (int)(R0 / a.h[1]) : 0;
             const int n1 = ND > 1 ? 2 * k1 + 2 : 1, n2 = ND > 2 ? 2 * k2 + 2 : 1;
             const float inv_n1 = 1.0f / (float)n1, inv_h0 = (float)(1.0 / a.h[0]);
             for (int idx = gl; idx < n1 * n2; idx += GRP) {
@@ -669,6 +851,8 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                 int lo = I[0] - k0 - 1, hi = I[0] + k0;
                 lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
                 const long long row = bits_row(a, c1, c2);
+                // the cells around the estimate have been measured above: not again
+                const bool seen_row = (ND < 2 || (c1 >= E[1] - 1 && c1 <= E[1] + 1)) && (ND < 3 || (c2 >= E[2] - 1 && c2 <= E[2] + 1));
                 for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
                     unsigned long long m = bits[row + w0];
                     if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
@@ -677,6 +861,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const int c0 = w0 * 64 + b;
+                        if (seen_row && c0 >= E[0] - 1 && c0 <= E[0] + 1) continue;
                         const double dx = gap(0, c0) * a.h[0];
                         if (dx * dx > rem) continue;
                         const unsigned slot = atomicAdd(&qn[g], 1u);
@@ -695,8 +880,9 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                 scan_cell((int)(c & 0x1fffff), (int)((c >> 21) & 0x1fffff), (int)((c >> 42) & 0x1fffff));
             }
         }
-        // the NSEED nearest of the lanes' bests, nearest first (the first is the exact nearest sample)
-        for (int k = 0; k < NSEED; ++k) {
+        // the exact nearest sample; seeds[1] = -4: the further near samples have not been collected — the closest-point kernel asks the
+        // shell search for them only where the solve from the first seed fails (src/sdf.jl:113-131: nn first, knn on the rare failure)
+        {
             const double m = group_min(bd);
             long long out = -1;
             if (m < __builtin_inf()) {
@@ -705,9 +891,8 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                 const unsigned lo = (unsigned)__shfl((int)(unsigned)(unsigned long long)bslot, owner, 64);
                 const unsigned hi = (unsigned)__shfl((int)(unsigned)((unsigned long long)bslot >> 32), owner, 64);
                 out = (long long)(((unsigned long long)hi << 32) | lo);
-                if (lane == owner) bd = __builtin_inf();
             }
-            if (gl == 0) seeds[NSEED * w + k] = out;
+            if (gl == 0) { seeds[NSEED * w] = out; seeds[NSEED * w + 1] = -4; }
         }
     }
 }
@@ -789,32 +974,8 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         // nearest samples when ϕ is anywhere near a distance function; the cells around it give a tight upper bound,
         // and scanning every cell that meets the ball of that radius around the node then makes the result exact.
         {
-            // a few Newton steps on the node-wise linear model ϕ_J + ∇ϕ_J·(x - x_J), J the node nearest to the iterate
-            // (centred differences): cheap, and within a cell of the interface even when ϕ is far from a distance function
-            double xe[3] = {xq[0], xq[1], xq[2]};
-            bool have = true;
-            for (int it = 0; it < 5 && have; ++it) {
-                int J[3] = {0, 0, 0};
-                long long qj = a.origin;
-                for (int d = 0; d < ND; ++d) {
-                    int j = (int)floor((xe[d] - a.lc[d]) / a.h[d] + 0.5) - a.goff[d];
-                    j = j < 0 ? 0 : (j > a.n[d] - 1 ? a.n[d] - 1 : j);
-                    J[d] = j;
-                    qj += (long long)j * (d == 0 ? 1 : (d == 1 ? a.s1 : a.s2));
-                }
-                if (a.mask && !a.mask[qj]) break;              // left the band: keep the last iterate
-                const double vj = ld_val(a.phi, qj, a.f32);
-                double g[3] = {0, 0, 0}, g2 = 0.0, val = vj;
-                for (int d = 0; d < ND; ++d) {
-                    const long long sd = d == 0 ? 1 : (d == 1 ? a.s1 : a.s2);
-                    g[d] = (ld_val(a.phi, qj + sd, a.f32) - ld_val(a.phi, qj - sd, a.f32)) / (2.0 * a.h[d]);
-                    g2 += g[d] * g[d];
-                    val += g[d] * (xe[d] - (a.lc[d] + (double)(J[d] + a.goff[d]) * a.h[d]));
-                }
-                if (!(g2 > 0.0) || !(val == val)) { have = it > 0; break; }
-                for (int d = 0; d < ND; ++d) xe[d] -= val * g[d] / g2;
-                if (val * val < 0.0625 * hmin * hmin * g2) break;   // within a quarter cell of the model's zero
-            }
+            double xe[3];
+            const bool have = first_order_foot<ND>(a, xq, hmin, xe);
             if (have) {
                 int E[3];
                 cell_of(a, xe, E);
@@ -879,20 +1040,25 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
     }
 }
 
-// (b) closest point from the seeds, signed distance
-template <int NV>
+// (b) closest point from the seeds, signed distance.  Pass 0 runs over every node: a node that comes with its nearest sample only
+// (seeds[1] == -4) and whose solve from it does not converge is appended to `retry` and marked for the shell search (seeds[0] = -2),
+// which collects its NSEED nearest samples; pass 1 runs over the `retry` list with them.
+template <int NV, int ND>
 __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S, const double* pts, const long long* node_list, long long nlist,
-                                                            const long long* seeds, void* out, unsigned* nfail, unsigned* nfar) {
-    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+                                                            long long* seeds, void* out, unsigned* nfail, unsigned* nfar, unsigned* retry,
+                                                            unsigned* retry_count, int pass) {
+    const long long total = pass ? (long long)*retry_count : (node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2]);
     double hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
-    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long w = pass ? (long long)retry[i] : i;
         const long long t = node_list ? node_list[w] : w;
         const int I[3] = {(int)(t % a.n[0]), (int)((t / a.n[0]) % a.n[1]), (int)(t / ((long long)a.n[0] * a.n[1]))};
         const long long q = a.origin + I[0] + I[1] * a.s1 + I[2] * a.s2;
         double xq[3] = {0, 0, 0};
         for (int d = 0; d < a.ndim; ++d) xq[d] = a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d];
-        const long long* bslot = seeds + NSEED * w;
+        long long* bslot = seeds + NSEED * w;
+        const bool first_only = pass == 0 && bslot[0] >= 0 && bslot[1] == -4;
         double cp[3] = {xq[0], xq[1], xq[2]};
         bool conv = false;
         if (bslot[0] < 0) {
@@ -900,15 +1066,20 @@ __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S,
         } else {
             const double safeguard = 1.5 * hmax;
             double bestcp[3] = {0, 0, 0}, bestd = __builtin_inf();
-            for (int k = 0; k < NSEED && bslot[k] >= 0 && !conv; ++k) {
+            for (int k = 0; k < (first_only ? 1 : NSEED) && bslot[k] >= 0 && !conv; ++k) {
                 const double seed[3] = {pts[3 * bslot[k]], pts[3 * bslot[k] + 1], pts[3 * bslot[k] + 2]};
                 int J[3];
-                cell_of(a, seed, J);
+                cell_of<ND>(a, seed, J);
                 double c3[3];
-                conv = closest_on_patch<NV>(a, J, xq, seed, safeguard, c3);
+                conv = closest_on_patch<NV, ND>(a, J, xq, seed, safeguard, c3);
                 double d2 = 0.0;
                 for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
                 if (conv || d2 < bestd) { bestd = d2; bestcp[0] = c3[0]; bestcp[1] = c3[1]; bestcp[2] = c3[2]; }
+            }
+            if (first_only && !conv) {                    // the further near samples are needed: second pass
+                retry[atomicAdd(retry_count, 1u)] = (unsigned)w;
+                bslot[0] = -2;
+                continue;
             }
             cp[0] = bestcp[0]; cp[1] = bestcp[1]; cp[2] = bestcp[2];
             if (!conv) atomicAdd(nfail, 1u);
@@ -1069,12 +1240,16 @@ static hipError_t grow(T*& p, size_t& cap, size_t bytes, bool* fresh = nullptr) 
 struct ReinitWorkspace {
     SampleSet ss;
     long long* seeds = nullptr;
-    size_t cap_seeds = 0;
+    unsigned* retry = nullptr;         // nodes whose solve from the nearest sample failed (second pass of the closest-point kernel)
+    long long* foot = nullptr;         // cell of the first-order closest-point estimate per node
+    size_t cap_seeds = 0, cap_retry = 0, cap_foot = 0;
 };
 void reinit_workspace_free(ReinitWorkspace* w) {
     if (!w) return;
     w->ss.release();
     (void)hipFree(w->seeds);
+    (void)hipFree(w->retry);
+    (void)hipFree(w->foot);
     delete w;
 }
 // band calls on a workspace: back to cand_id == -1, bits == 0, blk == 0 by visiting the candidate cells of the call that ends
@@ -1190,10 +1365,14 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     if (ncand) {
         const long long work = (long long)ncand * S;
         const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
-        if (a.nv == 2) hipLaunchKernelGGL(reinit_sample_kernel<2>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
-        else if (a.nv == 4) hipLaunchKernelGGL(reinit_sample_kernel<4>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
-        else hipLaunchKernelGGL(reinit_sample_kernel<6>, dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid);
-        hipLaunchKernelGGL(reinit_compact_kernel, dim3((ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid, ss.cnt,
+#define LSM_SAMPLE(NV_, ND_) hipLaunchKernelGGL((reinit_sample_kernel<NV_, ND_>), dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid)
+        // (the dimension stays a run-time value here: the version with it fixed needs 288 registers in 3-D — one wave per SIMD — and
+        // is slower capped at 256, 1.74 against 1.65 ms for the 256³ band call)
+        if (a.nv == 2) LSM_SAMPLE(2, 0);
+        else if (a.nv == 4) LSM_SAMPLE(4, 0);
+        else LSM_SAMPLE(6, 0);
+#undef LSM_SAMPLE
+        hipLaunchKernelGGL(reinit_compact_kernel, dim3(S <= 32 ? (ncand + 7) / 8 : (ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid, ss.cnt,
                            ss.blk, ss.bits);
     }
     return 0;
@@ -1209,7 +1388,7 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     ReinitWorkspace& W = wsp ? **wsp : local;
     SampleSet& ss = W.ss;
     auto done = [&](int rc) {
-        if (!wsp) { ss.release(); (void)hipFree(W.seeds); W.seeds = nullptr; }
+        if (!wsp) { ss.release(); (void)hipFree(W.seeds); (void)hipFree(W.retry); (void)hipFree(W.foot); W.seeds = nullptr; W.retry = nullptr; W.foot = nullptr; }
         return rc;
     };
     if (int r = setup_args(ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, phi, f32, mask, err)) return done(r);
@@ -1221,21 +1400,37 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         if (grow(W.seeds, W.cap_seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return done(2); }
         long long* seeds = W.seeds;
         const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
+        if (nwork > 0xffffffffll) { *err = "reinitialize: more than 2^32 nodes to evaluate"; if (wsp) ss.release(); return done(1); }
+        if (grow(W.retry, W.cap_retry, sizeof(unsigned) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(retry)"; ss.release(); return done(2); }
+        if (grow(W.foot, W.cap_foot, sizeof(long long) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(foot)"; ss.release(); return done(2); }
         const long long grp_blocks = (nwork * GRP + 255) / 256;
         const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
-        if (ndim == 3) hipLaunchKernelGGL(reinit_search_group_kernel<3>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
-        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_group_kernel<2>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
-        else hipLaunchKernelGGL(reinit_search_group_kernel<1>, gg, dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, seeds);
-        if (ndim == 3) hipLaunchKernelGGL(reinit_search_kernel<3>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
-        else if (ndim == 2) hipLaunchKernelGGL(reinit_search_kernel<2>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
-        else hipLaunchKernelGGL(reinit_search_kernel<1>, dim3(gsr), dim3(256), 0, stream, a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+#define LSM_BY_ND(KERNEL, GRID, ...) do { \
+        if (ndim == 3) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
+        else if (ndim == 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, stream, __VA_ARGS__); } while (0)
+#define LSM_NEWTON_K(NV_, ND_, PASS, GRID) hipLaunchKernelGGL((reinit_newton_kernel<NV_, ND_>), GRID, dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, \
+                                                             ss.counters + 1, ss.counters + 2, W.retry, ss.counters, PASS)
+#define LSM_NEWTON(PASS, GRID) do { \
+        if (a.nv == 4 && ndim == 3) LSM_NEWTON_K(4, 3, PASS, GRID); \
+        else if (a.nv == 4 && ndim == 2) LSM_NEWTON_K(4, 2, PASS, GRID); \
+        else if (a.nv == 2 && ndim == 3) LSM_NEWTON_K(2, 3, PASS, GRID); \
+        else if (a.nv == 2 && ndim == 2) LSM_NEWTON_K(2, 2, PASS, GRID); \
+        else if (a.nv == 2) LSM_NEWTON_K(2, 0, PASS, GRID); \
+        else if (a.nv == 4) LSM_NEWTON_K(4, 0, PASS, GRID); \
+        else LSM_NEWTON_K(6, 0, PASS, GRID); } while (0)
+        // nearest sample per node (exact); what the guided search cannot settle goes to the shell search
+        LSM_BY_ND(reinit_foot_kernel, dim3(gsr), a, ss.node_list, nwork, W.foot);
+        LSM_BY_ND(reinit_search_group_kernel, gg, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, W.foot, seeds);
+        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
-        if (a.nv == 2)
-            hipLaunchKernelGGL(reinit_newton_kernel<2>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
-        else if (a.nv == 4)
-            hipLaunchKernelGGL(reinit_newton_kernel<4>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
-        else
-            hipLaunchKernelGGL(reinit_newton_kernel<6>, dim3(gn), dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, ss.counters + 1, ss.counters + 2);
+        LSM_NEWTON(0, dim3(gn));
+        // second pass for the nodes whose solve from the nearest sample did not converge (usually none: two short launches)
+        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+        LSM_NEWTON(1, dim3(gn > 1024 ? 1024 : gn));
+#undef LSM_NEWTON
+#undef LSM_NEWTON_K
+#undef LSM_BY_ND
         hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nwork + 255) / 256 > 65535 ? 65535 : (nwork + 255) / 256)), dim3(256), 0, stream, a,
                            out_field, phi, ss.node_list, nwork);
     }
@@ -1342,7 +1537,7 @@ __global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int
                 int J[3];
                 cell_of(a, seed, J);
                 double c3[3];
-                conv = closest_on_patch<NV>(a, J, xq, seed, safeguard, c3);
+                conv = closest_on_patch<NV, 0>(a, J, xq, seed, safeguard, c3);
                 double d2 = 0.0;
                 for (int d = 0; d < a.ndim; ++d) d2 += (xq[d] - c3[d]) * (xq[d] - c3[d]);
                 if (conv || d2 < bestd) {
