@@ -158,8 +158,8 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, help="HIP-event pairs around every N-th stage launch of the timed region (1 = all)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "local"],
                     help="rccl: one process per GPU (torch.distributed.run); local: --gpus N rank THREADS on device 0 over the in-process transport (rehearsal)")
-    ap.add_argument("--config", default="headline", choices=["headline", "2", "3", "5"],
-                    help="headline = BASELINE config 4's equation at 512^3 on one GPU (the metric); 2, 3, 5: the other single-GPU BASELINE configs (tools/configs.py)")
+    ap.add_argument("--config", default="headline", choices=["headline", "2", "3", "5", "5r"],
+                    help="headline = BASELINE config 4's equation at 512^3 on one GPU (the metric); 2, 3, 5: the other single-GPU BASELINE configs; 5r: config 5 with reinitialize! every 10 steps (tools/configs.py)")
     args = ap.parse_args()
     if args.config != "headline":
         sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -305,8 +305,9 @@ __device__ void bernstein_extrema_reg(const ReinitArgs& a, long long q0, double&
 // cand_id has been set to -1 by the caller.
 __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* maybe, unsigned* maybe_count,
                                                            const long long* node_list, long long nlist) {
+    __shared__ unsigned blk_n, blk_base;
     const long long nc = node_list ? nlist : ncells(a);
-    const long long span = (nc + 255) / 256 * 256;      // whole waves reach the ballot
+    const long long span = (nc + 255) / 256 * 256;      // whole workgroups reach the barriers
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < span; w += (long long)gridDim.x * blockDim.x) {
         bool keep = false;
         long long c = w;
@@ -342,48 +343,138 @@ __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* ca
             }
             if (!node_list) cand_id[c] = -1;
         }
+        // one append per workgroup (every thread of it reaches this point: `span` is a multiple of 256)
         const unsigned long long bal = __ballot(keep);
-        if (!bal) continue;
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(maybe_count, (unsigned)__popcll(bal));
-        base = __shfl(base, leader, 64);
-        if (keep) maybe[base + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+        const int lane = threadIdx.x & 63;
+        if (threadIdx.x == 0) blk_n = 0;
+        __syncthreads();
+        unsigned wbase = 0;
+        if (bal && lane == 0) wbase = atomicAdd(&blk_n, (unsigned)__popcll(bal));
+        wbase = __shfl(wbase, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(maybe_count, blk_n);
+        __syncthreads();
+        if (keep) maybe[blk_base + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = c;
     }
 }
 template <int NV, int NC, int NDIM>   // NV = 0: the general version
-__global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const long long* maybe, unsigned nmaybe, int* cand_id,
+__global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const long long* maybe, const unsigned* maybe_count, int* cand_id,
                                                             long long* cand_cell, unsigned* cand_count) {
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nmaybe; i += gridDim.x * blockDim.x) {
-        const long long c = maybe[i];
-        int I[3];
-        cell_unlin(a, c, I);
-        const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
-        double clo, chi;
-        if constexpr (NV == 0) bernstein_extrema(a, q0, clo, chi);
-        else bernstein_extrema_reg<NV, NC, NDIM>(a, q0, clo, chi);
-        if (clo * chi > 0.0) continue;
-        const unsigned id = atomicAdd(cand_count, 1u);
-        cand_id[c] = (int)id;
-        cand_cell[id] = c;
+    const unsigned nmaybe = *maybe_count;          // stays on the device: the launch does not wait for it
+    __shared__ unsigned blk_n, blk_base;
+    const int lane = threadIdx.x & 63;
+    for (unsigned base = blockIdx.x * blockDim.x; base < nmaybe; base += gridDim.x * blockDim.x) {     // uniform per workgroup
+        const unsigned i = base + threadIdx.x;
+        bool keep = false;
+        long long c = 0;
+        if (i < nmaybe) {
+            c = maybe[i];
+            int I[3];
+            cell_unlin(a, c, I);
+            const long long q0 = a.origin + (I[0] + a.off) + (a.ndim > 1 ? (I[1] + a.off) * a.s1 : 0) + (a.ndim > 2 ? (I[2] + a.off) * a.s2 : 0);
+            double clo, chi;
+            if constexpr (NV == 0) bernstein_extrema(a, q0, clo, chi);
+            else bernstein_extrema_reg<NV, NC, NDIM>(a, q0, clo, chi);
+            keep = !(clo * chi > 0.0);
+        }
+        // candidate ids: one append to the counter per workgroup
+        const unsigned long long bal = __ballot(keep);
+        if (threadIdx.x == 0) blk_n = 0;
+        __syncthreads();
+        unsigned wbase = 0;
+        if (bal && lane == 0) wbase = atomicAdd(&blk_n, (unsigned)__popcll(bal));
+        wbase = __shfl(wbase, 0, 64);
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(cand_count, blk_n);
+        __syncthreads();
+        if (keep) {
+            const unsigned id = blk_base + wbase + __popcll(bal & ((1ull << lane) - 1ull));
+            cand_id[c] = (int)id;
+            cand_cell[id] = c;
+        }
     }
 }
 
-// ---- 2. interface samples: one thread per (candidate cell, start point)
+// ---- 2. interface samples.  Every candidate cell has (upsample + 1)^N start points on its closure, and a start point on a
+// face, edge or corner belongs to up to 2^N cells: its projection follows the iterate across cells whichever cell it was started
+// for, so the copies run the same trajectory and only the copy of the cell the point lands in is kept (src/sdf.jl:186-236).  Here
+// each start point is projected once: (a) the copy of the lowest candidate cell sharing a point registers it; (b) one thread per
+// registered point projects it and, where it converges into a candidate cell whose closure holds the start point, stores it in
+// that cell's slot of that start point — the reference's sample set, with 8 instead of 27 projections per cell in 3-D.
+__global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, unsigned ncand, int S,
+                                                            unsigned long long* starts, unsigned* nstarts) {
+    // a workgroup collects the registered points of 1024 (cell, start point) pairs in LDS and appends them with ONE atomic: a wave-level
+    // append to the single counter took 375 µs for 16 k waves
+    constexpr int CHUNK = 4;
+    __shared__ unsigned long long buf[256 * CHUNK];
+    __shared__ unsigned nbuf, gbase;
+    const long long total = (long long)ncand * S;
+    const int up = a.upsample, up1 = up + 1;
+    const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
+    const int lane = threadIdx.x & 63;
+    for (long long sc = blockIdx.x; sc * (256 * CHUNK) < total; sc += gridDim.x) {
+        if (threadIdx.x == 0) nbuf = 0;
+        __syncthreads();
+        for (int c = 0; c < CHUNK; ++c) {
+            const long long w = (sc * CHUNK + c) * 256 + threadIdx.x;
+            bool own = false;
+            unsigned long long rec = 0;
+            if (w < total) {
+                const long long id = w / S;
+                const int s = (int)(w - id * S);
+                int I[3];
+                cell_unlin(a, cand_cell[id], I);
+                const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
+                // the cells sharing the point: I + δ, δ_d ∈ {-1, 0} where the point lies on the cell's lower face of dimension d,
+                // {0, +1} on its upper face; a copy is dropped when a candidate cell that precedes I (last dimension first) shares it
+                int lo[3], hi[3];
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = (d < a.ndim && xi[d] == 0 && I[d] > 0) ? -1 : 0;
+                    hi[d] = (d < a.ndim && xi[d] == up && I[d] < nc_[d] - 1) ? 1 : 0;
+                }
+                own = true;
+                for (int d2 = lo[2]; d2 <= hi[2] && own; ++d2)
+                    for (int d1 = lo[1]; d1 <= hi[1] && own; ++d1)
+                        for (int d0 = lo[0]; d0 <= hi[0] && own; ++d0) {
+                            const bool lower = d2 < 0 || (d2 == 0 && (d1 < 0 || (d1 == 0 && d0 < 0)));
+                            if (!lower) continue;
+                            const int C[3] = {I[0] + d0, I[1] + d1, I[2] + d2};
+                            if (cand_id[cell_lin(a, C)] >= 0) own = false;
+                        }
+                rec = (unsigned long long)id | ((unsigned long long)s << 32);
+            }
+            const unsigned long long bal = __ballot(own);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&nbuf, (unsigned)__popcll(bal));
+                base = __shfl(base, leader, 64);
+                if (own) buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = rec;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) gbase = atomicAdd(nstarts, nbuf);
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < nbuf; i += 256) starts[gbase + i] = buf[i];
+        __syncthreads();
+    }
+}
 #ifndef LSM_SAMPLE_MINBLOCKS
 #define LSM_SAMPLE_MINBLOCKS 2
 #endif
 template <int NV, int ND>
-__global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
-                                                            unsigned char* valid) {
+__global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, int S,
+                                                                                  const unsigned long long* starts, const unsigned* nstarts,
+                                                                                  double* pts, unsigned char* valid) {
     const int nd = ndim_of<ND>(a);
-    const long long total = (long long)ncand * S;
+    const long long total = (long long)*nstarts;
     double hmax = a.h[0];
     for (int d = 1; d < nd; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
-    const int up1 = a.upsample + 1;
+    const int up = a.upsample, up1 = up + 1;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
-        const long long id = w / S;
-        const int s = (int)(w - id * S);
+        const unsigned long long rec = starts[w];
+        const long long id = (long long)(rec & 0xffffffffull);
+        const int s = (int)(rec >> 32);
         int I[3];
         cell_unlin(a, cand_cell[id], I);
         const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
@@ -393,10 +484,7 @@ __global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kerne
             if (d < nd) x0[d] = (a.lc[d] + (double)(I[d] + a.goff[d]) * a.h[d]) + a.h[d] * (double)xi[d] / (double)a.upsample;
         x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2];
         bool conv = false;
-#ifndef LSM_SAMPLE_REGS
-#define LSM_SAMPLE_REGS 1
-#endif
-        PatchValues<NV, ND, (NV <= 4) && LSM_SAMPLE_REGS> pv;
+        PatchValues<NV, ND> pv;
         int Jp[3] = {-1, -1, -1};
         for (int it = 0; it < a.maxiters; ++it) {      // _project_to_interface (src/sdf.jl:223-236)
             int J[3];
@@ -413,15 +501,25 @@ __global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kerne
                 if (d < nd) { x[d] = x[d] - val * g[d] / g2; dist2 += (x[d] - x0[d]) * (x[d] - x0[d]); }
             if (sqrt(dist2) > hmax) break;
         }
-        bool keep = false;
-        if (conv) {
-            int J[3];
-            cell_of<ND>(a, x, J);
-            keep = J[0] == I[0] && J[1] == I[1] && J[2] == I[2];
+        if (!conv) continue;
+        // the cell the point landed in keeps it — if it is a candidate and the start point is one of its own
+        int J[3];
+        cell_of<ND>(a, x, J);
+        const int jid = cand_id[cell_lin(a, J)];
+        if (jid < 0) continue;
+        int sj = 0, mul = 1;
+        bool mine = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int xj = d < nd ? up * (I[d] - J[d]) + xi[d] : 0;     // the start point's index on cell J
+            mine = mine && xj >= 0 && xj <= up;
+            sj += xj * mul;
+            mul *= up1;
         }
-        const long long slot = id * S + s;
-        valid[slot] = keep ? 1 : 0;
-        if (keep) { pts[3 * slot] = x[0]; pts[3 * slot + 1] = x[1]; pts[3 * slot + 2] = x[2]; }
+        if (!mine) continue;
+        const long long slot = (long long)jid * S + sj;
+        valid[slot] = 1;
+        pts[3 * slot] = x[0]; pts[3 * slot + 1] = x[1]; pts[3 * slot + 2] = x[2];
     }
 }
 
@@ -1205,22 +1303,23 @@ struct SampleSet {
     long long nwork = 0;       // active nodes (band) or all nodes
     int* cand_id = nullptr;
     long long *cand_cell = nullptr, *maybe = nullptr, *node_list = nullptr;
-    unsigned* counters = nullptr;      // [0] scratch / candidates, [1] nfail, [2] nfar, [3] band nodes
+    unsigned* counters = nullptr;      // [0] maybe cells, [1] nfail, [2] nfar, [3] band nodes, [4] start points, [5] candidate cells, [6] retried nodes
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
     unsigned long long* bits = nullptr;
+    unsigned long long* starts = nullptr;   // start points to project: candidate id | slot << 32
     // bytes allocated behind each pointer (grow(): a buffer is re-allocated only when a call needs more — the set of a NewtonSDF
     // object is built once; the workspace of reinitialize! lives on the handle and stops allocating after the first calls)
     size_t cap_cand_id = 0, cap_cand_cell = 0, cap_maybe = 0, cap_node_list = 0, cap_counters = 0, cap_pts = 0, cap_valid = 0, cap_cnt = 0, cap_blk = 0,
-           cap_bits = 0;
+           cap_bits = 0, cap_starts = 0;
     // workspace only: cand_id == -1, bits == 0 and blk == 0 everywhere for a grid of `clean_cells` cells — the state every band call
     // starts from, and restores by un-marking its own candidate cells (reinit_unmark_kernel) instead of clearing arrays of the size of the grid
     long long clean_cells = -1;
     void release() {
         (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(node_list); (void)hipFree(counters);
-        (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(bits);
-        cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; bits = nullptr;
-        cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = 0;
+        (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(bits); (void)hipFree(starts);
+        cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; bits = nullptr; starts = nullptr;
+        cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = cap_starts = 0;
         clean_cells = -1;
     }
 };
@@ -1294,9 +1393,9 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     const int S = ss.S;
     bool fresh_id = false, fresh_blk = false, fresh_bits = false;
     RE_HIP(grow(ss.cand_id, ss.cap_cand_id, sizeof(int) * (size_t)nc, &fresh_id));
-    RE_HIP(grow(ss.counters, ss.cap_counters, 4 * sizeof(unsigned)));
-    unsigned nmaybe = 0, ncand = 0;
-    RE_HIP(hipMemsetAsync(ss.counters, 0, 4 * sizeof(unsigned), stream));
+    RE_HIP(grow(ss.counters, ss.cap_counters, 8 * sizeof(unsigned)));
+    unsigned ncand = 0;
+    RE_HIP(hipMemsetAsync(ss.counters, 0, 8 * sizeof(unsigned), stream));
     size_t nblk = 1;
     for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
     size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
@@ -1332,12 +1431,12 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     const unsigned gb = (unsigned)((ncell_work + 255) / 256 > 65535 ? 65535 : (ncell_work + 255) / 256);
     RE_HIP(grow(ss.maybe, ss.cap_maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
     if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, ss.cand_id, ss.maybe, ss.counters, ss.node_list, ss.nwork);
-    RE_HIP(hipMemcpyAsync(&nmaybe, ss.counters, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    RE_HIP(hipStreamSynchronize(stream));
-    RE_HIP(grow(ss.cand_cell, ss.cap_cand_cell, sizeof(long long) * (size_t)(nmaybe ? nmaybe : 1)));
-    if (nmaybe) {
-        const dim3 g2((nmaybe + 255) / 256), b2(256);
-#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, nmaybe, ss.cand_id, ss.cand_cell, ss.counters + 1)
+    // every "maybe" cell may turn out a candidate; their number is read by the next kernel on the device (a grid for half of the cells looked at,
+    // walked with a stride: about a sixth of them are "maybe" cells on a band)
+    RE_HIP(grow(ss.cand_cell, ss.cap_cand_cell, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
+    if (ncell_work) {
+        const dim3 g2((unsigned)((ncell_work / 2 + 255) / 256 > 65535 ? 65535 : (ncell_work / 2 + 255) / 256)), b2(256);
+#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, ss.counters, ss.cand_id, ss.cand_cell, ss.counters + 5)
         const int ncf = a.order + 1;
         if (a.nv == 4 && ncf == 4 && ndim == 3) LSM_CELLS2(4, 4, 3);
         else if (a.nv == 4 && ncf == 4 && ndim == 2) LSM_CELLS2(4, 4, 2);
@@ -1347,25 +1446,28 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
         else if (a.nv == 2 && ncf == 2 && ndim == 2) LSM_CELLS2(2, 2, 2);
         else LSM_CELLS2(0, 0, 0);
 #undef LSM_CELLS2
-        RE_HIP(hipMemcpyAsync(&ncand, ss.counters + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RE_HIP(hipMemcpyAsync(&ncand, ss.counters + 5, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RE_HIP(hipStreamSynchronize(stream));
     }
     ss.ncand = ncand;
-    RE_HIP(hipMemsetAsync(ss.counters, 0, 3 * sizeof(unsigned), stream));
     const size_t slots = (size_t)(ncand ? ncand : 1) * S;
     RE_HIP(grow(ss.pts, ss.cap_pts, sizeof(double) * 3 * slots));
     RE_HIP(grow(ss.valid, ss.cap_valid, slots));
     RE_HIP(hipMemsetAsync(ss.valid, 0, slots, stream));
     RE_HIP(grow(ss.cnt, ss.cap_cnt, (size_t)(ncand ? ncand : 1)));
-    RE_HIP(hipMemsetAsync(ss.cnt, 0, (size_t)(ncand ? ncand : 1), stream));
     if (!clean) {
         RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
         RE_HIP(hipMemsetAsync(ss.bits, 0, sizeof(unsigned long long) * nwords, stream));
     }
     if (ncand) {
         const long long work = (long long)ncand * S;
-        const unsigned gs = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
-#define LSM_SAMPLE(NV_, ND_) hipLaunchKernelGGL((reinit_sample_kernel<NV_, ND_>), dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid)
+        const unsigned gw = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
+        RE_HIP(grow(ss.starts, ss.cap_starts, sizeof(unsigned long long) * (size_t)work));
+        hipLaunchKernelGGL(reinit_starts_kernel, dim3((gw + 3) / 4), dim3(256), 0, stream, a, ss.cand_cell, ss.cand_id, ncand, S, ss.starts, ss.counters + 4);
+        // the projection kernel walks the registered points with a stride (their number stays on the device: about a third of `work` in 3-D)
+        const unsigned gs = gw / 2 + 1;
+#define LSM_SAMPLE(NV_, ND_) hipLaunchKernelGGL((reinit_sample_kernel<NV_, ND_>), dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ss.cand_id, S, ss.starts, \
+                                                ss.counters + 4, ss.pts, ss.valid)
         // (the dimension stays a run-time value here: the version with it fixed needs 288 registers in 3-D — one wave per SIMD — and
         // is slower capped at 256, 1.74 against 1.65 ms for the 256³ band call)
         if (a.nv == 2) LSM_SAMPLE(2, 0);
@@ -1410,7 +1512,7 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         else if (ndim == 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
         else hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, stream, __VA_ARGS__); } while (0)
 #define LSM_NEWTON_K(NV_, ND_, PASS, GRID) hipLaunchKernelGGL((reinit_newton_kernel<NV_, ND_>), GRID, dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, \
-                                                             ss.counters + 1, ss.counters + 2, W.retry, ss.counters, PASS)
+                                                             ss.counters + 1, ss.counters + 2, W.retry, ss.counters + 6, PASS)
 #define LSM_NEWTON(PASS, GRID) do { \
         if (a.nv == 4 && ndim == 3) LSM_NEWTON_K(4, 3, PASS, GRID); \
         else if (a.nv == 4 && ndim == 2) LSM_NEWTON_K(4, 2, PASS, GRID); \

@@ -108,6 +108,59 @@ def config5(n=768, steps=10, nlayers=3):
     return res
 
 
+def config5r(n=768, steps=40, nlayers=3, every=10):
+    """Config 5's float32 band with reinitialize! every `every` steps — the workflow of the reference's own narrow-band tests
+    (a posthook that reinitialises, test/test-narrow-band.jl:355-395).  `steps` is rounded to a multiple of `every`."""
+    import warnings
+    steps = max(every, steps // every * every)
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    f = lambda x: np.sqrt(x[0] ** 2 + x[1] ** 2 + x[2] ** 2) - 0.5
+    vals = lsm.LazyMeshField(f, grid).local_values(None).astype(np.float32)
+    eq = lsm.LevelSetEquation(terms=(lsm.AdvectionTerm(lsm.RigidRotation(), lsm.WENO5()), lsm.CurvatureTerm(-0.01)),
+                              ic=lsm.NarrowBandMeshField(lsm.MeshField(vals, grid, dtype=np.float32), nlayers=nlayers),
+                              bc=lsm.NeumannBC(), integrator=lsm.RK3())
+    del vals
+    state = {"tc": 0.0, "k": 0, "reinit_s": 0.0}
+
+    def one(timed_reinit=False):
+        tc = state["tc"]
+        eq._update_terms(eq.state, tc)
+        step = eq.integrator.cfl * eq.compute_cfl(tc)
+        eq._advance(tc, step)
+        eq.update_band()
+        state["tc"] = tc + step
+        state["k"] += 1
+        if state["k"] % every == 0:
+            if timed_reinit:
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+            lsm.reinitialize_(eq)
+            if timed_reinit:
+                torch.cuda.synchronize()
+                state["reinit_s"] += time.perf_counter() - t
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(every):
+            one()
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter()                      # out of the idle power state first (see timed())
+        while time.perf_counter() - t_pre < 0.08:
+            for _ in range(every):
+                one()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        for _ in range(steps):                            # a second pass with a synchronisation either side of every reinitialize!
+            one(True)
+    c = eq.state.active_count()
+    return {"config": f"3D {n}^3 float32 narrow band (nlayers {nlayers}), rotation WENO5 + curvature, RK3, reinitialize! every {every} steps",
+            "ms_per_step": round(ms, 3), "reinitialize_ms": round(state["reinit_s"] / (steps // every) * 1e3, 3), "reinitialize_every": every,
+            "active_nodes": c, "Mcells_s_grid": round(n ** 3 / ms / 1e3, 1), "Mcells_s_active": round(c / ms / 1e3, 1)}
+
+
 def upwind(n=512, steps=10):
     """An HBM-bound member of the family: first-order upwind advection, ForwardEuler, both storage types."""
     grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
@@ -166,11 +219,11 @@ def calib(n=512):
 
 
 def run(which, steps=None, warmup=None):
-    """`python bench.py --config {2,3,5}`: one JSON object in bench.py's vocabulary for a non-headline BASELINE config."""
+    """`python bench.py --config {2,3,5,5r}`: one JSON object in bench.py's vocabulary for a non-headline BASELINE config."""
     kw = {} if steps is None else {"steps": steps}
-    r = {"2": config2, "3": config3, "5": config5}[which](**kw)
+    r = {"2": config2, "3": config3, "5": config5, "5r": config5r}[which](**kw)
     out = {"metric": "Mcells/s per RK3 step", "unit": "Mcells/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
-           "dtype": "f32 storage / f64 arithmetic" if which == "5" else "f64", "config": {"workload": r["config"]}, "detail": r}
+           "dtype": "f32 storage / f64 arithmetic" if which in ("5", "5r") else "f64", "config": {"workload": r["config"]}, "detail": r}
     if which == "2":
         out["value"], out["ms_per_step"] = round(r["advect_Mcells_s"], 1), round(r["advect_ms_per_step"], 4)
     elif which == "3":
@@ -178,6 +231,8 @@ def run(which, steps=None, warmup=None):
         a = r["GBs_algorithmic"]
         out["roofline"] = {"bound": "hbm", "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 4), "traffic": None,
                            "kernel": "stage_kernel<3,NormalMotion,Curvature>", "avg_launch_ms": round(r["stage_ms"], 4)}
+    elif which == "5r":
+        out["value"], out["ms_per_step"] = r["Mcells_s_grid"], r["ms_per_step"]
     else:
         out["value"], out["ms_per_step"] = r["float32"]["Mcells_s_grid"], r["float32"]["ms_per_step"]
         # algorithmic bytes of a band step (SURVEY.md §8d with s = 4): 8 s = 32 B per ACTIVE node per RK3 step
@@ -197,6 +252,8 @@ if __name__ == "__main__":
         out.append(config3())
     if mode in ("all", "5"):
         out.append(config5())
+    if mode == "5r":
+        out.append(config5r())
     if mode in ("all", "upwind"):
         out.append(upwind())
     if mode == "terms":
