@@ -892,21 +892,6 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
                 if (d2 < bd) { bd = d2; bslot = slot; }
             }
         };
-        auto scan_row = [&](int lo, int hi, int c1, int c2) {
-            if (c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) return;
-            lo = lo < 0 ? 0 : lo; hi = hi >= nc_[0] ? nc_[0] - 1 : hi;
-            const long long row = bits_row(a, c1, c2);
-            for (int w0 = lo >> 6; w0 <= (hi >> 6); ++w0) {
-                unsigned long long m = bits[row + w0];
-                if (w0 == (lo >> 6)) m &= ~0ull << (lo & 63);
-                if (w0 == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    scan_cell(w0 * 64 + b, c1, c2);
-                }
-            }
-        };
         auto group_min = [&](double v) {
             for (int off = GRP / 2; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, GRP); v = o < v ? o : v; }
             return v;
@@ -914,9 +899,13 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
         const long long fe = foot[w];                 // the estimate's cell (reinit_foot_kernel)
         const bool have = fe >= 0;
         const int E[3] = {(int)(fe & 0x1fffff), (int)((fe >> 21) & 0x1fffff), (int)((fe >> 42) & 0x1fffff)};
-        if (have) {     // the rows around the estimate's cell, one per lane
-            const int r1 = ND > 1 ? 3 : 1, r2 = ND > 2 ? 3 : 1;
-            if (gl < r1 * r2) scan_row(E[0] - 1, E[0] + 1, E[1] + (ND > 1 ? gl % 3 - 1 : 0), E[2] + (ND > 2 ? gl / 3 - 1 : 0));
+        if (have) {     // the 3^N cells around the estimate's cell, spread over the lanes (two each in 3-D)
+            const int ncell = ND > 2 ? 27 : (ND > 1 ? 9 : 3);
+            for (int r = gl; r < ncell; r += GRP) {
+                const int c0 = E[0] + r % 3 - 1, c1 = ND > 1 ? E[1] + (r / 3) % 3 - 1 : 0, c2 = ND > 2 ? E[2] + r / 9 - 1 : 0;
+                if (c0 < 0 || c0 >= nc_[0] || c1 < 0 || c1 >= nc_[1] || c2 < 0 || c2 >= nc_[2]) continue;
+                scan_cell(c0, c1, c2);
+            }
         }
         bound = group_min(bd);
         const double R0 = sqrt(bound);
