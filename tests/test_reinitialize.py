@@ -115,6 +115,30 @@ def test_gpu_dense_matches_restatement(lsm, n, order, upsample):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,band", [((48, 44), None), ((22, 20, 21), None), ((40, 40, 40), 3)])
+def test_nodes_whose_first_solve_fails_take_the_second_pass(lsm, n, band):
+    """src/sdf.jl:113-131: the solve starts from the nearest sample; only where it does not converge are further near samples
+    collected and tried in order.  An unreachable xtol makes EVERY first solve "fail" (its iterate is at the closest point all the
+    same): every node then goes through the second pass — the shell search's five nearest samples, tried in order, the best
+    iterate kept — and must end where the ordinary call ends; the warning counts every evaluated node."""
+    nd = len(n)
+    ctr = (0.07, -0.04, 0.05)[:nd]
+    phi = _field(n, lambda X: sum((X[d] - ctr[d]) ** 2 for d in range(nd)) - 0.5 ** 2)
+    grid = lsm.CartesianGrid((-1.0,) * nd, (1.0,) * nd, n)
+    a = _device_field(lsm, phi, grid, lsm.ExtrapolationBC(3), band_layers=band).current_state()
+    b = _device_field(lsm, phi, grid, lsm.ExtrapolationBC(3), band_layers=band).current_state()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lsm.reinitialize_(a)
+    with pytest.warns(UserWarning, match="did not converge for") as rec:
+        lsm.reinitialize_(b, xtol=1e-300)
+    nodes = b.active_count() if band else int(np.prod(n))
+    assert f"did not converge for {nodes} / {nodes} points" in str(rec[0].message)
+    m = a.active_mask() if band else np.ones(n, bool)
+    assert np.abs(a.values()[m] - b.values()[m]).max() < 1e-7
+
+
+@pytest.mark.gpu
 def test_gpu_reference_tests_dense(lsm):
     """test/test-reinitializer.jl:71-100 through the host API: 2-D 100² (error < 2 sqrt(eps), volume preserved) and
     3-D 31³ with upsample 4 (error < 5e-3)."""
