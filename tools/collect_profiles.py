@@ -26,7 +26,7 @@ stats("trace_c5", "kernel_stats_config5.csv")
 stats("trace_reinit", "kernel_stats_reinit.csv")
 for f in ("pmc_per_dispatch.json", "bench_default_run.json", "bench_config2.json", "bench_config3.json", "bench_config5.json",
           "clock_probe.json", "slab_overhead.json", "reinit_bench.json", "terms.json", "timeline_probe.json", "timeline_probe_no_tail.json",
-          "tail_probe.jsonl", "pmc_terms.json", "bench_local8.json"):
+          "tail_probe.jsonl", "pmc_terms.json", "bench_local8.json", "bench_config5r.json", "reinit_bench_512.json", "reinit_timeline_256.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 

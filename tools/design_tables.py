@@ -78,8 +78,16 @@ def configs_table():
     f = os.path.join(P, "reinit_bench.json")
     if os.path.exists(f):
         r = json.load(open(f))
+        f5 = os.path.join(P, "reinit_bench_512.json")
+        if os.path.exists(f5):
+            r = r[:1] + [x for x in json.load(open(f5)) if x["band"]] + r[1:]
         rows.append("| `reinitialize!` (`tools/reinit_bench.py`) | " + "; ".join("%d³ %s, %.2f M nodes: %.2f ms" % (
-            x["n"], "band" if x["band"] else "dense", x["active_nodes"] / 1e6, x["ms"]) for x in r) + " | `reinit_bench.json`, `kernel_stats_reinit.csv` |")
+            x["n"], "band" if x["band"] else "dense", x["active_nodes"] / 1e6, x["ms"]) for x in r) + " | `reinit_bench.json`, `reinit_bench_512.json`, `kernel_stats_reinit.csv` |")
+    f = os.path.join(P, "bench_config5r.json")
+    if os.path.exists(f):
+        d = json.load(open(f))["detail"]
+        rows.append("| config 5 with `reinitialize!` every %d steps (`bench.py --config 5r`) | %.3f ms per step, `reinitialize!` %.2f ms per call (%.2f M band nodes) | `bench_config5r.json` |" % (
+            d["reinitialize_every"], d["ms_per_step"], d["reinitialize_ms"], d["active_nodes"] / 1e6))
     return "\n".join(rows)
 
 

@@ -36,5 +36,8 @@ python3 tools/pmc_terms_summary.py $OUT $OUT/pmc_terms.json > $OUT/pmc_terms.log
 python3 tools/slab_overhead.py > $OUT/slab_overhead.json 2> $OUT/slab_overhead.err
 python3 bench.py --transport local --gpus 8 --steps 6 --warmup 2 --prewarm 4 --no-cpu-baseline > $OUT/bench_local8.json 2> $OUT/bench_local8.err
 python3 tools/reinit_bench.py > $OUT/reinit_bench.json 2> $OUT/reinit_bench.err
+python3 tools/reinit_bench.py 512 32 > $OUT/reinit_bench_512.json 2> $OUT/reinit_bench_512.err
+python3 bench.py --config 5r > $OUT/bench_config5r.json 2> $OUT/bench_config5r.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_reinit -- python3 tools/reinit_bench.py > /dev/null 2> $OUT/trace_reinit.err
+tools/reinit_prof.sh ${OUT#*gpurun_out/}/reinit_prof > /dev/null 2>&1 && python3 tools/reinit_timeline.py $OUT/reinit_prof > $OUT/reinit_timeline_256.txt 2>&1   # (reinit_prof.sh writes under /root/repo/gpurun_out/)
 ls $OUT
