@@ -133,7 +133,7 @@ class ReinitRef:
             lo = self.node(I)
             for xi in itertools.product(range(self.upsample + 1), repeat=self.N):
                 xi = xi[::-1]             # Iterators.product: first range fastest (order is irrelevant to the point set)
-                x = lo + self.h * np.array(xi) / self.upsample
+                x = lo + ((lo + self.h) - lo) * np.array(xi) / self.upsample    # cell.lc .+ (cell.hc .- cell.lc) .* ξ ./ upsample (src/sdf.jl:167)
                 pt = self._project(x, safeguard)
                 if pt is None or self.cell_of(pt) != I:
                     continue

@@ -288,6 +288,34 @@ def test_newton_sdf_points_match_the_restatement(orc, ndim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,order,upsample", [((33, 29), 3, 2), ((31, 30), 2, 3), ((26, 22), 1, 1), ((17, 15, 16), 3, 2), ((19, 18, 17), 2, 3),
+                                              ((15, 16, 14), 3, 1)])
+def test_interface_samples_are_the_restatements_set(orc, n, order, upsample):
+    """get_sample_points (src/sdf.jl:56-63,186-221): the device projects every distinct start point once (a point on a face, edge or
+    corner is shared by up to 2^N cells) and the cell it lands in keeps it; the restatement projects it once per sharing cell, as
+    the reference does.  Same points, none twice, none missing — for upsample 1 (corners only: every start point is shared),
+    2 and 3, odd and even orders, 2-D and 3-D."""
+    import lsm_amd as lsm
+    from _reinit_ref import ReinitRef
+    nd = len(n)
+    lc, hc = (-1.0,) * nd, (1.0,) * nd
+    og = orc.Grid(lc, hc, n)
+    X = np.meshgrid(*og.coords(), indexing="ij")
+    vals = np.asfortranarray(np.sqrt(sum((x - 0.04 * (d + 1)) ** 2 for d, x in enumerate(X))) - 0.55 + 0.06 * np.sin(4 * X[0]) * np.cos(3 * X[-1]))
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(vals, lsm.CartesianGrid(lc, hc, n)), bc=lsm.ExtrapolationBC(2))
+    sdf = lsm.NewtonSDF(eq.current_state(), order=order, upsample=upsample, maxiters=12)
+    got = np.asarray(sdf.get_sample_points())
+    obc = orc.make_bc(("extrapolation", 2), nd)
+    ref = ReinitRef(lambda J: orc.get(og, obc, vals, J), n, lc, hc, order=order, upsample=upsample, maxiters=12)
+    want = np.asarray(ref.pts)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    from scipy.spatial import cKDTree
+    dist, idx = cKDTree(want).query(got)
+    assert dist.max() < 1e-11                       # every device sample is a sample of the restatement ...
+    assert len(np.unique(idx)) == len(want)         # ... and each of those exactly once
+
+
+@pytest.mark.gpu
 def test_hausdorff_distance_of_two_circles():
     """src/sdf.jl:129-150: concentric circles of radii 0.5 and 0.6 are 0.1 apart; a shifted one by its shift."""
     import lsm_amd as lsm
