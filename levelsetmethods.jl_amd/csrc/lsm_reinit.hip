@@ -401,8 +401,10 @@ __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const 
 // each start point is projected once: (a) the copy of the lowest candidate cell sharing a point registers it; (b) one thread per
 // registered point projects it and, where it converges into a candidate cell whose closure holds the start point, stores it in
 // that cell's slot of that start point — the reference's sample set, with 8 instead of 27 projections per cell in 3-D.  A cell
-// computes a start point from its own corner; two sharing cells are served by one projection only where they get the same
-// coordinates bit for bit (nearly always), since a point ON a cell boundary picks the patch of its first step by its last bit.
+// computes a start point from its own corner, the copies of two sharing cells may differ in the last bit, and a point ON a cell
+// boundary picks the patch of its first step by that bit (projections from the two patches end 1e-5 apart along the interface): two
+// cells are served by one projection only where their copies pick the same first cell (≈85 % of the shared coordinates); the
+// shared projection then differs from a cell's own by the last bit of its start.
 // coordinate d of start point xi (0..upsample) of the cell with lower corner index c, as the reference's cell computes it:
 // cell.lc .+ (cell.hc .- cell.lc) .* ξ ./ upsample with cell.lc = g.lc + (I - 1)·h, cell.hc = cell.lc + h (src/sdf.jl:167,
 // src/meshes.jl:114-117,183-184) — the cell's width is the difference of its corners, not h
@@ -410,6 +412,11 @@ __device__ __forceinline__ double start_coord(const ReinitArgs& a, int d, int c,
     const double lo = a.lc[d] + (double)(c + a.goff[d]) * a.h[d];
     const double hi = lo + a.h[d];
     return lo + (hi - lo) * (double)xi / (double)a.upsample;
+}
+// index along d of the cell whose patch the first projection step from coordinate x uses (cell_of, one dimension)
+__device__ __forceinline__ int first_cell(const ReinitArgs& a, int d, double x) {
+    const int i = (int)floor((x - a.lc[d]) / a.h[d]) - a.goff[d];
+    return i < 0 ? 0 : (i > a.n[d] - 2 ? a.n[d] - 2 : i);
 }
 __global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, unsigned ncand, int S,
                                                             unsigned long long* starts, unsigned* nstarts) {
@@ -437,12 +444,14 @@ __global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const 
                 const int xi[3] = {s % up1, (s / up1) % up1, s / (up1 * up1)};
                 // the cells sharing the point: I + δ, δ_d ∈ {-1, 0} where the point lies on the cell's lower face of dimension d,
                 // {0, +1} on its upper face; a copy is dropped when a candidate cell that precedes I (last dimension first) shares it
-                // (a neighbour computes the shared point from its own corner: where that differs in the last bit it is a different start
-                // point — the first step of its projection may pick another cell's patch — and both are projected)
+                // (a neighbour computes the shared point from its own corner; the two may differ in the last bit, and a point ON a cell
+                // boundary picks the patch of its first step by that bit: the copies are one projection only where they pick the same)
                 int lo[3], hi[3];
                 for (int d = 0; d < 3; ++d) {
-                    lo[d] = (d < a.ndim && xi[d] == 0 && I[d] > 0 && start_coord(a, d, I[d] - 1, up) == start_coord(a, d, I[d], 0)) ? -1 : 0;
-                    hi[d] = (d < a.ndim && xi[d] == up && I[d] < nc_[d] - 1 && start_coord(a, d, I[d] + 1, 0) == start_coord(a, d, I[d], up)) ? 1 : 0;
+                    lo[d] = (d < a.ndim && xi[d] == 0 && I[d] > 0 &&
+                             first_cell(a, d, start_coord(a, d, I[d] - 1, up)) == first_cell(a, d, start_coord(a, d, I[d], 0))) ? -1 : 0;
+                    hi[d] = (d < a.ndim && xi[d] == up && I[d] < nc_[d] - 1 &&
+                             first_cell(a, d, start_coord(a, d, I[d] + 1, 0)) == first_cell(a, d, start_coord(a, d, I[d], up))) ? 1 : 0;
                 }
                 own = true;
                 for (int d2 = lo[2]; d2 <= hi[2] && own; ++d2)
@@ -524,7 +533,7 @@ __global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kerne
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int xj = d < nd ? up * (I[d] - J[d]) + xi[d] : 0;     // the start point's index on cell J
-            mine = mine && xj >= 0 && xj <= up && (d >= nd || J[d] == I[d] || start_coord(a, d, J[d], xj) == x0[d]);
+            mine = mine && xj >= 0 && xj <= up && (d >= nd || J[d] == I[d] || first_cell(a, d, start_coord(a, d, J[d], xj)) == first_cell(a, d, x0[d]));
             sj += xj * mul;
             mul *= up1;
         }
