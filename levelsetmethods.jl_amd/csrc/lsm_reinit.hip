@@ -480,11 +480,8 @@ __global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const 
         __syncthreads();
     }
 }
-#ifndef LSM_SAMPLE_MINBLOCKS
-#define LSM_SAMPLE_MINBLOCKS 2
-#endif
-template <int NV, int ND>
-__global__ void __launch_bounds__(256, LSM_SAMPLE_MINBLOCKS) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, int S,
+template <int NV, int ND>      // (two workgroups per CU: at most 256 registers)
+__global__ void __launch_bounds__(256, 2) reinit_sample_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, int S,
                                                                                   const unsigned long long* starts, const unsigned* nstarts,
                                                                                   double* pts, unsigned char* valid) {
     const int nd = ndim_of<ND>(a);
