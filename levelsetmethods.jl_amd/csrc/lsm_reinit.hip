@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const
         int I[3];
         cell_unlin(a, cand_cell[id], I);
         const int B[3] = {I[0] / RB, I[1] / RB, I[2] / RB};
-        blk[blk_lin(a, B)] = 1;
+        blk[blk_lin(a, B)] = 1;                                                        // one byte per block of RB^N cells with samples
         atomicOr(bits + bits_row(a, I[1], I[2]) + I[0] / 64, 1ull << (I[0] & 63));     // one bit per cell with samples
     };
     if (S <= 32) {
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
 // (a) nearest samples of every active node -> seeds[NSEED * w .. ]   (latency-bound: keep it light on registers)
 template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
-                                                            const unsigned char* blk, const unsigned long long* bits,
+                                                            const unsigned long long* sup, const unsigned long long* bits,
                                                             const long long* node_list, long long nlist, long long* seeds) {
     // one lane per node, for the nodes the group kernel flagged (seeds[0] == -2)
     const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
@@ -1013,8 +1013,6 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
     for (int d = 1; d < ND; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
     const int nc_[3] = {a.n[0] - 1, ND > 1 ? a.n[1] - 1 : 1, ND > 2 ? a.n[2] - 1 : 1};      // cells per dimension
     const int nb_[3] = {(nc_[0] + RB - 1) / RB, (nc_[1] + RB - 1) / RB, (nc_[2] + RB - 1) / RB};  // blocks per dimension
-    int rmax = 1;
-    for (int d = 0; d < ND; ++d) rmax = nb_[d] > rmax ? nb_[d] : rmax;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
         if (seeds[NSEED * w] != -2) continue;
         const long long t = node_list ? node_list[w] : w;
@@ -1109,7 +1107,7 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
         }
         // otherwise: cells within Chebyshev radius s of the node, shell by shell; every unseen sample is then farther
         // than s*hmin
-        for (int s = 1; s <= FINE_SHELLS && !done; ++s) {
+        for (int s = 1; s <= FINE_SHELLS && !done && bslot[0] < 0; ++s) {      // (with a sample in hand the ball scan below is cheaper)
             const int lo[3] = {I[0] - s, ND > 1 ? I[1] - s : 0, ND > 2 ? I[2] - s : 0};
             const int hi[3] = {I[0] + s - 1, ND > 1 ? I[1] + s - 1 : 0, ND > 2 ? I[2] + s - 1 : 0};
             for (int c2 = lo[2]; c2 <= hi[2]; ++c2)
@@ -1119,26 +1117,61 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
                 }
             done = bslot[0] >= 0 && sqrt(bd[0]) <= (double)s * hmin;
         }
-        // far field: the same over blocks of RB^N cells, skipping blocks without samples; after block radius r every
-        // unseen sample is farther than (RB*r - 1)*hmin (the node lies inside the central block)
+        // far field: two levels of occupancy above the cells — blocks of RB^N cells, and per super-block of 8^N blocks the mask of its
+        // occupied blocks (`sup`, 8 words).  With nothing found yet the nearest occupied super-block is scanned first; then every
+        // super-block, and in it every occupied block, that meets the ball of the best distance so far.
         if (!done) {
-            const int Bn[3] = {(I[0] < nc_[0] ? I[0] : nc_[0] - 1) / RB, (I[1] < nc_[1] ? I[1] : nc_[1] - 1) / RB, (I[2] < nc_[2] ? I[2] : nc_[2] - 1) / RB};
-            for (int r = 0; r <= rmax && !done; ++r) {
-                const int lo[3] = {Bn[0] - r, ND > 1 ? Bn[1] - r : 0, ND > 2 ? Bn[2] - r : 0};
-                const int hi[3] = {Bn[0] + r, ND > 1 ? Bn[1] + r : 0, ND > 2 ? Bn[2] + r : 0};
-                for (int b2 = lo[2]; b2 <= hi[2]; ++b2)
-                    for (int b1 = lo[1]; b1 <= hi[1]; ++b1) {
-                        const bool edge12 = (ND > 2 && (b2 == lo[2] || b2 == hi[2])) || (ND > 1 && (b1 == lo[1] || b1 == hi[1]));
-                        for (int b0 = lo[0]; b0 <= hi[0]; b0 += (edge12 || hi[0] == lo[0]) ? 1 : (hi[0] - lo[0])) {
-                            if (b0 < 0 || b0 >= nb_[0] || b1 < 0 || b1 >= nb_[1] || b2 < 0 || b2 >= nb_[2]) continue;
-                            const int B[3] = {b0, b1, b2};
-                            if (!blk[blk_lin(a, B)] || box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[0]) continue;
-                            for (int c2 = b2 * RB; c2 < (ND > 2 ? (b2 + 1) * RB : 1); ++c2)
-                                for (int c1 = b1 * RB; c1 < (ND > 1 ? (b1 + 1) * RB : 1); ++c1)
-                                    scan_row(b0 * RB, (b0 + 1) * RB - 1, c1, c2);
-                        }
+            const int ns_[3] = {(nb_[0] + 7) / 8, (nb_[1] + 7) / 8, (nb_[2] + 7) / 8};
+            constexpr int SW = RB * 8;                     // cells per super-block and dimension
+            constexpr int NWORD = ND == 3 ? 8 : 1;
+            auto scan_super = [&](int s0, int s1, int s2) {
+                const long long sl = s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2);
+                for (int wd = 0; wd < NWORD; ++wd) {
+                    unsigned long long m = sup[8 * sl + wd];
+                    while (m) {
+                        const int l = wd * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int b0 = s0 * 8 + (l & 7), b1 = ND > 1 ? s1 * 8 + ((l >> 3) & 7) : 0, b2 = ND > 2 ? s2 * 8 + (l >> 6) : 0;
+                        if (box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[0]) continue;
+                        for (int c2 = b2 * RB; c2 < (ND > 2 ? (b2 + 1) * RB : 1); ++c2)
+                            for (int c1 = b1 * RB; c1 < (ND > 1 ? (b1 + 1) * RB : 1); ++c1)
+                                scan_row(b0 * RB, (b0 + 1) * RB - 1, c1, c2);
                     }
-                done = bslot[0] >= 0 && r >= 1 && sqrt(bd[0]) <= (double)(RB * r - 1) * hmin;
+                }
+            };
+            long long first = -1;
+            if (bslot[0] < 0) {
+                double best = __builtin_inf();
+                int f[3] = {0, 0, 0};
+                for (int s2 = 0; s2 < ns_[2]; ++s2)
+                    for (int s1 = 0; s1 < ns_[1]; ++s1)
+                        for (int s0 = 0; s0 < ns_[0]; ++s0) {
+                            const long long sl = s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2);
+                            unsigned long long any = 0;
+                            for (int wd = 0; wd < NWORD; ++wd) any |= sup[8 * sl + wd];
+                            if (!any) continue;
+                            const double d2 = box_d2(s0 * SW, s1 * SW, s2 * SW, SW);
+                            if (d2 < best) { best = d2; first = sl; f[0] = s0; f[1] = s1; f[2] = s2; }
+                        }
+                if (first >= 0) scan_super(f[0], f[1], f[2]);
+            }
+            if (bslot[0] >= 0) {
+                const double R = sqrt(bd[0]);
+                int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                for (int d = 0; d < ND; ++d) {
+                    const double kk = R / a.h[d];
+                    const int k = kk < (double)nc_[d] ? (int)kk : nc_[d];      // cells whose gap to the node is at most floor(R / h)
+                    int l = I[d] - k - 1, u = I[d] + k;
+                    l = l < 0 ? 0 : l; u = u > nc_[d] - 1 ? nc_[d] - 1 : u;
+                    lo[d] = l / SW; hi[d] = u / SW;
+                }
+                for (int s2 = lo[2]; s2 <= hi[2]; ++s2)
+                    for (int s1 = lo[1]; s1 <= hi[1]; ++s1)
+                        for (int s0 = lo[0]; s0 <= hi[0]; ++s0) {
+                            if (s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2) == first) continue;
+                            if (box_d2(s0 * SW, s1 * SW, s2 * SW, SW) > bd[0]) continue;
+                            scan_super(s0, s1, s2);
+                        }
             }
         }
         for (int k = 0; k < NSEED; ++k) seeds[NSEED * w + k] = bslot[k];
@@ -1313,20 +1346,21 @@ struct SampleSet {
     unsigned* counters = nullptr;      // [0] maybe cells, [1] nfail, [2] nfar, [3] band nodes, [4] start points, [5] candidate cells, [6] retried nodes
     double* pts = nullptr;
     unsigned char *valid = nullptr, *cnt = nullptr, *blk = nullptr;
+    unsigned long long* sup = nullptr;      // occupied blocks per super-block (reinit_sup_kernel)
     unsigned long long* bits = nullptr;
     unsigned long long* starts = nullptr;   // start points to project: candidate id | slot << 32
     // bytes allocated behind each pointer (grow(): a buffer is re-allocated only when a call needs more — the set of a NewtonSDF
     // object is built once; the workspace of reinitialize! lives on the handle and stops allocating after the first calls)
     size_t cap_cand_id = 0, cap_cand_cell = 0, cap_maybe = 0, cap_node_list = 0, cap_counters = 0, cap_pts = 0, cap_valid = 0, cap_cnt = 0, cap_blk = 0,
-           cap_bits = 0, cap_starts = 0;
+           cap_bits = 0, cap_starts = 0, cap_sup = 0;
     // workspace only: cand_id == -1, bits == 0 and blk == 0 everywhere for a grid of `clean_cells` cells — the state every band call
     // starts from, and restores by un-marking its own candidate cells (reinit_unmark_kernel) instead of clearing arrays of the size of the grid
     long long clean_cells = -1;
     void release() {
         (void)hipFree(cand_id); (void)hipFree(cand_cell); (void)hipFree(maybe); (void)hipFree(node_list); (void)hipFree(counters);
-        (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(bits); (void)hipFree(starts);
-        cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; bits = nullptr; starts = nullptr;
-        cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = cap_starts = 0;
+        (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(sup); (void)hipFree(bits); (void)hipFree(starts);
+        cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; sup = nullptr; bits = nullptr; starts = nullptr;
+        cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = cap_starts = cap_sup = 0;
         clean_cells = -1;
     }
 };
@@ -1357,6 +1391,21 @@ void reinit_workspace_free(ReinitWorkspace* w) {
     (void)hipFree(w->retry);
     (void)hipFree(w->foot);
     delete w;
+}
+// the second level of the far-field search: per super-block of 8^N blocks the mask of its occupied blocks, 8 words each (bit
+// b0 + 8·(b1 + 8·b2) of them), written whole from the block bytes
+__global__ void __launch_bounds__(256) reinit_sup_kernel(ReinitArgs a, const unsigned char* blk, unsigned long long* sup, long long nwords) {
+    const int nb_[3] = {(a.n[0] - 1 + RB - 1) / RB, a.ndim > 1 ? (a.n[1] - 1 + RB - 1) / RB : 1, a.ndim > 2 ? (a.n[2] - 1 + RB - 1) / RB : 1};
+    const long long s0n = (nb_[0] + 7) / 8, s1n = (nb_[1] + 7) / 8;
+    const int b = threadIdx.x & 63;                      // a wave per word, a lane per block
+    for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwords; w += ((long long)gridDim.x * blockDim.x) >> 6) {
+        const long long sl = w >> 3;
+        const int l = (int)(w & 7) * 64 + b;
+        const int s0 = (int)(sl % s0n), s1 = (int)((sl / s0n) % s1n), s2 = (int)(sl / (s0n * s1n));
+        const int B[3] = {s0 * 8 + (l & 7), s1 * 8 + ((l >> 3) & 7), s2 * 8 + (l >> 6)};
+        const unsigned long long m = __ballot(B[0] < nb_[0] && B[1] < nb_[1] && B[2] < nb_[2] && blk[blk_lin(a, B)] != 0);
+        if (b == 0) sup[w] = m;
+    }
 }
 // band calls on a workspace: back to cand_id == -1, bits == 0, blk == 0 by visiting the candidate cells of the call that ends
 __global__ void __launch_bounds__(256) reinit_unmark_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int* cand_id, unsigned char* blk,
@@ -1403,11 +1452,12 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     RE_HIP(grow(ss.counters, ss.cap_counters, 8 * sizeof(unsigned)));
     unsigned ncand = 0;
     RE_HIP(hipMemsetAsync(ss.counters, 0, 8 * sizeof(unsigned), stream));
-    size_t nblk = 1;
-    for (int d = 0; d < ndim; ++d) nblk *= (size_t)((n[d] - 1 + RB - 1) / RB);
+    size_t nblk = 1, nsupw = 8;                          // block bytes; words of `sup` (8 per super-block of 8^N blocks)
+    for (int d = 0; d < ndim; ++d) { nblk *= (size_t)((n[d] - 1 + RB - 1) / RB); nsupw *= (size_t)(((n[d] - 1 + RB - 1) / RB + 7) / 8); }
     size_t nwords = (size_t)((n[0] - 1 + 63) / 64);
     for (int d = 1; d < ndim; ++d) nwords *= (size_t)(n[d] - 1);
     RE_HIP(grow(ss.blk, ss.cap_blk, nblk, &fresh_blk));
+    RE_HIP(grow(ss.sup, ss.cap_sup, sizeof(unsigned long long) * nsupw));
     RE_HIP(grow(ss.bits, ss.cap_bits, sizeof(unsigned long long) * nwords, &fresh_bits));
     const bool clean = keep_clean && a.mask && ss.clean_cells == nc && !fresh_id && !fresh_blk && !fresh_bits;
     ss.clean_cells = -1;                       // until the caller has restored the state at the end of a successful call
@@ -1484,6 +1534,7 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
         hipLaunchKernelGGL(reinit_compact_kernel, dim3(S <= 32 ? (ncand + 7) / 8 : (ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid, ss.cnt,
                            ss.blk, ss.bits);
     }
+    hipLaunchKernelGGL(reinit_sup_kernel, dim3((unsigned)((nsupw + 3) / 4 > 65535 ? 65535 : (nsupw + 3) / 4)), dim3(256), 0, stream, a, ss.blk, ss.sup, (long long)nsupw);
     return 0;
 }
 
@@ -1531,11 +1582,11 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         // nearest sample per node (exact); what the guided search cannot settle goes to the shell search
         LSM_BY_ND(reinit_foot_kernel, dim3(gsr), a, ss.node_list, nwork, W.foot);
         LSM_BY_ND(reinit_search_group_kernel, gg, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, W.foot, seeds);
-        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, nwork, seeds);
         const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
         LSM_NEWTON(0, dim3(gn));
         // second pass for the nodes whose solve from the nearest sample did not converge (usually none: two short launches)
-        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.blk, ss.bits, ss.node_list, nwork, seeds);
+        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, nwork, seeds);
         LSM_NEWTON(1, dim3(gn > 1024 ? 1024 : gn));
 #undef LSM_NEWTON
 #undef LSM_NEWTON_K
@@ -1576,11 +1627,13 @@ struct SdfObject {
 
 // One thread per query point.  The nearest sample: Chebyshev shells of cells around the (clamped) cell of x, occupied
 // cells from the occupancy bits; every cell not yet visited after shell r lies at least r·hmin away from x, so the search
-// stops once the best sample is nearer than that — exact.  The next shell is scanned as well for the fall-back seeds.
+// stops once the best sample is nearer than that — exact.  The next shell is scanned as well for the fall-back seeds.  After four
+// shells the search goes on over occupied blocks (8^N cells) and super-blocks (8^N blocks) within the ball of the NSEED-th best
+// distance: a query far from the interface, or outside the grid, costs the blocks near its closest point, not r³ cells.
 template <int NV>
 __global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
-                                                         const unsigned long long* bits, long long npts, const double* xs, double* dist, double* cps,
-                                                         unsigned* nfail) {
+                                                         const unsigned long long* bits, const unsigned long long* sup, long long npts, const double* xs,
+                                                         double* dist, double* cps, unsigned* nfail) {
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
     const int nc_[3] = {a.n[0] - 1, a.ndim > 1 ? a.n[1] - 1 : 1, a.ndim > 2 ? a.n[2] - 1 : 1};
@@ -1604,6 +1657,9 @@ __global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int
                 double d2 = 0.0;
                 for (int d = 0; d < a.ndim; ++d) { const double e = pts[3 * slot + d] - xq[d]; d2 += e * e; }
                 if (!(d2 < bd[NSEED - 1])) continue;
+                bool dup = false;                         // (the block scan below revisits cells of the shells)
+                for (int q = 0; q < NSEED; ++q) dup = dup || bs[q] == slot;
+                if (dup) continue;
                 int q = NSEED - 1;                        // sorted insertion
                 while (q > 0 && d2 < bd[q - 1]) { bd[q] = bd[q - 1]; bs[q] = bs[q - 1]; --q; }
                 bd[q] = d2; bs[q] = slot;
@@ -1626,7 +1682,8 @@ __global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int
             }
         };
         int extra = 1;                                    // shells still to scan after the nearest sample is settled
-        for (int r = 0; r <= rmax && extra >= 0; ++r) {
+        constexpr int NEAR_SHELLS = 4;                    // beyond them: blocks and super-blocks (below)
+        for (int r = 0; r <= (rmax < NEAR_SHELLS ? rmax : NEAR_SHELLS) && extra >= 0; ++r) {
             const int r1 = a.ndim > 1 ? r : 0, r2 = a.ndim > 2 ? r : 0;
             for (int d2i = -r2; d2i <= r2; ++d2i)
                 for (int d1i = -r1; d1i <= r1; ++d1i) {
@@ -1635,6 +1692,65 @@ __global__ void __launch_bounds__(128) sdf_points_kernel(ReinitArgs a, const int
                     else { scan_row(C[0] - r, C[0] - r, C[1] + d1i, C[2] + d2i); scan_row(C[0] + r, C[0] + r, C[1] + d1i, C[2] + d2i); }
                 }
             if (bs[0] >= 0 && bd[0] <= ((double)r * hmin) * ((double)r * hmin)) --extra;
+        }
+        // far from the interface (or from the grid): the two occupancy levels above the cells, as in reinit_search_kernel — with
+        // nothing found yet the nearest occupied super-block first, then every super-block, and in it every occupied block, that
+        // meets the ball of the best distance so far
+        if (extra >= 0 && rmax > NEAR_SHELLS) {
+            const int nb_[3] = {(nc_[0] + RB - 1) / RB, (nc_[1] + RB - 1) / RB, (nc_[2] + RB - 1) / RB};
+            const int ns_[3] = {(nb_[0] + 7) / 8, (nb_[1] + 7) / 8, (nb_[2] + 7) / 8};
+            constexpr int SW = RB * 8;
+            const int nword = a.ndim == 3 ? 8 : 1;
+            auto box_d2 = [&](int c0, int c1, int c2, int w) {           // squared distance from x to the cells [c, c + w) per dimension
+                const int c[3] = {c0, c1, c2};
+                double d2 = 0.0;
+                for (int d = 0; d < a.ndim; ++d) {
+                    const int top = c[d] + w < nc_[d] ? c[d] + w : nc_[d];
+                    const double lo = a.lc[d] + (double)(c[d] + a.goff[d]) * a.h[d], hi = a.lc[d] + (double)(top + a.goff[d]) * a.h[d];
+                    const double e = xq[d] < lo ? lo - xq[d] : (xq[d] > hi ? xq[d] - hi : 0.0);
+                    d2 += e * e;
+                }
+                return d2;
+            };
+            auto scan_super = [&](int s0, int s1, int s2) {
+                const long long sl = s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2);
+                for (int wd = 0; wd < nword; ++wd) {
+                    unsigned long long m = sup[8 * sl + wd];
+                    while (m) {
+                        const int l = wd * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int b0 = s0 * 8 + (l & 7), b1 = a.ndim > 1 ? s1 * 8 + ((l >> 3) & 7) : 0, b2 = a.ndim > 2 ? s2 * 8 + (l >> 6) : 0;
+                        if (box_d2(b0 * RB, b1 * RB, b2 * RB, RB) > bd[NSEED - 1]) continue;       // (the fall-back seeds want the NSEED nearest)
+                        for (int c2 = b2 * RB; c2 < (a.ndim > 2 ? (b2 + 1) * RB : 1); ++c2)
+                            for (int c1 = b1 * RB; c1 < (a.ndim > 1 ? (b1 + 1) * RB : 1); ++c1)
+                                scan_row(b0 * RB, (b0 + 1) * RB - 1, c1, c2);
+                    }
+                }
+            };
+            long long first = -1;
+            if (bs[0] < 0) {
+                double best = __builtin_inf();
+                int f[3] = {0, 0, 0};
+                for (int s2 = 0; s2 < ns_[2]; ++s2)
+                    for (int s1 = 0; s1 < ns_[1]; ++s1)
+                        for (int s0 = 0; s0 < ns_[0]; ++s0) {
+                            const long long sl = s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2);
+                            unsigned long long any = 0;
+                            for (int wd = 0; wd < nword; ++wd) any |= sup[8 * sl + wd];
+                            if (!any) continue;
+                            const double d2 = box_d2(s0 * SW, s1 * SW, s2 * SW, SW);
+                            if (d2 < best) { best = d2; first = sl; f[0] = s0; f[1] = s1; f[2] = s2; }
+                        }
+                if (first >= 0) scan_super(f[0], f[1], f[2]);
+            }
+            if (bs[0] >= 0)
+                for (int s2 = 0; s2 < ns_[2]; ++s2)
+                    for (int s1 = 0; s1 < ns_[1]; ++s1)
+                        for (int s0 = 0; s0 < ns_[0]; ++s0) {
+                            if (s0 + (long long)ns_[0] * (s1 + (long long)ns_[1] * s2) == first) continue;
+                            if (box_d2(s0 * SW, s1 * SW, s2 * SW, SW) > bd[NSEED - 1]) continue;
+                            scan_super(s0, s1, s2);
+                        }
         }
         double cp[3] = {xq[0], xq[1], xq[2]}, g[3] = {0, 0, 0};
         bool conv = false, have = false;
@@ -1715,7 +1831,7 @@ int sdf_eval(SdfObject* o, long long npts, const double* xs, double* dist, doubl
     if (npts <= 0) { if (nfail) *nfail = 0; return 0; }
     (void)hipMemsetAsync(o->ss.counters + 1, 0, sizeof(unsigned), o->stream);
     const unsigned gb = (unsigned)((npts + 127) / 128 > 65535 ? 65535 : (npts + 127) / 128);
-#define LSM_SDF(NV_) hipLaunchKernelGGL(sdf_points_kernel<NV_>, dim3(gb), dim3(128), 0, o->stream, a, o->ss.cand_id, o->ss.S, o->ss.pts, o->ss.cnt, o->ss.bits, npts, xs, dist, cps, o->ss.counters + 1)
+#define LSM_SDF(NV_) hipLaunchKernelGGL(sdf_points_kernel<NV_>, dim3(gb), dim3(128), 0, o->stream, a, o->ss.cand_id, o->ss.S, o->ss.pts, o->ss.cnt, o->ss.bits, o->ss.sup, npts, xs, dist, cps, o->ss.counters + 1)
     if (a.nv == 2) LSM_SDF(2); else if (a.nv == 4) LSM_SDF(4); else LSM_SDF(6);
 #undef LSM_SDF
     unsigned nf = 0;

@@ -316,6 +316,47 @@ def test_interface_samples_are_the_restatements_set(orc, n, order, upsample):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(150, 141), (75, 70, 72)])
+def test_far_queries_and_far_nodes_cross_the_block_levels(orc, n):
+    """Far from the interface the nearest sample is found over occupied blocks (8^N cells) and super-blocks (8^N blocks) instead of
+    shells of cells; these grids have two and more super-blocks per dimension.  NewtonSDF at points far inside, far outside and
+    beyond the grid, and reinitialize! of the dense field at its far corners, against the restatement (exact KD-tree seed)."""
+    import lsm_amd as lsm
+    from _reinit_ref import ReinitRef
+    nd = len(n)
+    lc, hc = (-1.0,) * nd, (1.0,) * nd
+    og = orc.Grid(lc, hc, n)
+    X = np.meshgrid(*og.coords(), indexing="ij")
+    ctr = (0.45, -0.4, 0.35)[:nd]
+    vals = np.asfortranarray(np.sqrt(sum((x - c) ** 2 for x, c in zip(X, ctr))) - 0.3)
+    obc = orc.make_bc(("extrapolation", 2), nd)
+    # the restatement samples the cells around the interface only (every other cell is proven empty anyway)
+    near = np.argwhere(np.abs(vals) < 3 * (2.0 / (min(n) - 1)))
+    cells = sorted({tuple(int(min(max(i + o, 0), n[d] - 2)) for d, (i, o) in enumerate(zip(I, off)))
+                    for I in near for off in itertools.product((-1, 0), repeat=nd)})
+    ref = ReinitRef(lambda J: orc.get(og, obc, vals, J), n, lc, hc, order=3, upsample=2, maxiters=12, cells=cells)
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.MeshField(vals, lsm.CartesianGrid(lc, hc, n)), bc=lsm.ExtrapolationBC(2))
+    sdf = lsm.NewtonSDF(eq.current_state(), order=3, upsample=2, maxiters=12)
+    assert sdf.nsamples == len(ref.pts)
+    rng = np.random.default_rng(4)
+    pts = np.concatenate([-1.0 + 2.0 * rng.random((24, nd)), -1.6 + 3.2 * rng.random((8, nd)), np.array([ctr]), np.array([lc]), np.array([hc])])
+    cp, nfail = sdf.closest_point(pts)
+    assert nfail == 0
+    for k, x in enumerate(pts):
+        rcp, ok = ref.closest_point(x)
+        assert ok and np.abs(cp[k] - rcp).max() <= 1e-9, (k, x, cp[k], rcp)
+    st = eq.current_state()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lsm.reinitialize_(st, order=3, upsample=2, maxiters=12)
+    got = st.values()
+    corners = list(itertools.product(*[(0, k // 3, k - 1) for k in n]))
+    want, nf = ref.reinitialize(corners)
+    assert nf == 0
+    assert max(abs(got[I] - v) for I, v in want.items()) < 1e-9
+
+
+@pytest.mark.gpu
 def test_hausdorff_distance_of_two_circles():
     """src/sdf.jl:129-150: concentric circles of radii 0.5 and 0.6 are 0.1 apart; a shifted one by its shift."""
     import lsm_amd as lsm
