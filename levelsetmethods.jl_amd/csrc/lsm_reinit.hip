@@ -17,7 +17,8 @@
 //  * closest point (src/sdf.jl:85-131,223-249): the nearest sample — exact, like the reference's KD-tree query:
 //    a cheap estimate of the closest point (one lane per node) leads to the cells that hold it, and every cell meeting the
 //    ball of that radius around the node is then scanned (16 lanes per node; occupancy bits per cell); nodes without a
-//    usable estimate fall back to expanding shells of cells, then of 8^N-cell blocks — seeds a damped
+//    usable estimate fall back to expanding shells of cells, nodes far from the interface to the occupied 8^N-cell blocks of the
+//    occupied super-blocks (8^N blocks) that meet the ball of the best distance so far — seeds a damped
 //    Newton–Lagrange solve on the seed cell's patch.  Where that solve fails, the NSEED nearest samples are collected by the
 //    shell search and tried in order in a second pass (the reference: nn first, then knn with up to 10).
 // fp64 throughout; -ffp-contract=off except inside the patch evaluation (cardinal functions and the tensor contraction), which
