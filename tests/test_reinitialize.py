@@ -92,7 +92,7 @@ def _device_field(lsm, phi, grid, bc, band_layers=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,order,upsample", [((40, 36), 3, 2), ((33, 30), 2, 3), ((30, 41), 5, 2), ((14, 12, 13), 3, 2)])
+@pytest.mark.parametrize("n,order,upsample", [((40, 36), 3, 2), ((33, 30), 2, 3), ((30, 41), 5, 2), ((14, 12, 13), 3, 2), ((90,), 3, 2), ((61,), 4, 3)])
 def test_gpu_dense_matches_restatement(lsm, n, order, upsample):
     """Same samples-to-seed-to-closest-point pipeline with tight tolerances: the two implementations must agree to
     round-off amplification (1e-10), not just to the solver tolerance."""
@@ -108,7 +108,7 @@ def test_gpu_dense_matches_restatement(lsm, n, order, upsample):
         lsm.reinitialize_(st, order=order, upsample=upsample, xtol=1e-13, ftol=1e-13)
     got = st.values()
     R = ReinitRef(_dense_getter(phi, 3), n, (-1.0,) * nd, (1.0,) * nd, order=order, upsample=upsample, xtol=1e-13, ftol=1e-13)
-    nodes = [I for k, I in enumerate(itertools.product(*[range(k) for k in n])) if k % (3 if nd == 2 else 11) == 0]
+    nodes = [I for k, I in enumerate(itertools.product(*[range(k) for k in n])) if k % {1: 1, 2: 3, 3: 11}[nd] == 0]
     want, nfail = R.reinitialize(nodes)
     assert nfail == 0
     assert max(abs(got[I] - v) for I, v in want.items()) < 1e-10
