@@ -23,6 +23,7 @@
 //    shell search and tried in order in a second pass (the reference: nn first, then knn with up to 10).
 // fp64 throughout; -ffp-contract=off except inside the patch evaluation (cardinal functions and the tensor contraction), which
 // contracts to fma.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -45,6 +46,20 @@ struct ReinitArgs {
     int f32;
     const unsigned char* mask;   // NULL = dense
 };
+
+// A length that may still be on the device when the kernel is launched: the host sizes grids and buffers from what the previous call
+// needed, the kernel reads the count and never goes beyond the buffer's capacity; whether it fitted is checked once, at the end of
+// the call (reinit_run).  p == NULL: the host knows the length.
+struct DevCount {
+    const unsigned* p;
+    unsigned cap;
+    long long host;
+};
+__device__ __forceinline__ long long count_of(const DevCount& c) {
+    if (!c.p) return c.host;
+    const unsigned v = *c.p;
+    return v < c.cap ? v : c.cap;
+}
 
 __device__ __constant__ double kBinom[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0},
                                                {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
@@ -305,9 +320,9 @@ __device__ void bernstein_extrema_reg(const ReinitArgs& a, long long q0, double&
 // node_list != NULL (band fields): only the cells whose lowest corner is a listed (active) node are looked at, and
 // cand_id has been set to -1 by the caller.
 __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* cand_id, long long* maybe, unsigned* maybe_count,
-                                                           const long long* node_list, long long nlist) {
+                                                           const long long* node_list, DevCount nlist) {
     __shared__ unsigned blk_n, blk_base;
-    const long long nc = node_list ? nlist : ncells(a);
+    const long long nc = node_list ? count_of(nlist) : ncells(a);
     const long long span = (nc + 255) / 256 * 256;      // whole workgroups reach the barriers
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < span; w += (long long)gridDim.x * blockDim.x) {
         bool keep = false;
@@ -360,7 +375,7 @@ __global__ void __launch_bounds__(256) reinit_cells_kernel(ReinitArgs a, int* ca
 }
 template <int NV, int NC, int NDIM>   // NV = 0: the general version
 __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const long long* maybe, const unsigned* maybe_count, int* cand_id,
-                                                            long long* cand_cell, unsigned* cand_count) {
+                                                            long long* cand_cell, unsigned* cand_count, unsigned cand_cap) {
     const unsigned nmaybe = *maybe_count;          // stays on the device: the launch does not wait for it
     __shared__ unsigned blk_n, blk_base;
     const int lane = threadIdx.x & 63;
@@ -389,9 +404,13 @@ __global__ void __launch_bounds__(256) reinit_cells2_kernel(ReinitArgs a, const 
         if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(cand_count, blk_n);
         __syncthreads();
         if (keep) {
+            // a candidate beyond what the per-candidate buffers (samples, counts) hold is counted — the host repeats the round with larger
+            // buffers — and otherwise left alone: no id may point outside them
             const unsigned id = blk_base + wbase + __popcll(bal & ((1ull << lane) - 1ull));
-            cand_id[c] = (int)id;
-            cand_cell[id] = c;
+            if (id < cand_cap) {
+                cand_id[c] = (int)id;
+                cand_cell[id] = c;
+            }
         }
     }
 }
@@ -419,8 +438,9 @@ __device__ __forceinline__ int first_cell(const ReinitArgs& a, int d, double x) 
     const int i = (int)floor((x - a.lc[d]) / a.h[d]) - a.goff[d];
     return i < 0 ? 0 : (i > a.n[d] - 2 ? a.n[d] - 2 : i);
 }
-__global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, unsigned ncand, int S,
+__global__ void __launch_bounds__(256) reinit_starts_kernel(ReinitArgs a, const long long* cand_cell, const int* cand_id, DevCount ncand_, int S,
                                                             unsigned long long* starts, unsigned* nstarts) {
+    const long long ncand = count_of(ncand_);
     // a workgroup collects the registered points of 1024 (cell, start point) pairs in LDS and appends them with ONE atomic: a wave-level
     // append to the single counter took 375 µs for 16 k waves
     constexpr int CHUNK = 4;
@@ -553,9 +573,10 @@ __device__ __forceinline__ long long bits_row(const ReinitArgs& a, int c1, int c
     const long long wpr = (a.n[0] - 1 + 63) / 64, c1n = a.ndim > 1 ? a.n[1] - 1 : 1;
     return wpr * (c1 + c1n * (long long)c2);
 }
-__global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int S, double* pts,
+__global__ void __launch_bounds__(256) reinit_compact_kernel(ReinitArgs a, const long long* cand_cell, DevCount ncand_, int S, double* pts,
                                                              const unsigned char* valid, unsigned char* cnt, unsigned char* blk,
                                                              unsigned long long* bits) {
+    const unsigned ncand = (unsigned)count_of(ncand_);
     auto mark = [&](unsigned id) {
         int I[3];
         cell_unlin(a, cand_cell[id], I);
@@ -841,8 +862,8 @@ __device__ __forceinline__ bool first_order_foot(const ReinitArgs& a, const doub
 // the estimate's cell per node, one lane per node (21 bits per index; -1 = no usable estimate): the 16 lanes that share a node in the
 // search below would all compute the same five dependent steps — a third of that kernel's instructions
 template <int ND>
-__global__ void __launch_bounds__(256) reinit_foot_kernel(ReinitArgs a, const long long* node_list, long long nlist, long long* foot) {
-    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+__global__ void __launch_bounds__(256) reinit_foot_kernel(ReinitArgs a, const long long* node_list, DevCount nlist, long long* foot) {
+    const long long total = node_list ? count_of(nlist) : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0];
     for (int d = 1; d < ND; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
@@ -875,9 +896,9 @@ constexpr int QCAP = LSM_REINIT_QCAP;
 template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts,
                                                                   const unsigned char* cnt, const unsigned long long* bits,
-                                                                  const long long* node_list, long long nlist, const long long* foot,
+                                                                  const long long* node_list, DevCount nlist, const long long* foot,
                                                                   long long* seeds) {
-    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    const long long total = node_list ? count_of(nlist) : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0];
     for (int d = 1; d < ND; ++d) hmin = a.h[d] < hmin ? a.h[d] : hmin;
     const int nc_[3] = {a.n[0] - 1, ND > 1 ? a.n[1] - 1 : 1, ND > 2 ? a.n[2] - 1 : 1};
@@ -1007,9 +1028,9 @@ __global__ void __launch_bounds__(256) reinit_search_group_kernel(ReinitArgs a, 
 template <int ND>
 __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const int* cand_id, int S, const double* pts, const unsigned char* cnt,
                                                             const unsigned long long* sup, const unsigned long long* bits,
-                                                            const long long* node_list, long long nlist, long long* seeds) {
+                                                            const long long* node_list, DevCount nlist, long long* seeds) {
     // one lane per node, for the nodes the group kernel flagged (seeds[0] == -2)
-    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+    const long long total = node_list ? count_of(nlist) : (long long)a.n[0] * a.n[1] * a.n[2];
     double hmin = a.h[0], hmax = a.h[0];
     for (int d = 1; d < ND; ++d) { hmin = a.h[d] < hmin ? a.h[d] : hmin; hmax = a.h[d] > hmax ? a.h[d] : hmax; }
     const int nc_[3] = {a.n[0] - 1, ND > 1 ? a.n[1] - 1 : 1, ND > 2 ? a.n[2] - 1 : 1};      // cells per dimension
@@ -1183,10 +1204,10 @@ __global__ void __launch_bounds__(256) reinit_search_kernel(ReinitArgs a, const 
 // (seeds[1] == -4) and whose solve from it does not converge is appended to `retry` and marked for the shell search (seeds[0] = -2),
 // which collects its NSEED nearest samples; pass 1 runs over the `retry` list with them.
 template <int NV, int ND>
-__global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S, const double* pts, const long long* node_list, long long nlist,
+__global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S, const double* pts, const long long* node_list, DevCount nlist,
                                                             long long* seeds, void* out, unsigned* nfail, unsigned* nfar, unsigned* retry,
                                                             unsigned* retry_count, int pass) {
-    const long long total = pass ? (long long)*retry_count : (node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2]);
+    const long long total = pass ? (long long)*retry_count : (node_list ? count_of(nlist) : (long long)a.n[0] * a.n[1] * a.n[2]);
     double hmax = a.h[0];
     for (int d = 1; d < a.ndim; ++d) hmax = a.h[d] > hmax ? a.h[d] : hmax;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1232,8 +1253,11 @@ __global__ void __launch_bounds__(128) reinit_newton_kernel(ReinitArgs a, int S,
 }
 
 // copy the new values of the active nodes back (the evaluation phase never writes ϕ: src/reinitializer.jl:21-24)
-__global__ void __launch_bounds__(256) reinit_commit_kernel(ReinitArgs a, const void* src, void* dst, const long long* node_list, long long nlist) {
-    const long long total = node_list ? nlist : (long long)a.n[0] * a.n[1] * a.n[2];
+// — unless one of the call's lists did not fit its buffer (the host repeats the call with larger ones: ϕ must still be what it was)
+__global__ void __launch_bounds__(256) reinit_commit_kernel(ReinitArgs a, const void* src, void* dst, const long long* node_list, DevCount nlist,
+                                                            DevCount ncand) {
+    if ((nlist.p && *nlist.p > nlist.cap) || (ncand.p && *ncand.p > ncand.cap)) return;
+    const long long total = node_list ? count_of(nlist) : (long long)a.n[0] * a.n[1] * a.n[2];
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
         const long long t = node_list ? node_list[w] : w;
         const long long q = a.origin + (t % a.n[0]) + ((t / a.n[0]) % a.n[1]) * a.s1 + (t / ((long long)a.n[0] * a.n[1])) * a.s2;
@@ -1341,6 +1365,8 @@ struct SampleSet {
     ReinitArgs a;
     int S = 0;                 // start points per cell
     unsigned ncand = 0;        // candidate cells
+    unsigned cap_nodes_e = 0, cap_cand_e = 0;   // entries the node list / the per-candidate buffers were launched with (launch_samples)
+    DevCount dn{nullptr, 0, 0}, dc{nullptr, 0, 0};   // the two lengths as the kernels of this round see them
     long long nwork = 0;       // active nodes (band) or all nodes
     int* cand_id = nullptr;
     long long *cand_cell = nullptr, *maybe = nullptr, *node_list = nullptr;
@@ -1362,6 +1388,7 @@ struct SampleSet {
         (void)hipFree(pts); (void)hipFree(valid); (void)hipFree(cnt); (void)hipFree(blk); (void)hipFree(sup); (void)hipFree(bits); (void)hipFree(starts);
         cand_id = nullptr; cand_cell = maybe = node_list = nullptr; counters = nullptr; pts = nullptr; valid = cnt = blk = nullptr; sup = nullptr; bits = nullptr; starts = nullptr;
         cap_cand_id = cap_cand_cell = cap_maybe = cap_node_list = cap_counters = cap_pts = cap_valid = cap_cnt = cap_blk = cap_bits = cap_starts = cap_sup = 0;
+        cap_nodes_e = cap_cand_e = 0;
         clean_cells = -1;
     }
 };
@@ -1384,6 +1411,7 @@ struct ReinitWorkspace {
     unsigned* retry = nullptr;         // nodes whose solve from the nearest sample failed (second pass of the closest-point kernel)
     long long* foot = nullptr;         // cell of the first-order closest-point estimate per node
     size_t cap_seeds = 0, cap_retry = 0, cap_foot = 0;
+    unsigned last_nodes = 0, last_cand = 0;      // band nodes and candidate cells of the previous call: what the next one is launched for
 };
 void reinit_workspace_free(ReinitWorkspace* w) {
     if (!w) return;
@@ -1409,8 +1437,9 @@ __global__ void __launch_bounds__(256) reinit_sup_kernel(ReinitArgs a, const uns
     }
 }
 // band calls on a workspace: back to cand_id == -1, bits == 0, blk == 0 by visiting the candidate cells of the call that ends
-__global__ void __launch_bounds__(256) reinit_unmark_kernel(ReinitArgs a, const long long* cand_cell, unsigned ncand, int* cand_id, unsigned char* blk,
+__global__ void __launch_bounds__(256) reinit_unmark_kernel(ReinitArgs a, const long long* cand_cell, DevCount ncand_, int* cand_id, unsigned char* blk,
                                                             unsigned long long* bits) {
+    const unsigned ncand = (unsigned)count_of(ncand_);
     for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < ncand; id += gridDim.x * blockDim.x) {
         const long long c = cand_cell[id];
         cand_id[c] = -1;
@@ -1437,9 +1466,12 @@ static int setup_args(ReinitArgs& a, int ndim, const int n[3], const int goff[3]
 }
 
 #define RE_HIP(call) do { if ((call) != hipSuccess) { *err = #call; ss.release(); return 2; } } while (0)
-// candidate cells -> interface samples -> per-cell counts, occupancy bits and blocks (steps 1 and 2 above); ss.a is set.
-// `keep_clean`: ss is a workspace whose cand_id / bits / blk are restored by the caller after the call (band fields only)
-static int build_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err, bool keep_clean = false) {
+// Candidate cells -> interface samples -> per-cell counts, occupancy bits, blocks and super-blocks (steps 1 and 2 above) — launched
+// without waiting for anything: the number of band nodes and of candidate cells stay on the device (DevCount), the buffers are sized
+// for `want_nodes` / `want_cand` entries (what the previous call needed, with headroom) and the caller checks afterwards whether
+// both fitted (samples_fit) — if not it launches again with what it has learnt; a first call takes up to three rounds.  ss.a is set.
+// `keep_clean`: ss is a workspace whose cand_id / bits / blk are restored by the caller after the call (band fields only).
+static int launch_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err, bool keep_clean, unsigned want_nodes, unsigned want_cand) {
     const ReinitArgs& a = ss.a;
     const int ndim = a.ndim;
     const int* n = a.n;
@@ -1451,7 +1483,6 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     bool fresh_id = false, fresh_blk = false, fresh_bits = false;
     RE_HIP(grow(ss.cand_id, ss.cap_cand_id, sizeof(int) * (size_t)nc, &fresh_id));
     RE_HIP(grow(ss.counters, ss.cap_counters, 8 * sizeof(unsigned)));
-    unsigned ncand = 0;
     RE_HIP(hipMemsetAsync(ss.counters, 0, 8 * sizeof(unsigned), stream));
     size_t nblk = 1, nsupw = 8;                          // block bytes; words of `sup` (8 per super-block of 8^N blocks)
     for (int d = 0; d < ndim; ++d) { nblk *= (size_t)((n[d] - 1 + RB - 1) / RB); nsupw *= (size_t)(((n[d] - 1 + RB - 1) / RB + 7) / 8); }
@@ -1461,40 +1492,42 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
     RE_HIP(grow(ss.sup, ss.cap_sup, sizeof(unsigned long long) * nsupw));
     RE_HIP(grow(ss.bits, ss.cap_bits, sizeof(unsigned long long) * nwords, &fresh_bits));
     const bool clean = keep_clean && a.mask && ss.clean_cells == nc && !fresh_id && !fresh_blk && !fresh_bits;
-    ss.clean_cells = -1;                       // until the caller has restored the state at the end of a successful call
+    ss.clean_cells = -1;                       // until the caller has restored the state at the end of the call
     // band fields: the compact list of the active nodes first — candidate cells, the distance computation and the
     // commit all run over it (the band is ~1 % of a 3-D grid)
     const long long nodes = (long long)n[0] * n[1] * n[2];
-    ss.nwork = nodes;
+    if (nodes > 0xffffffffll) { *err = "reinitialize: more than 2^32 nodes"; ss.release(); return 1; }
     if (a.mask) {
-        unsigned nact = 0;
+        RE_HIP(grow(ss.node_list, ss.cap_node_list, sizeof(long long) * (size_t)(want_nodes ? want_nodes : 1)));
+        ss.cap_nodes_e = (unsigned)std::min<size_t>(ss.cap_node_list / sizeof(long long), 0xffffffffu);
         const long long nvec = (total + 15) / 16;
         const unsigned gl = (unsigned)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        // the list is filled in ONE pass when the workspace already holds one (the band's size drifts slowly: the count is checked
-        // against the capacity afterwards); the first call counts first
-        const size_t have = ss.node_list ? ss.cap_node_list / sizeof(long long) : 0;
-        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, (long long)have, ss.counters + 3);
-        RE_HIP(hipMemcpyAsync(&nact, ss.counters + 3, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        RE_HIP(hipStreamSynchronize(stream));
-        if (nact > have) {
-            RE_HIP(grow(ss.node_list, ss.cap_node_list, sizeof(long long) * (size_t)(nact ? nact : 1)));
-            RE_HIP(hipMemsetAsync(ss.counters + 3, 0, sizeof(unsigned), stream));
-            hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, (long long)(ss.cap_node_list / sizeof(long long)),
-                               ss.counters + 3);
-        }
-        ss.nwork = nact;
+        hipLaunchKernelGGL(reinit_band_nodes_kernel, dim3(gl), dim3(256), 0, stream, a, total, ss.node_list, (long long)ss.cap_nodes_e, ss.counters + 3);
         if (!clean) RE_HIP(hipMemsetAsync(ss.cand_id, 0xFF, sizeof(int) * (size_t)nc, stream));     // -1 everywhere; the cells kernel visits the band only
+        ss.dn = DevCount{ss.counters + 3, ss.cap_nodes_e, 0};
+    } else {
+        ss.cap_nodes_e = (unsigned)nodes;
+        ss.dn = DevCount{nullptr, 0, nodes};
     }
-    const long long ncell_work = a.mask ? ss.nwork : nc;
-    const unsigned gb = (unsigned)((ncell_work + 255) / 256 > 65535 ? 65535 : (ncell_work + 255) / 256);
+    // the cells looked at: those whose lowest corner is a band node, or all of them
+    const long long ncell_work = a.mask ? (long long)ss.cap_nodes_e : nc, ncell_grid = a.mask ? (long long)(want_nodes ? want_nodes : 1) : nc;
+    const unsigned gb = (unsigned)((ncell_grid + 255) / 256 > 65535 ? 65535 : (ncell_grid + 255) / 256);
     RE_HIP(grow(ss.maybe, ss.cap_maybe, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
-    if (ncell_work) hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, ss.cand_id, ss.maybe, ss.counters, ss.node_list, ss.nwork);
-    // every "maybe" cell may turn out a candidate; their number is read by the next kernel on the device (a grid for half of the cells looked at,
-    // walked with a stride: about a sixth of them are "maybe" cells on a band)
+    hipLaunchKernelGGL(reinit_cells_kernel, dim3(gb), dim3(256), 0, stream, a, ss.cand_id, ss.maybe, ss.counters, ss.node_list, ss.dn);
+    // samples: S slots per candidate cell, for at most cap_cand_e of them
+    const size_t wantc = want_cand ? want_cand : 1;
+    RE_HIP(grow(ss.pts, ss.cap_pts, sizeof(double) * 3 * wantc * S));
+    RE_HIP(grow(ss.valid, ss.cap_valid, wantc * S));
+    RE_HIP(grow(ss.cnt, ss.cap_cnt, wantc));
+    RE_HIP(grow(ss.starts, ss.cap_starts, sizeof(unsigned long long) * wantc * S));
+    const size_t capc = std::min(std::min(ss.cap_pts / (sizeof(double) * 3 * S), ss.cap_valid / S), std::min(ss.cap_cnt, ss.cap_starts / (sizeof(unsigned long long) * S)));
+    ss.cap_cand_e = want_cand ? (unsigned)std::min<size_t>(capc, 0xffffffffu) : 0u;
+    ss.dc = DevCount{ss.counters + 5, ss.cap_cand_e, 0};
+    // the list of candidate cells (as long as the "maybe" list could be)
     RE_HIP(grow(ss.cand_cell, ss.cap_cand_cell, sizeof(long long) * (size_t)(ncell_work ? ncell_work : 1)));
-    if (ncell_work) {
-        const dim3 g2((unsigned)((ncell_work / 2 + 255) / 256 > 65535 ? 65535 : (ncell_work / 2 + 255) / 256)), b2(256);
-#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, ss.counters, ss.cand_id, ss.cand_cell, ss.counters + 5)
+    {
+        const dim3 g2((unsigned)((ncell_grid / 2 + 256) / 256 > 65535 ? 65535 : (ncell_grid / 2 + 256) / 256)), b2(256);
+#define LSM_CELLS2(NV_, NC_, ND_) hipLaunchKernelGGL((reinit_cells2_kernel<NV_, NC_, ND_>), g2, b2, 0, stream, a, ss.maybe, ss.counters, ss.cand_id, ss.cand_cell, ss.counters + 5, ss.cap_cand_e)
         const int ncf = a.order + 1;
         if (a.nv == 4 && ncf == 4 && ndim == 3) LSM_CELLS2(4, 4, 3);
         else if (a.nv == 4 && ncf == 4 && ndim == 2) LSM_CELLS2(4, 4, 2);
@@ -1504,24 +1537,16 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
         else if (a.nv == 2 && ncf == 2 && ndim == 2) LSM_CELLS2(2, 2, 2);
         else LSM_CELLS2(0, 0, 0);
 #undef LSM_CELLS2
-        RE_HIP(hipMemcpyAsync(&ncand, ss.counters + 5, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        RE_HIP(hipStreamSynchronize(stream));
     }
-    ss.ncand = ncand;
-    const size_t slots = (size_t)(ncand ? ncand : 1) * S;
-    RE_HIP(grow(ss.pts, ss.cap_pts, sizeof(double) * 3 * slots));
-    RE_HIP(grow(ss.valid, ss.cap_valid, slots));
-    RE_HIP(hipMemsetAsync(ss.valid, 0, slots, stream));
-    RE_HIP(grow(ss.cnt, ss.cap_cnt, (size_t)(ncand ? ncand : 1)));
+    if (ss.cap_cand_e) RE_HIP(hipMemsetAsync(ss.valid, 0, (size_t)ss.cap_cand_e * S, stream));
     if (!clean) {
         RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
         RE_HIP(hipMemsetAsync(ss.bits, 0, sizeof(unsigned long long) * nwords, stream));
     }
-    if (ncand) {
-        const long long work = (long long)ncand * S;
+    if (ss.cap_cand_e) {
+        const long long work = (long long)want_cand * S;
         const unsigned gw = (unsigned)((work + 255) / 256 > 262144 ? 262144 : (work + 255) / 256);
-        RE_HIP(grow(ss.starts, ss.cap_starts, sizeof(unsigned long long) * (size_t)work));
-        hipLaunchKernelGGL(reinit_starts_kernel, dim3((gw + 3) / 4), dim3(256), 0, stream, a, ss.cand_cell, ss.cand_id, ncand, S, ss.starts, ss.counters + 4);
+        hipLaunchKernelGGL(reinit_starts_kernel, dim3((gw + 3) / 4), dim3(256), 0, stream, a, ss.cand_cell, ss.cand_id, ss.dc, S, ss.starts, ss.counters + 4);
         // the projection kernel walks the registered points with a stride (their number stays on the device: about a third of `work` in 3-D)
         const unsigned gs = gw / 2 + 1;
 #define LSM_SAMPLE(NV_, ND_) hipLaunchKernelGGL((reinit_sample_kernel<NV_, ND_>), dim3(gs), dim3(256), 0, stream, a, ss.cand_cell, ss.cand_id, S, ss.starts, \
@@ -1532,12 +1557,22 @@ static int build_samples(SampleSet& ss, long long total, hipStream_t stream, con
         else if (a.nv == 4) LSM_SAMPLE(4, 0);
         else LSM_SAMPLE(6, 0);
 #undef LSM_SAMPLE
-        hipLaunchKernelGGL(reinit_compact_kernel, dim3(S <= 32 ? (ncand + 7) / 8 : (ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ncand, S, ss.pts, ss.valid, ss.cnt,
-                           ss.blk, ss.bits);
+        hipLaunchKernelGGL(reinit_compact_kernel, dim3(S <= 32 ? (want_cand + 7) / 8 : (want_cand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ss.dc, S, ss.pts,
+                           ss.valid, ss.cnt, ss.blk, ss.bits);
     }
     hipLaunchKernelGGL(reinit_sup_kernel, dim3((unsigned)((nsupw + 3) / 4 > 65535 ? 65535 : (nsupw + 3) / 4)), dim3(256), 0, stream, a, ss.blk, ss.sup, (long long)nsupw);
     return 0;
 }
+// after the stream has been synchronised: did the band nodes and the candidate cells fit the buffers they were launched with?  Sets
+// ss.nwork / ss.ncand to the true counts either way.
+static bool samples_fit(SampleSet& ss, const unsigned cn[8]) {
+    const long long nodes = (long long)ss.a.n[0] * ss.a.n[1] * ss.a.n[2];
+    ss.nwork = ss.a.mask ? (long long)cn[3] : nodes;
+    ss.ncand = cn[5];
+    return (!ss.a.mask || cn[3] <= ss.cap_nodes_e) && cn[5] <= ss.cap_cand_e;
+}
+// what to size the buffers for, from what was needed last (the band drifts from call to call)
+static unsigned headroom(unsigned n) { return n ? (unsigned)std::min<unsigned long long>((unsigned long long)n + n / 8 + 256, 0xffffffffull) : 0u; }
 
 // returns 0 on success; out_counts = {samples kept, nodes whose solve did not converge, nodes with no sample at all}
 int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long long s2, long long origin, long long total, const double lc[3],
@@ -1553,64 +1588,75 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         return rc;
     };
     if (int r = setup_args(ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, phi, f32, mask, err)) return done(r);
-    if (int r = build_samples(ss, total, stream, err, wsp != nullptr)) return r;     // (build_samples released ss)
     const ReinitArgs& a = ss.a;
-    const int S = ss.S;
-    const long long nwork = ss.nwork;
-    if (nwork) {
-        if (grow(W.seeds, W.cap_seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return done(2); }
-        long long* seeds = W.seeds;
-        const unsigned gsr = (unsigned)((nwork + 255) / 256 > 262144 ? 262144 : (nwork + 255) / 256);
-        if (nwork > 0xffffffffll) { *err = "reinitialize: more than 2^32 nodes to evaluate"; if (wsp) ss.release(); return done(1); }
-        if (grow(W.retry, W.cap_retry, sizeof(unsigned) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(retry)"; ss.release(); return done(2); }
-        if (grow(W.foot, W.cap_foot, sizeof(long long) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(foot)"; ss.release(); return done(2); }
-        const long long grp_blocks = (nwork * GRP + 255) / 256;
-        const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
+    long long nc = 1;
+    for (int d = 0; d < ndim; ++d) nc *= n[d] - 1;
+    unsigned cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // One round = everything, launched without a host round trip: node list, candidate cells, samples, nearest samples, closest points,
+    // commit, un-marking.  The commit kernel leaves ϕ alone when a list did not fit; the round is then repeated with larger buffers
+    // (the first call on a workspace: one round to count the band, one to count the candidate cells, one that fits).
+    for (int round = 0;; ++round) {
+        if (int r = launch_samples(ss, total, stream, err, wsp != nullptr, std::max(headroom(W.last_nodes), ss.cap_nodes_e), std::max(headroom(W.last_cand), ss.cap_cand_e)))
+            return r;     // (launch_samples released ss)
+        const int S = ss.S;
+        const long long nwork = ss.cap_nodes_e;          // what the per-node buffers and grids are sized for
+        if (nwork) {
+            if (grow(W.seeds, W.cap_seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return done(2); }
+            if (grow(W.retry, W.cap_retry, sizeof(unsigned) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(retry)"; ss.release(); return done(2); }
+            if (grow(W.foot, W.cap_foot, sizeof(long long) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(foot)"; ss.release(); return done(2); }
+            long long* seeds = W.seeds;
+            const long long ngrid = a.mask ? (long long)std::max(headroom(W.last_nodes), 1u) : nwork;      // nodes expected
+            const unsigned gsr = (unsigned)((ngrid + 255) / 256 > 262144 ? 262144 : (ngrid + 255) / 256);
+            const long long grp_blocks = (ngrid * GRP + 255) / 256;
+            const dim3 gg((unsigned)(grp_blocks > 1048576 ? 1048576 : grp_blocks));
 #define LSM_BY_ND(KERNEL, GRID, ...) do { \
-        if (ndim == 3) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
-        else if (ndim == 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, stream, __VA_ARGS__); } while (0)
-#define LSM_NEWTON_K(NV_, ND_, PASS, GRID) hipLaunchKernelGGL((reinit_newton_kernel<NV_, ND_>), GRID, dim3(128), 0, stream, a, S, ss.pts, ss.node_list, nwork, seeds, out_field, \
+            if (ndim == 3) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
+            else if (ndim == 2) hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, stream, __VA_ARGS__); } while (0)
+#define LSM_NEWTON_K(NV_, ND_, PASS, GRID) hipLaunchKernelGGL((reinit_newton_kernel<NV_, ND_>), GRID, dim3(128), 0, stream, a, S, ss.pts, ss.node_list, ss.dn, seeds, out_field, \
                                                              ss.counters + 1, ss.counters + 2, W.retry, ss.counters + 6, PASS)
 #define LSM_NEWTON(PASS, GRID) do { \
-        if (a.nv == 4 && ndim == 3) LSM_NEWTON_K(4, 3, PASS, GRID); \
-        else if (a.nv == 4 && ndim == 2) LSM_NEWTON_K(4, 2, PASS, GRID); \
-        else if (a.nv == 2 && ndim == 3) LSM_NEWTON_K(2, 3, PASS, GRID); \
-        else if (a.nv == 2 && ndim == 2) LSM_NEWTON_K(2, 2, PASS, GRID); \
-        else if (a.nv == 2) LSM_NEWTON_K(2, 0, PASS, GRID); \
-        else if (a.nv == 4) LSM_NEWTON_K(4, 0, PASS, GRID); \
-        else LSM_NEWTON_K(6, 0, PASS, GRID); } while (0)
-        // nearest sample per node (exact); what the guided search cannot settle goes to the shell search
-        LSM_BY_ND(reinit_foot_kernel, dim3(gsr), a, ss.node_list, nwork, W.foot);
-        LSM_BY_ND(reinit_search_group_kernel, gg, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, nwork, W.foot, seeds);
-        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, nwork, seeds);
-        const unsigned gn = (unsigned)((nwork + 127) / 128 > 262144 ? 262144 : (nwork + 127) / 128);
-        LSM_NEWTON(0, dim3(gn));
-        // second pass for the nodes whose solve from the nearest sample did not converge (usually none: two short launches)
-        LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, nwork, seeds);
-        LSM_NEWTON(1, dim3(gn > 1024 ? 1024 : gn));
+            if (a.nv == 4 && ndim == 3) LSM_NEWTON_K(4, 3, PASS, GRID); \
+            else if (a.nv == 4 && ndim == 2) LSM_NEWTON_K(4, 2, PASS, GRID); \
+            else if (a.nv == 2 && ndim == 3) LSM_NEWTON_K(2, 3, PASS, GRID); \
+            else if (a.nv == 2 && ndim == 2) LSM_NEWTON_K(2, 2, PASS, GRID); \
+            else if (a.nv == 2) LSM_NEWTON_K(2, 0, PASS, GRID); \
+            else if (a.nv == 4) LSM_NEWTON_K(4, 0, PASS, GRID); \
+            else LSM_NEWTON_K(6, 0, PASS, GRID); } while (0)
+            // nearest sample per node (exact); what the guided search cannot settle goes to the shell search
+            LSM_BY_ND(reinit_foot_kernel, dim3(gsr), a, ss.node_list, ss.dn, W.foot);
+            LSM_BY_ND(reinit_search_group_kernel, gg, a, ss.cand_id, S, ss.pts, ss.cnt, ss.bits, ss.node_list, ss.dn, W.foot, seeds);
+            LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, ss.dn, seeds);
+            const unsigned gn = (unsigned)((ngrid + 127) / 128 > 262144 ? 262144 : (ngrid + 127) / 128);
+            LSM_NEWTON(0, dim3(gn));
+            // second pass for the nodes whose solve from the nearest sample did not converge (usually none: two short launches)
+            LSM_BY_ND(reinit_search_kernel, dim3(gsr), a, ss.cand_id, S, ss.pts, ss.cnt, ss.sup, ss.bits, ss.node_list, ss.dn, seeds);
+            LSM_NEWTON(1, dim3(gn > 1024 ? 1024 : gn));
 #undef LSM_NEWTON
 #undef LSM_NEWTON_K
 #undef LSM_BY_ND
-        hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((nwork + 255) / 256 > 65535 ? 65535 : (nwork + 255) / 256)), dim3(256), 0, stream, a,
-                           out_field, phi, ss.node_list, nwork);
+            hipLaunchKernelGGL(reinit_commit_kernel, dim3((unsigned)((ngrid + 255) / 256 > 65535 ? 65535 : (ngrid + 255) / 256)), dim3(256), 0, stream, a,
+                               out_field, phi, ss.node_list, ss.dn, ss.dc);
+        }
+        hipError_t e = hipMemcpyAsync(cn, ss.counters, sizeof(cn), hipMemcpyDeviceToHost, stream);
+        // a workspace serving a band goes back to its clean state by un-marking this round's candidate cells (behind everything that read
+        // them; cells beyond the buffers' capacity were never marked)
+        const bool restore = wsp && a.mask && e == hipSuccess;
+        if (restore) {
+            const unsigned gu = (std::max(headroom(W.last_cand), 256u) + 255) / 256;
+            hipLaunchKernelGGL(reinit_unmark_kernel, dim3(gu), dim3(256), 0, stream, a, ss.cand_cell, ss.dc, ss.cand_id, ss.blk, ss.bits);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { *err = "reinitialize: device error"; if (wsp) ss.release(); return done(2); }
+        if (restore) ss.clean_cells = nc;
+        const bool fit = samples_fit(ss, cn);
+        W.last_nodes = a.mask ? cn[3] : 0u;
+        W.last_cand = cn[5];
+        if (fit) break;
+        if (round >= 3) { *err = "reinitialize: the lists did not fit their buffers after four rounds"; if (wsp) ss.release(); return done(2); }
     }
-    unsigned cn[4] = {0, 0, 0, 0};
-    hipError_t e = hipMemcpyAsync(cn, ss.counters, sizeof(cn), hipMemcpyDeviceToHost, stream);
-    // a workspace serving a band goes back to its clean state by un-marking this call's candidate cells (behind everything that read them)
-    const bool restore = wsp && a.mask && e == hipSuccess;
-    if (restore && ss.ncand)
-        hipLaunchKernelGGL(reinit_unmark_kernel, dim3((ss.ncand + 255) / 256), dim3(256), 0, stream, a, ss.cand_cell, ss.ncand, ss.cand_id, ss.blk, ss.bits);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e == hipSuccess) e = hipGetLastError();
-    const unsigned ncand = ss.ncand;
-    if (e != hipSuccess) { *err = "reinitialize: device error"; if (wsp) ss.release(); return done(2); }
-    if (restore) {
-        long long nc = 1;
-        for (int d = 0; d < ndim; ++d) nc *= n[d] - 1;
-        ss.clean_cells = nc;
-    }
-    out_counts[0] = ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
+    out_counts[0] = ss.ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
     return done(0);
 }
 #undef RE_HIP
@@ -1812,7 +1858,18 @@ int sdf_build(int ndim, const int n[3], const int goff[3], long long s1, long lo
     if (int r = setup_args(o->ss.a, ndim, n, goff, s1, s2, origin, lc, h, order, upsample, maxiters, xtol, ftol, o->phi_copy, f32, o->mask_copy, err)) {
         (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); delete o; return r;
     }
-    if (int r = build_samples(o->ss, total, stream, err)) { (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); delete o; return r; }
+    // rounds of launch_samples until the node list and the candidate cells fit their buffers (a fresh object: two or three)
+    unsigned want_nodes = 0, want_cand = 0;
+    for (int round = 0;; ++round) {
+        if (int r = launch_samples(o->ss, total, stream, err, false, want_nodes, want_cand)) { (void)hipFree(o->phi_copy); (void)hipFree(o->mask_copy); delete o; return r; }
+        unsigned cn[8];
+        if (hipMemcpyAsync(cn, o->ss.counters, sizeof(cn), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return bail("candidate counts");
+        if (samples_fit(o->ss, cn)) break;
+        if (round >= 3) return bail("NewtonSDF: the lists did not fit their buffers after four rounds");
+        want_nodes = std::max(want_nodes, mask ? cn[3] : 0u);
+        want_cand = std::max(want_cand, cn[5]);
+    }
     unsigned long long* cnt = nullptr;
     unsigned long long hc = 0;
     if (hipMalloc((void**)&cnt, 8) != hipSuccess || hipMemsetAsync(cnt, 0, 8, stream) != hipSuccess) return bail("hipMalloc(count)");

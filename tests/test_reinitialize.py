@@ -139,6 +139,38 @@ def test_nodes_whose_first_solve_fails_take_the_second_pass(lsm, n, band):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(120, 120), (56, 56, 56)])
+def test_a_band_that_outgrows_the_previous_calls_buffers(lsm, n):
+    """A call is launched without waiting for its own counts: node list, candidate cells and samples go into buffers sized from the
+    previous call on the handle, and a call whose band no longer fits repeats itself with larger ones — ϕ untouched in between.  One
+    handle reinitialises a small circle, then (copy!) a band three times as long, then the small one again; every result is that
+    of a fresh handle, and a second call on the unchanged band (buffers now fit: one round) repeats the first."""
+    nd = len(n)
+    grid = lsm.CartesianGrid((-1.0,) * nd, (1.0,) * nd, n)
+
+    def band(r):
+        return _device_field(lsm, _field(n, lambda X: np.sqrt(sum(x ** 2 for x in X)) * 1.3 - 1.3 * r), grid, lsm.ExtrapolationBC(2), band_layers=3)
+
+    def fresh(r):
+        st = band(r).current_state()
+        lsm.reinitialize_(st)
+        return st.values(), st.active_mask()
+
+    small, big = fresh(0.22), fresh(0.75)
+    eq = band(0.22)
+    st = eq.current_state()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for r, (want, m) in ((0.22, small), (0.75, big), (0.75, big), (0.22, small)):
+            st.copy_(band(r).current_state())
+            lsm.reinitialize_(st)
+            assert (st.active_mask() == m).all()
+            assert np.abs(st.values()[m] - want[m]).max() < 1e-12, r
+            lsm.reinitialize_(st)          # ϕ is a distance function now: again, from the buffers that fit
+            assert np.abs(st.values()[m] - want[m]).max() < 1e-4     # (not idempotent: the interpolant of the new values differs at O(h^4))
+
+
+@pytest.mark.gpu
 def test_gpu_reference_tests_dense(lsm):
     """test/test-reinitializer.jl:71-100 through the host API: 2-D 100² (error < 2 sqrt(eps), volume preserved) and
     3-D 31³ with upsample 4 (error < 5e-3)."""
