@@ -446,7 +446,9 @@ int lsm_advance_band_rk3(LsmHandle* h, const LsmTerm* terms, int nterms, const L
  *      seed cell's Bernstein patch).  phi: ghosts filled (lsm_fill_ghosts) and, with a mask, the band halo
  *      filled (lsm_band_prepare); work: a field-sized scratch array.  order in 1..5.
  *      Out: candidate cells sampled, nodes whose solve did not converge (the reference warns), nodes left
- *      untouched because the field has no interface sample at all. */
+ *      untouched because the field has no interface sample at all.
+ *      The handle keeps the call's device buffers and sizes the next call's from them: a call is enqueued whole, synchronises the
+ *      stream once at its end, and repeats itself when the band has outgrown the buffers (ϕ is written by the last round only). */
 int lsm_reinitialize(LsmHandle* h, void* phi, const void* mask, void* work, int order, int upsample, int maxiters,
                      double xtol, double ftol, int64_t* ncandidate_cells, int64_t* nfail, int64_t* nfar);
 
