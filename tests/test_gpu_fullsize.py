@@ -313,3 +313,38 @@ def test_768_cubed_config5_float32_band_is_symmetric_and_matches_the_dense_run(l
         d_deep = max(d_deep, float(np.abs(b64[deep] - d64[deep]).max()))
         d_near = max(d_near, float(np.abs(b64[near] - d64[near]).max()))
     assert n_deep > 1.0e5 and n_near > 3.0e4 and d_deep <= 1e-6 and d_near <= 1e-5, (n_deep, n_near, d_deep, d_near)
+
+
+def test_768_cubed_config5_band_reinitialize_is_symmetric_and_a_distance(lsm):
+    """`reinitialize!` at config 5's size (768³, float32 storage, nlayers = 3: 3.7 M band nodes, the workload of
+    `bench.py --config 5r`), from a field that is NOT a distance function (x² + y² + z² − ¼, |∇ϕ| = 1 on the interface only):
+      * every band node ends at sign(ϕ)·distance to the sphere r = ½ — to 1e-6 with the solver's tolerances at 1e-9 (their default
+        is √eps of the storage type: 3.5e-4 for float32, src/sdf.jl:66-67), where the input was off by more than 1e-4;
+      * the reflections of the three axes and x <-> y map the result onto itself to the last bit of its float32 values but for
+        ties: the exact nearest sample of two mirror nodes are mirror samples, the solves start from them — 1e-7;
+      * nothing was left unconverged or without a sample, and the band itself is untouched."""
+    import warnings
+    n = 768
+    grid = lsm.CartesianGrid((-1, -1, -1), (1, 1, 1), (n, n, n))
+    ax = np.linspace(-1.0, 1.0, n)
+    ax = 0.5 * (ax - ax[::-1])                           # exactly antisymmetric coordinates
+    r2 = (ax ** 2)[:, None, None] + (ax ** 2)[None, :, None] + (ax ** 2)[None, None, :]
+    phi0 = np.asfortranarray((r2 - 0.25).astype(np.float32))
+    del r2
+    eq = lsm.LevelSetEquation(terms=(lsm.NormalMotionTerm(0.0),), ic=lsm.NarrowBandMeshField(lsm.MeshField(phi0, grid, dtype=np.float32), nlayers=3),
+                              bc=lsm.NeumannBC())
+    st = eq.current_state()
+    m0 = st.active_mask()
+    assert 3.0e6 < m0.sum() < 4.5e6
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                   # a non-converged node or a node without samples warns
+        lsm.reinitialize_(st, xtol=1e-9, ftol=1e-9)
+    assert np.array_equal(st.active_mask(), m0)
+    v = st.values()
+    idx = np.nonzero(m0)
+    got = v[idx].astype(np.float64)
+    exact = np.sqrt(ax[idx[0]] ** 2 + ax[idx[1]] ** 2 + ax[idx[2]] ** 2) - 0.5
+    assert np.abs(phi0[idx] - exact).max() > 1e-4        # the input was not a distance function
+    assert np.abs(got - exact).max() < 1e-6
+    for mirror in (v[::-1, :, :], v[:, ::-1, :], v[:, :, ::-1], v.transpose(1, 0, 2)):
+        assert np.abs(mirror[idx].astype(np.float64) - got).max() < 1e-7
