@@ -1469,9 +1469,11 @@ static int setup_args(ReinitArgs& a, int ndim, const int n[3], const int goff[3]
 // Candidate cells -> interface samples -> per-cell counts, occupancy bits, blocks and super-blocks (steps 1 and 2 above) — launched
 // without waiting for anything: the number of band nodes and of candidate cells stay on the device (DevCount), the buffers are sized
 // for `want_nodes` / `want_cand` entries (what the previous call needed, with headroom) and the caller checks afterwards whether
-// both fitted (samples_fit) — if not it launches again with what it has learnt; a first call takes up to three rounds.  ss.a is set.
+// both fitted (samples_fit) — if not it launches again with what it has learnt.  `count_only`: stop behind the candidate-cell test
+// (a first call: nothing is known yet, the rest of the round would work on a handful of cells).  ss.a is set.
 // `keep_clean`: ss is a workspace whose cand_id / bits / blk are restored by the caller after the call (band fields only).
-static int launch_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err, bool keep_clean, unsigned want_nodes, unsigned want_cand) {
+static int launch_samples(SampleSet& ss, long long total, hipStream_t stream, const char** err, bool keep_clean, unsigned want_nodes, unsigned want_cand,
+                          bool count_only = false) {
     const ReinitArgs& a = ss.a;
     const int ndim = a.ndim;
     const int* n = a.n;
@@ -1538,6 +1540,7 @@ static int launch_samples(SampleSet& ss, long long total, hipStream_t stream, co
         else LSM_CELLS2(0, 0, 0);
 #undef LSM_CELLS2
     }
+    if (count_only) return 0;          // the caller wants the two counts first (nothing is known about this field yet)
     if (ss.cap_cand_e) RE_HIP(hipMemsetAsync(ss.valid, 0, (size_t)ss.cap_cand_e * S, stream));
     if (!clean) {
         RE_HIP(hipMemsetAsync(ss.blk, 0, nblk, stream));
@@ -1596,11 +1599,14 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
     // commit, un-marking.  The commit kernel leaves ϕ alone when a list did not fit; the round is then repeated with larger buffers
     // (the first call on a workspace: one round to count the band, one to count the candidate cells, one that fits).
     for (int round = 0;; ++round) {
-        if (int r = launch_samples(ss, total, stream, err, wsp != nullptr, std::max(headroom(W.last_nodes), ss.cap_nodes_e), std::max(headroom(W.last_cand), ss.cap_cand_e)))
+        // nothing known about the band or about its candidate cells (the first call on the handle): a round that only counts them
+        const bool count_only = (a.mask && W.last_nodes == 0) || W.last_cand == 0;
+        if (int r = launch_samples(ss, total, stream, err, wsp != nullptr, std::max(headroom(W.last_nodes), ss.cap_nodes_e), std::max(headroom(W.last_cand), ss.cap_cand_e),
+                                   count_only))
             return r;     // (launch_samples released ss)
         const int S = ss.S;
         const long long nwork = ss.cap_nodes_e;          // what the per-node buffers and grids are sized for
-        if (nwork) {
+        if (nwork && !count_only) {
             if (grow(W.seeds, W.cap_seeds, sizeof(long long) * NSEED * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(seeds)"; ss.release(); return done(2); }
             if (grow(W.retry, W.cap_retry, sizeof(unsigned) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(retry)"; ss.release(); return done(2); }
             if (grow(W.foot, W.cap_foot, sizeof(long long) * (size_t)nwork) != hipSuccess) { *err = "hipMalloc(foot)"; ss.release(); return done(2); }
@@ -1651,10 +1657,15 @@ int reinit_run(int ndim, const int n[3], const int goff[3], long long s1, long l
         if (e != hipSuccess) { *err = "reinitialize: device error"; if (wsp) ss.release(); return done(2); }
         if (restore) ss.clean_cells = nc;
         const bool fit = samples_fit(ss, cn);
+        const bool nodes_fit = !a.mask || cn[3] <= ss.cap_nodes_e;
         W.last_nodes = a.mask ? cn[3] : 0u;
-        W.last_cand = cn[5];
-        if (fit) break;
-        if (round >= 3) { *err = "reinitialize: the lists did not fit their buffers after four rounds"; if (wsp) ss.release(); return done(2); }
+        W.last_cand = nodes_fit ? cn[5] : 0u;         // (counted over a truncated node list: not the field's)
+        if (fit && !count_only) break;
+        if (count_only && nodes_fit && cn[5] == 0) {           // no candidate cell at all: ϕ stays, every node is one "without a sample"
+            cn[1] = 0; cn[2] = (unsigned)ss.nwork;
+            break;
+        }
+        if (round >= 4) { *err = "reinitialize: the lists did not fit their buffers after five rounds"; if (wsp) ss.release(); return done(2); }
     }
     out_counts[0] = ss.ncand; out_counts[1] = cn[1]; out_counts[2] = cn[2];
     return done(0);
